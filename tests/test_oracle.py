@@ -1,0 +1,154 @@
+"""The oracle checked against itself (fp64 finite differences), analytic known answers and an
+independent torch-CPU autograd implementation.  The reference holds no golden vectors for this
+path, so this is what "pinning" is available -- see oracle/gcn_oracle.py header."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from geographconv_amd import synth
+from oracle import gcn_oracle as O
+
+
+def _tiny(N=40, V=30, C=5, hid=(8, 8, 8), highway=True, seed=0, dtype=np.float64):
+    A, X, Y = synth.small_graph(N, 3.0, V, 6, C, seed=seed, empty_rows=2)
+    params = O.random_params(V, list(hid), C, highway, seed=seed + 5, dtype=dtype, scale=0.6)
+    tr = np.arange(0, N // 2, dtype=np.int32)
+    dev = np.arange(N // 2, 3 * N // 4, dtype=np.int32)
+    rng = np.random.RandomState(seed + 9)
+    mask = (rng.rand(N, hid[0]) < 0.5).astype(dtype)
+    return A, X, Y, params, tr, dev, mask
+
+
+def _loss(params, A, X, Y, tr, hid, highway, p, mask, reg):
+    c = O.forward(params, X, A, hid, highway, p, mask, deterministic=False, dtype=np.float64)
+    l, _, _ = O.metrics(c['P'], tr, Y[tr])
+    return l + O.reg_penalty(params, hid, highway, reg)
+
+
+@pytest.mark.parametrize("highway,p,reg", [(True, 0.5, 0.0), (False, 0.0, 0.0), (True, 0.0, 1e-3)])
+def test_backward_matches_fp64_finite_differences(highway, p, reg):
+    hid = [8, 8, 8] if highway else [8, 6, 7]
+    A, X, Y, params, tr, dev, mask = _tiny(hid=hid, highway=highway)
+    c = O.forward(params, X, A, hid, highway, p, mask, deterministic=False, dtype=np.float64)
+    grads = O.backward(params, c, X, A, tr, Y[tr], hid, highway, reg, dtype=np.float64)
+    rng = np.random.RandomState(1)
+    eps = 1e-6
+    for pi, (p_arr, g) in enumerate(zip(params, grads)):
+        assert g.shape == p_arr.shape
+        for _ in range(6):
+            idx = tuple(rng.randint(0, s) for s in p_arr.shape)
+            if pi == 0 and X[:, idx[0]].nnz == 0:
+                continue
+            old = p_arr[idx]
+            p_arr[idx] = old + eps
+            lp = _loss(params, A, X, Y, tr, hid, highway, p, mask, reg)
+            p_arr[idx] = old - eps
+            lm = _loss(params, A, X, Y, tr, hid, highway, p, mask, reg)
+            p_arr[idx] = old
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - g[idx]) <= 1e-6 * max(1.0, abs(fd)) + 1e-8, (pi, idx, fd, g[idx])
+
+
+@pytest.mark.parametrize("highway", [True, False])
+def test_against_torch_autograd(highway):
+    torch = pytest.importorskip("torch")
+    hid = [8, 8, 8] if highway else [8, 6, 7]
+    A, X, Y, params, tr, dev, mask = _tiny(hid=hid, highway=highway)
+    p = 0.5
+    c = O.forward(params, X, A, hid, highway, p, mask, deterministic=False, dtype=np.float64)
+    grads = O.backward(params, c, X, A, tr, Y[tr], hid, highway, 0.0, dtype=np.float64)
+    tp = [torch.tensor(q, dtype=torch.float64, requires_grad=True) for q in params]
+    At = torch.tensor(A.toarray(), dtype=torch.float64)
+    Xt = torch.tensor(X.toarray(), dtype=torch.float64)
+    H = torch.tanh(Xt @ tp[0] + tp[1]) * torch.tensor(mask) / (1 - p)
+    k = 2
+    for _ in range(len(hid) - 1):
+        if highway:
+            Wt, bt, Wh, bh = tp[k:k + 4]
+            k += 4
+            Hc = torch.tanh(At @ (H @ Wh) + bh)
+            T = torch.sigmoid(H @ Wt + bt)
+            H = T * Hc + (1 - T) * H
+        else:
+            Wi, bi = tp[k:k + 2]
+            k += 2
+            H = torch.tanh(At @ (H @ Wi) + bi)
+    P = torch.softmax(At @ (H @ tp[k]) + tp[k + 1], dim=1)
+    assert np.allclose(P.detach().numpy(), c['P'], rtol=1e-10, atol=1e-12)
+    loss = -torch.log(P[torch.tensor(tr, dtype=torch.long), torch.tensor(Y[tr], dtype=torch.long)]).mean()
+    loss.backward()
+    for q, g in zip(tp, grads):
+        assert np.allclose(q.grad.numpy(), g, rtol=1e-8, atol=1e-12)
+
+
+def test_identity_graph_is_dense_mlp():
+    A, X, Y, params, tr, dev, mask = _tiny(hid=[8, 8], highway=False)
+    I = sps.identity(X.shape[0], dtype=np.float64, format='csr')
+    c = O.forward(params, X, I, [8, 8], False, dtype=np.float64)
+    Xd = X.toarray().astype(np.float64)
+    H = np.tanh(Xd @ params[0] + params[1])
+    H = np.tanh(H @ params[2] + params[3])
+    P = O.softmax_rows(H @ params[4] + params[5])
+    assert np.allclose(c['P'], P, rtol=1e-12, atol=1e-14)
+    assert np.allclose(c['P'].sum(axis=1), 1.0)
+
+
+def test_gate_closed_form_and_uniform_ce():
+    # Wt = 0, bt = -4  =>  T = sigma(-4) everywhere (highway_dense default gcnmodel.py:274)
+    A, X, Y, params, tr, dev, mask = _tiny(hid=[8, 8], highway=True)
+    params[2][:] = 0
+    params[3][:] = -4.0
+    c = O.forward(params, X, A, [8, 8], True, dtype=np.float64)
+    assert np.allclose(c['blocks'][0]['T'], 0.01798620996209156)
+    # zero output layer => uniform probs => CE = log C
+    params[-2][:] = 0
+    params[-1][:] = 0
+    c = O.forward(params, X, A, [8, 8], True, dtype=np.float64)
+    l, _, _ = O.metrics(c['P'], tr, Y[tr])
+    assert abs(l - np.log(5)) < 1e-12
+
+
+def test_lasagne_adam_three_steps_hand_computed():
+    # lasagne.updates.adam, SURVEY.md A.4: a_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= a_t*m/(sqrt(v)+eps)
+    p = [np.array([1.0, -2.0])]
+    st = O.AdamState(p)
+    lr, b1, b2, eps = 2e-3, 0.9, 0.999, 1e-8
+    m = np.zeros(2)
+    v = np.zeros(2)
+    ref = p[0].copy()
+    for t in range(1, 4):
+        g = 2 * ref                      # d/dp of p^2
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        a = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ref = ref - a * m / (np.sqrt(v) + eps)
+        p = O.adam_step(p, [2 * p[0]], st, lr, b1, b2, eps)
+        assert np.allclose(p[0], ref, rtol=1e-14)
+    # first step moves each coordinate by ~lr regardless of gradient scale
+    assert st.t == 3
+
+
+def test_fp32_vs_fp64_envelope_defines_tolerance():
+    """Derives the tolerance the GPU parity tests state: fp32 oracle vs fp64 oracle."""
+    s = synth.CMU
+    A, X, Y = synth.small_graph(2000, 7.0, 500, 30, 20, seed=3)
+    hid = [300, 300, 300]
+    params = O.random_params(500, hid, 20, True, seed=1)
+    c32 = O.forward(params, X, A, hid, True, dtype=np.float32)
+    c64 = O.forward(params, X, A, hid, True, dtype=np.float64)
+    err = np.abs(c32['logits'] - c64['logits']).max()
+    assert err < 2e-5, err
+    assert np.abs(c32['P'] - c64['P']).max() < 1e-6
+
+
+def test_f_train_dev_metrics_use_dropout_pass():
+    A, X, Y, params, tr, dev, mask = _tiny(hid=[8, 8, 8], highway=True, dtype=np.float32)
+    st = O.AdamState(params)
+    newp, outs, grads = O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, [8, 8, 8], True, 0.5,
+                                  mask.astype(np.float32))
+    c = O.forward(params, X, A, [8, 8, 8], True, 0.5, mask, deterministic=False)
+    l_dev, a_dev, _ = O.metrics(c['P'], dev, Y[dev])
+    assert outs[2] == l_dev and outs[3] == a_dev
+    assert outs[4].shape == (X.shape[0], 5)
+    pred, probs = O.f_val(newp, X, A, dev, [8, 8, 8], True)
+    assert pred.dtype == np.int64 and probs.shape == (len(dev), 5)

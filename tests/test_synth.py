@@ -1,0 +1,43 @@
+"""Pinned generators reproduce SURVEY.md §8d (CRC32 of the index arrays)."""
+import numpy as np
+
+from geographconv_amd import synth
+
+
+def test_cmu_pinned():
+    s = synth.CMU
+    A = synth.powerlaw_ahat(s.N, s.E_target)
+    X = synth.bow_x(s.N, s.V, s.mean_nnz)
+    assert synth.check_pinned('cmu', 'A', A)
+    assert synth.check_pinned('cmu', 'X', X)
+    assert A.dtype == np.float32 and A.indices.dtype == np.int32 and A.indptr.dtype == np.int32
+    # reference gcnmain.py:115-128 with unit weights gives an exactly symmetric float32 matrix
+    assert abs(A - A.T).max() == 0.0
+    assert abs(A.data.astype(np.float64).sum() - 8008.101088) < 1e-5
+    assert abs(X.data.astype(np.float64).sum() - 70417.157366) < 1e-5
+    # rows of X are L2 normalised (data.py:276-278)
+    rn = np.sqrt(np.asarray(X.multiply(X).sum(axis=1)).ravel())
+    assert np.allclose(rn, 1.0, atol=1e-6)
+
+
+def test_normalize_star_graph_closed_form():
+    import scipy.sparse as sps
+    n = 6
+    A = sps.lil_matrix((n, n))
+    for j in range(1, n):
+        A[0, j] = 1
+        A[j, 0] = 1
+    A.setdiag(1)
+    Ah = synth.normalize_adjacency(A.tocsr()).toarray()
+    d = np.array([n] + [2] * (n - 1), dtype=np.float64)
+    for i in range(n):
+        for j in range(n):
+            if Ah[i, j] != 0:
+                assert abs(Ah[i, j] - 1 / np.sqrt(d[i] * d[j])) < 1e-7
+
+
+def test_normalize_zero_degree_row():
+    import scipy.sparse as sps
+    A = sps.csr_matrix(np.array([[1, 1, 0], [1, 1, 0], [0, 0, 0]], dtype=np.float64))
+    Ah = synth.normalize_adjacency(A).toarray()
+    assert np.all(np.isfinite(Ah)) and np.all(Ah[2] == 0)     # inf -> 0 (gcnmain.py:125)
