@@ -1,0 +1,96 @@
+"""ctypes binding of libgeogcn.so (include/geogcn.h).  No torch types cross this boundary: the
+callers in ops.py pass ``tensor.data_ptr()`` integers and the raw hipStream_t of torch's current
+stream.  There is NO fallback: if the library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgeogcn.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'geogcn.h')
+
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+
+c_i32, c_i64, c_f32, c_sz, c_ptr = C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_void_p
+c_u64 = C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/geogcn.h one to one
+SIGNATURES = {
+    'geogcn_version': (c_i32, []),
+    'geogcn_last_error': (C.c_char_p, []),
+    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
+    'geogcn_spmm_plan_destroy': (None, [c_ptr]),
+    'geogcn_spmm_plan_num_long_rows': (c_i64, [c_ptr]),
+    'geogcn_spmm_plan_num_chunks': (c_i64, [c_ptr]),
+    'geogcn_spmm_workspace_bytes': (c_sz, [c_ptr, c_i32]),
+    'geogcn_spmm_csr_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                    c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_gemm_workspace_bytes': (c_sz, [c_i32, c_i32, c_i64, c_i64, c_i64]),
+    'geogcn_gemm_f32': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
+                                c_i64, c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
+    'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
+                                       c_ptr, c_ptr]),
+    'geogcn_tanh_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr]),
+    'geogcn_colsum_workspace_bytes': (c_sz, [c_i64, c_i32]),
+    'geogcn_colsum_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_sz, c_ptr]),
+    'geogcn_dropout_mask_philox': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_u64, c_ptr, c_ptr]),
+    'geogcn_dropout_apply_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr]),
+    'geogcn_softmax_rows_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
+    'geogcn_ce_metrics_workspace_bytes': (c_sz, [c_i64]),
+    'geogcn_ce_metrics_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                                      c_sz, c_ptr]),
+    'geogcn_softmax_ce_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                          c_ptr]),
+    'geogcn_gather_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
+                                     c_i32, c_f32, c_f32, c_ptr]),
+    'geogcn_reg_penalty_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_sz, c_ptr]),
+}
+
+
+def header_symbols():
+    """Every function name include/geogcn.h declares."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(geogcn_[a-z0-9_]+)\s*\(', text)))
+
+
+class GeoGcnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libgeogcn.so (once).  torch is imported first so that the library resolves
+    libamdhip64.so.7 to the SAME HIP runtime torch already loaded (one runtime per process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GeoGcnError(
+            "libgeogcn.so not found at %s -- build it with `python -m geographconv_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the GCN hot path." % LIB_PATH)
+    import torch  # noqa: F401  (loads the HIP runtime)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.geogcn_version() != 1:
+        raise GeoGcnError("libgeogcn.so ABI version %d != 1" % handle.geogcn_version())
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib().geogcn_last_error().decode('utf-8', 'replace')
+        kind = 'argument error' if rc < 0 else 'hipError'
+        raise GeoGcnError("%s failed (%s %d): %s" % (what or 'geogcn call', kind, rc, msg))

@@ -1,0 +1,60 @@
+// Shared host-side helpers for libgeogcn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/geogcn.h"
+
+namespace geogcn {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kNumXCD = 8;
+
+void set_error(const char* fmt, ...);
+
+#define GEOGCN_REQUIRE(cond, code, ...)             \
+    do {                                            \
+        if (!(cond)) {                              \
+            geogcn::set_error(__VA_ARGS__);         \
+            return (code);                          \
+        }                                           \
+    } while (0)
+
+// launch check: kernel launch errors surface through hipGetLastError (no sync)
+#define GEOGCN_LAUNCH_CHECK(name)                                              \
+    do {                                                                       \
+        hipError_t e__ = hipGetLastError();                                    \
+        if (e__ != hipSuccess) {                                               \
+            geogcn::set_error("%s: %s", name, hipGetErrorString(e__));         \
+            return (int)e__;                                                   \
+        }                                                                      \
+    } while (0)
+
+#define GEOGCN_HIP(call)                                                       \
+    do {                                                                       \
+        hipError_t e__ = (call);                                               \
+        if (e__ != hipSuccess) {                                               \
+            geogcn::set_error("%s: %s", #call, hipGetErrorString(e__));        \
+            return (int)e__;                                                   \
+        }                                                                      \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// device-side activation shared by SpMM / GEMM / elementwise epilogues
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+    if constexpr (ACT == GEOGCN_ACT_TANH) {
+        return tanhf(x);
+    } else if constexpr (ACT == GEOGCN_ACT_SIGMOID) {
+        return 1.0f / (1.0f + expf(-x));
+    } else {
+        return x;
+    }
+}
+
+}  // namespace geogcn

@@ -1,0 +1,355 @@
+// Streaming elementwise / reduction kernels of the GCN hot path (gfx950): the work Theano runs
+// as fused Elemwise / Sum{axis=0} / AdvancedSubtensor1 / MRG binomial C thunks.
+//   highway mix + gradients        reference gcnmodel.py:252-266, :268-288
+//   bias + nonlinearity            reference gcnmodel.py:41-42, :132-136, :155-157
+//   dropout                        reference gcnmodel.py:357 (lasagne DropoutLayer)
+// All are HBM-bound: 16-byte accesses, grid-stride over (row, float4) with the pad columns
+// [F, ld) written as zero, no LDS staging (no reuse to capture).
+#include "common.h"
+
+#include <algorithm>
+
+namespace geogcn {
+namespace {
+
+constexpr int TPB = 256;
+
+inline unsigned stream_grid(int64_t work_items) {
+    // ~8 blocks of 256 threads per CU is enough to saturate HBM; grid-stride the rest
+    const int64_t blocks = cdiv(work_items, TPB);
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)kNumCU * 8));
+}
+
+struct Idx2 {
+    int64_t row;
+    int q;       // float4 index within the row
+};
+
+__device__ __forceinline__ float4 mask_pad(float4 v, int col0, int F) {
+    if (col0 + 3 < F) return v;
+    if (col0 + 0 >= F) v.x = 0.f;
+    if (col0 + 1 >= F) v.y = 0.f;
+    if (col0 + 2 >= F) v.z = 0.f;
+    v.w = 0.f;
+    return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(TPB) void bias_act_kernel(int64_t n, int F, int F4, const float* __restrict__ X,
+                                                       int64_t ldx, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int64_t ldy) {
+    const int64_t total = n * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t row = e / F4;
+        const int q = (int)(e - row * F4);
+        const int c0 = q * 4;
+        float4 v = *reinterpret_cast<const float4*>(X + row * ldx + c0);
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (c0 + i < F) {
+                float x = o[i];
+                if (bias) x += bias[c0 + i];
+                o[i] = apply_act<ACT>(x);
+            } else {
+                o[i] = 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(Y + row * ldy + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Hout = T*Hc + (1-T)*H   (gcnmodel.py:266, same association as the reference expression)
+__global__ __launch_bounds__(TPB) void highway_fwd_kernel(int64_t total4, const float4* __restrict__ T,
+                                                          const float4* __restrict__ Hc,
+                                                          const float4* __restrict__ H, float4* __restrict__ Out) {
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total4; e += (int64_t)gridDim.x * TPB) {
+        const float4 t = T[e], hc = Hc[e], h = H[e];
+        float4 o;
+        o.x = t.x * hc.x + (1.0f - t.x) * h.x;
+        o.y = t.y * hc.y + (1.0f - t.y) * h.y;
+        o.z = t.z * hc.z + (1.0f - t.z) * h.z;
+        o.w = t.w * hc.w + (1.0f - t.w) * h.w;
+        Out[e] = o;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t total4, const float4* __restrict__ G,
+                                                          const float4* __restrict__ T, const float4* __restrict__ Hc,
+                                                          const float4* __restrict__ H, float4* __restrict__ dS,
+                                                          float4* __restrict__ dU, float4* __restrict__ dHc) {
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total4; e += (int64_t)gridDim.x * TPB) {
+        const float4 g = G[e], t = T[e], hc = Hc[e], h = H[e];
+        float4 s, u, c;
+#define GEOGCN_HW(m)                                   \
+    s.m = (g.m * t.m) * (1.0f - hc.m * hc.m);          \
+    u.m = ((g.m * (hc.m - h.m)) * t.m) * (1.0f - t.m); \
+    c.m = g.m * (1.0f - t.m);
+        GEOGCN_HW(x) GEOGCN_HW(y) GEOGCN_HW(z) GEOGCN_HW(w)
+#undef GEOGCN_HW
+        dS[e] = s;
+        dU[e] = u;
+        dHc[e] = c;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void tanh_bwd_kernel(int64_t n, int F, int F4, const float* __restrict__ G,
+                                                       const float* __restrict__ Y, int64_t ld,
+                                                       const uint8_t* __restrict__ mask, float scale,
+                                                       float* __restrict__ dS) {
+    const int64_t total = n * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t row = e / F4;
+        const int q = (int)(e - row * F4);
+        const int c0 = q * 4;
+        const float4 g = *reinterpret_cast<const float4*>(G + row * ld + c0);
+        const float4 y = *reinterpret_cast<const float4*>(Y + row * ld + c0);
+        float go[4] = {g.x, g.y, g.z, g.w};
+        const float yo[4] = {y.x, y.y, y.z, y.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float gg = go[i];
+            if (mask) gg = (c0 + i < F) ? gg * ((float)mask[row * F + c0 + i] * scale) : 0.f;
+            o[i] = gg * (1.0f - yo[i] * yo[i]);
+        }
+        *reinterpret_cast<float4*>(dS + row * ld + c0) = mask_pad(make_float4(o[0], o[1], o[2], o[3]), c0, F);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void dropout_apply_kernel(int64_t n, int F, int F4, const float* __restrict__ X,
+                                                            int64_t ld, const uint8_t* __restrict__ mask,
+                                                            float scale, float* __restrict__ Y) {
+    const int64_t total = n * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t row = e / F4;
+        const int q = (int)(e - row * F4);
+        const int c0 = q * 4;
+        const float4 x = *reinterpret_cast<const float4*>(X + row * ld + c0);
+        const float xo[4] = {x.x, x.y, x.z, x.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = (c0 + i < F) ? xo[i] * ((float)mask[row * F + c0 + i] * scale) : 0.f;
+        *reinterpret_cast<float4*>(Y + row * ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = element index / 4, key = seed ------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+}
+
+__global__ __launch_bounds__(TPB) void dropout_mask_kernel(int64_t total, float keep_prob, uint64_t seed,
+                                                           uint64_t offset, uint8_t* __restrict__ mask) {
+    const int64_t quads = (total + 3) / 4;
+    for (int64_t qd = (int64_t)blockIdx.x * TPB + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * TPB) {
+        const uint64_t ctr = (uint64_t)qd + offset;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t e = qd * 4 + i;
+            if (e < total) {
+                const float u = (float)(c[i] >> 8) * (1.0f / 16777216.0f);   // 24-bit uniform [0,1)
+                mask[e] = (u < keep_prob) ? 1 : 0;
+            }
+        }
+    }
+}
+
+// ---- column sums: pass 1 = per row-chunk partials, pass 2 = partials added in chunk order ----------
+__global__ __launch_bounds__(TPB) void colsum_partial_kernel(int64_t n, int F, const float* __restrict__ X,
+                                                             int64_t ldx, int64_t rows_per_block,
+                                                             float* __restrict__ P) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(n, r0 + rows_per_block);
+    for (int col = threadIdx.x; col < F; col += TPB) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            a0 += X[(r + 0) * ldx + col];
+            a1 += X[(r + 1) * ldx + col];
+            a2 += X[(r + 2) * ldx + col];
+            a3 += X[(r + 3) * ldx + col];
+        }
+        for (; r < r1; ++r) a0 += X[r * ldx + col];
+        P[(int64_t)blockIdx.x * F + col] = (a0 + a1) + (a2 + a3);
+    }
+}
+__global__ __launch_bounds__(TPB) void colsum_final_kernel(int nparts, int F, const float* __restrict__ P,
+                                                           float* __restrict__ out) {
+    const int col = blockIdx.x * TPB + threadIdx.x;
+    if (col >= F) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += P[(int64_t)p * F + col];
+    out[col] = a;
+}
+
+__global__ __launch_bounds__(TPB) void gather_rows_kernel(int F, const float* __restrict__ X, int64_t ldx,
+                                                          const int* __restrict__ idx, int64_t n_idx,
+                                                          float* __restrict__ out, int64_t ldo) {
+    const int64_t total = n_idx * F;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t j = e / F;
+        const int col = (int)(e - j * F);
+        out[j * ldo + col] = X[(int64_t)idx[j] * ldx + col];
+    }
+}
+
+int64_t colsum_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(n, 64))); }
+
+}  // namespace
+}  // namespace geogcn
+
+using namespace geogcn;
+
+#define CHECK_VEC(name, ld, ...)                                                                      \
+    do {                                                                                              \
+        const void* ptrs__[] = {__VA_ARGS__};                                                         \
+        for (const void* p__ : ptrs__)                                                                \
+            GEOGCN_REQUIRE(p__ && aligned16(p__), p__ ? GEOGCN_E_ALIGN : GEOGCN_E_NULL,               \
+                           name ": null or misaligned pointer");                                      \
+        GEOGCN_REQUIRE((ld) % 4 == 0 && (ld) >= (int64_t)((F + 3) / 4) * 4, GEOGCN_E_ALIGN,           \
+                       name ": ld=%lld must be a multiple of 4 and >= roundup4(F=%d)", (long long)(ld), F); \
+    } while (0)
+
+extern "C" {
+
+int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const float* bias, int32_t act,
+                        float* Y, int64_t ldy, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "bias_act_f32: negative size");
+    if (n == 0 || F == 0) return 0;
+    CHECK_VEC("bias_act_f32", ldx, X, Y);
+    CHECK_VEC("bias_act_f32", ldy, X, Y);
+    const int F4 = (F + 3) / 4;
+    const dim3 grid(stream_grid(n * F4));
+    hipStream_t st = (hipStream_t)stream;
+    if (act == GEOGCN_ACT_TANH)
+        hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_TANH>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
+    else if (act == GEOGCN_ACT_SIGMOID)
+        hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_SIGMOID>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
+    else if (act == GEOGCN_ACT_NONE)
+        hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_NONE>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
+    else {
+        set_error("bias_act_f32: unknown act %d", act);
+        return GEOGCN_E_ARG;
+    }
+    GEOGCN_LAUNCH_CHECK("bias_act_kernel");
+    return 0;
+}
+
+int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc, const float* H, int64_t ld,
+                           float* Hout, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "highway_fwd_f32: negative size");
+    if (n == 0 || F == 0) return 0;
+    CHECK_VEC("highway_fwd_f32", ld, T, Hc, H, Hout);
+    // operands share one pitch and keep zero pads, so the matrices are processed as flat arrays
+    const int64_t total4 = n * ld / 4;
+    hipLaunchKernelGGL(highway_fwd_kernel, dim3(stream_grid(total4)), dim3(TPB), 0, (hipStream_t)stream, total4,
+                       (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)Hout);
+    GEOGCN_LAUNCH_CHECK("highway_fwd_kernel");
+    return 0;
+}
+
+int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
+                           int64_t ld, float* dS, float* dU, float* dHcarry, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "highway_bwd_f32: negative size");
+    if (n == 0 || F == 0) return 0;
+    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU, dHcarry);
+    const int64_t total4 = n * ld / 4;
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(stream_grid(total4)), dim3(TPB), 0, (hipStream_t)stream, total4,
+                       (const float4*)G, (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS,
+                       (float4*)dU, (float4*)dHcarry);
+    GEOGCN_LAUNCH_CHECK("highway_bwd_kernel");
+    return 0;
+}
+
+int geogcn_tanh_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, const uint8_t* keep_mask,
+                        float scale, float* dS, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "tanh_bwd_f32: negative size");
+    if (n == 0 || F == 0) return 0;
+    CHECK_VEC("tanh_bwd_f32", ld, G, Y, dS);
+    const int F4 = (F + 3) / 4;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(stream_grid(n * F4)), dim3(TPB), 0, (hipStream_t)stream, n, F, F4, G, Y,
+                       ld, keep_mask, scale, dS);
+    GEOGCN_LAUNCH_CHECK("tanh_bwd_kernel");
+    return 0;
+}
+
+size_t geogcn_colsum_workspace_bytes(int64_t n, int32_t F) {
+    if (n <= 0 || F <= 0) return 0;
+    return (size_t)colsum_parts(n) * (size_t)F * sizeof(float);
+}
+
+int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes,
+                      void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "colsum_f32: negative size");
+    if (F == 0) return 0;
+    GEOGCN_REQUIRE(out, GEOGCN_E_NULL, "colsum_f32: null out");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        GEOGCN_HIP(hipMemsetAsync(out, 0, (size_t)F * sizeof(float), st));
+        return 0;
+    }
+    GEOGCN_REQUIRE(X && ldx >= F, GEOGCN_E_NULL, "colsum_f32: null X or ldx < F");
+    const int64_t parts = colsum_parts(n);
+    GEOGCN_REQUIRE(ws && ws_bytes >= (size_t)parts * F * sizeof(float), GEOGCN_E_ARG, "colsum_f32: workspace too small");
+    const int64_t rpb = cdiv(n, parts);
+    const int nparts = (int)cdiv(n, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, F, X, ldx, rpb, (float*)ws);
+    GEOGCN_LAUNCH_CHECK("colsum_partial_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, TPB)), dim3(TPB), 0, st, nparts, F,
+                       (const float*)ws, out);
+    GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
+int geogcn_dropout_mask_philox(int64_t n, int32_t F, float p_drop, uint64_t seed, uint64_t offset,
+                               uint8_t* keep_mask, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "dropout_mask_philox: negative size");
+    GEOGCN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GEOGCN_E_ARG, "dropout_mask_philox: p=%f outside [0,1)", p_drop);
+    if (n == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(keep_mask, GEOGCN_E_NULL, "dropout_mask_philox: null mask");
+    const int64_t total = n * F;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid((total + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream,
+                       total, 1.0f - p_drop, seed, offset, keep_mask);
+    GEOGCN_LAUNCH_CHECK("dropout_mask_kernel");
+    return 0;
+}
+
+int geogcn_dropout_apply_f32(int64_t n, int32_t F, const float* X, int64_t ld, const uint8_t* keep_mask,
+                             float p_drop, float* Y, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "dropout_apply_f32: negative size");
+    GEOGCN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GEOGCN_E_ARG, "dropout_apply_f32: p=%f outside [0,1)", p_drop);
+    if (n == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(keep_mask, GEOGCN_E_NULL, "dropout_apply_f32: null mask");
+    CHECK_VEC("dropout_apply_f32", ld, X, Y);
+    const int F4 = (F + 3) / 4;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(stream_grid(n * F4)), dim3(TPB), 0, (hipStream_t)stream, n, F, F4, X,
+                       ld, keep_mask, 1.0f / (1.0f - p_drop), Y);
+    GEOGCN_LAUNCH_CHECK("dropout_apply_kernel");
+    return 0;
+}
+
+int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t* idx, int64_t n_idx, float* out,
+                           int64_t ldo, void* stream) {
+    GEOGCN_REQUIRE(F >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "gather_rows_f32: negative size");
+    if (F == 0 || n_idx == 0) return 0;
+    GEOGCN_REQUIRE(X && idx && out, GEOGCN_E_NULL, "gather_rows_f32: null pointer");
+    GEOGCN_REQUIRE(ldx >= F && ldo >= F, GEOGCN_E_SIZE, "gather_rows_f32: ld < F");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(n_idx * F)), dim3(TPB), 0, (hipStream_t)stream, F, X, ldx,
+                       idx, n_idx, out, ldo);
+    GEOGCN_LAUNCH_CHECK("gather_rows_kernel");
+    return 0;
+}
+
+}  // extern "C"

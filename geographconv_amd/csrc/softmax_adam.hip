@@ -1,0 +1,264 @@
+// Output head + optimiser kernels of the GCN hot path (gfx950).
+//   softmax / argmax / cross-entropy / row gather+scatter   reference gcnmodel.py:374-382,389,393-394
+//   lasagne.updates.adam + l1/l2 penalty                     reference gcnmodel.py:383-387,407
+// One 64-lane wave per row for the row-wise ops (C <= a few hundred: 129 / 256 / 930), butterfly
+// shuffles for the reductions (fixed tree => run-to-run bitwise stable); scalar reductions over
+// index vectors use a fixed two-pass tree (no float atomics).
+#include "common.h"
+
+#include <algorithm>
+
+namespace geogcn {
+namespace {
+
+constexpr int TPB = 256;
+constexpr int kWavesPerBlock = TPB / kWave;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// probs = exp(x - max) / sum ; argmax = first index attaining the max (numpy / Theano argmax)
+__global__ __launch_bounds__(TPB) void softmax_rows_kernel(int64_t n, int C, const float* __restrict__ L, int64_t ldl,
+                                                           float* __restrict__ P, int64_t ldp, int ldp_pad,
+                                                           int* __restrict__ amax) {
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    if (row >= n) return;
+    const float* x = L + row * ldl;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = lane; c < C; c += kWave) {
+        const float v = x[c];
+        if (v > m) { m = v; mi = c; }          // strict > keeps the first index within a lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, kWave);
+        const int oi = __shfl_xor(mi, o, kWave);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float s = 0.f;
+    for (int c = lane; c < C; c += kWave) s += expf(x[c] - m);
+    s = wave_sum(s);
+    float* p = P + row * ldp;
+    for (int c = lane; c < ldp_pad; c += kWave) p[c] = (c < C) ? expf(x[c] - m) / s : 0.f;
+    if (amax && lane == 0) amax[row] = mi;
+}
+
+// per-index loss / hit, block partial sums in a fixed tree
+__global__ __launch_bounds__(TPB) void ce_partial_kernel(int C, const float* __restrict__ P, int64_t ldp,
+                                                         const int* __restrict__ amax,
+                                                         const int* __restrict__ idx, int64_t n_idx,
+                                                         const int* __restrict__ y, float* __restrict__ part) {
+    __shared__ float s_loss[kWavesPerBlock], s_hit[kWavesPerBlock];
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    float loss = 0.f, hit = 0.f;
+    if (j < n_idx) {
+        const int64_t row = idx[j];
+        const float* p = P + row * ldp;
+        const int yy = y[j];
+        loss = -logf(p[yy]);
+        int mi = 0;
+        if (amax) {
+            mi = amax[row];
+        } else {
+            float m = p[0];
+            for (int c = 1; c < C; ++c) {
+                const float v = p[c];
+                if (v > m) { m = v; mi = c; }
+            }
+        }
+        hit = (mi == yy) ? 1.f : 0.f;
+    }
+    loss = wave_sum(loss);
+    hit = wave_sum(hit);
+    const int w = threadIdx.x / kWave;
+    if (threadIdx.x % kWave == 0) { s_loss[w] = loss; s_hit[w] = hit; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < kWavesPerBlock; ++i) { a += s_loss[i]; b += s_hit[i]; }
+        part[2 * blockIdx.x] = a;
+        part[2 * blockIdx.x + 1] = b;
+    }
+}
+__global__ void pair_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < nparts; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+        out2[0] = a;
+        out2[1] = b;
+    }
+}
+
+// dlogits[idx[j], c] += (P[idx[j], c] - [c == y[j]]) / n_idx.  dlogits was zeroed just before; with the
+// unique indices the reference produces (np.random.choice(replace=False), gcnmain.py:207) every
+// element sees exactly one add onto 0, and k duplicates add k identical values -- order-free.
+__global__ __launch_bounds__(TPB) void ce_bwd_kernel(int C, const float* __restrict__ P, int64_t ldp,
+                                                     const int* __restrict__ idx, int64_t n_idx,
+                                                     const int* __restrict__ y, float inv_n,
+                                                     float* __restrict__ D, int64_t ldd) {
+    const int64_t j = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    if (j >= n_idx) return;
+    const int64_t row = idx[j];
+    const int yy = y[j];
+    for (int c = lane; c < C; c += kWave) {
+        const float g = (P[row * ldp + c] - (c == yy ? 1.0f : 0.0f)) * inv_n;
+        atomicAdd(D + row * ldd + c, g);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ regmask, float a_t, float b1, float b2,
+                                                   float eps, float l1, float l2) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const float pi = p[i];
+        float gi = g[i];
+        if (regmask) {
+            const float sgn = (pi > 0.f) ? 1.f : ((pi < 0.f) ? -1.f : 0.f);
+            gi += regmask[i] * (l1 * sgn + 2.0f * l2 * pi);
+        }
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - a_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void reg_partial_kernel(int64_t n, const float* __restrict__ p,
+                                                          const float* __restrict__ regmask, float l1, float l2,
+                                                          float* __restrict__ part) {
+    __shared__ float s[kWavesPerBlock];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const float pi = p[i];
+        const float r = regmask ? regmask[i] : 1.f;
+        a += r * (l1 * fabsf(pi) + l2 * pi * pi);
+    }
+    a = wave_sum(a);
+    if (threadIdx.x % kWave == 0) s[threadIdx.x / kWave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < kWavesPerBlock; ++i) t += s[i];
+        part[blockIdx.x] = t;
+    }
+}
+__global__ void scalar_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float a = 0.f;
+        for (int i = 0; i < nparts; ++i) a += part[i];
+        out[0] = a;
+    }
+}
+
+constexpr int kRegParts = 256;
+
+}  // namespace
+}  // namespace geogcn
+
+using namespace geogcn;
+
+extern "C" {
+
+int geogcn_softmax_rows_f32(int64_t n, int32_t C, const float* logits, int64_t ldl, float* probs, int64_t ldp,
+                            int32_t* argmax_out, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && C >= 0, GEOGCN_E_SIZE, "softmax_rows_f32: negative size");
+    if (n == 0 || C == 0) return 0;
+    GEOGCN_REQUIRE(logits && probs, GEOGCN_E_NULL, "softmax_rows_f32: null pointer");
+    GEOGCN_REQUIRE(ldl >= C && ldp >= C, GEOGCN_E_SIZE, "softmax_rows_f32: ld < C");
+    const int ldp_pad = (int)std::min<int64_t>(ldp, (int64_t)((C + 3) / 4) * 4);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(n, kWavesPerBlock)), dim3(TPB), 0, (hipStream_t)stream,
+                       n, C, logits, ldl, probs, ldp, ldp_pad, argmax_out);
+    GEOGCN_LAUNCH_CHECK("softmax_rows_kernel");
+    return 0;
+}
+
+size_t geogcn_ce_metrics_workspace_bytes(int64_t n_idx) {
+    if (n_idx <= 0) return 0;
+    return (size_t)cdiv(n_idx, TPB) * 2 * sizeof(float);
+}
+
+int geogcn_ce_metrics_f32(int32_t C, const float* probs, int64_t ldp, const int32_t* argmax, const int32_t* idx,
+                          int64_t n_idx, const int32_t* y, float* out2, void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(C > 0 && n_idx >= 0, GEOGCN_E_SIZE, "ce_metrics_f32: bad size");
+    GEOGCN_REQUIRE(out2, GEOGCN_E_NULL, "ce_metrics_f32: null out");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_idx == 0) {
+        GEOGCN_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(float), st));
+        return 0;
+    }
+    GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "ce_metrics_f32: null pointer");
+    const int nparts = (int)cdiv(n_idx, TPB);
+    GEOGCN_REQUIRE(ws && ws_bytes >= (size_t)nparts * 2 * sizeof(float), GEOGCN_E_ARG,
+                   "ce_metrics_f32: workspace too small");
+    hipLaunchKernelGGL(ce_partial_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, C, probs, ldp, argmax, idx, n_idx,
+                       y, (float*)ws);
+    GEOGCN_LAUNCH_CHECK("ce_partial_kernel");
+    hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(kWave), 0, st, nparts, (const float*)ws, out2);
+    GEOGCN_LAUNCH_CHECK("pair_final_kernel");
+    return 0;
+}
+
+int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t ldp, const int32_t* idx,
+                              int64_t n_idx, const int32_t* y, float* dlogits, int64_t ldd, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && C >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "softmax_ce_bwd_f32: negative size");
+    if (n == 0 || C == 0) return 0;
+    GEOGCN_REQUIRE(dlogits, GEOGCN_E_NULL, "softmax_ce_bwd_f32: null dlogits");
+    GEOGCN_REQUIRE(ldd >= C, GEOGCN_E_SIZE, "softmax_ce_bwd_f32: ldd < C");
+    hipStream_t st = (hipStream_t)stream;
+    GEOGCN_HIP(hipMemsetAsync(dlogits, 0, (size_t)n * (size_t)ldd * sizeof(float), st));
+    if (n_idx == 0) return 0;
+    GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "softmax_ce_bwd_f32: null pointer");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv(n_idx, kWavesPerBlock)), dim3(TPB), 0, st, C, probs, ldp, idx,
+                       n_idx, y, 1.0f / (float)n_idx, dlogits, ldd);
+    GEOGCN_LAUNCH_CHECK("ce_bwd_kernel");
+    return 0;
+}
+
+int geogcn_adam_step_f32(int64_t n, float* p, const float* g, float* m, float* v, const float* regmask, float lr,
+                         float b1, float b2, float eps, int32_t t, float l1, float l2, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && t >= 1, GEOGCN_E_SIZE, "adam_step_f32: n=%lld t=%d", (long long)n, t);
+    if (n == 0) return 0;
+    GEOGCN_REQUIRE(p && g && m && v, GEOGCN_E_NULL, "adam_step_f32: null pointer");
+    // lasagne.updates.adam: a_t = lr * sqrt(1 - b2^t) / (1 - b1^t), computed in fp32 like floatX=float32
+    const float a_t = lr * sqrtf(1.0f - powf(b2, (float)t)) / (1.0f - powf(b1, (float)t));
+    const int64_t blocks = std::min<int64_t>(cdiv(n, TPB), (int64_t)kNumCU * 8);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, n, p, g, m, v,
+                       (l1 != 0.f || l2 != 0.f) ? regmask : nullptr, a_t, b1, b2, eps, l1, l2);
+    GEOGCN_LAUNCH_CHECK("adam_kernel");
+    return 0;
+}
+
+int geogcn_reg_penalty_f32(int64_t n, const float* p, const float* regmask, float l1, float l2, float* out, void* ws,
+                           size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(n >= 0, GEOGCN_E_SIZE, "reg_penalty_f32: negative size");
+    GEOGCN_REQUIRE(out, GEOGCN_E_NULL, "reg_penalty_f32: null out");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        GEOGCN_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+        return 0;
+    }
+    GEOGCN_REQUIRE(p, GEOGCN_E_NULL, "reg_penalty_f32: null p");
+    GEOGCN_REQUIRE(ws && ws_bytes >= kRegParts * sizeof(float), GEOGCN_E_ARG, "reg_penalty_f32: workspace < %zu bytes",
+                   kRegParts * sizeof(float));
+    const int nparts = (int)std::min<int64_t>(kRegParts, cdiv(n, TPB));
+    hipLaunchKernelGGL(reg_partial_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, p, regmask, l1, l2, (float*)ws);
+    GEOGCN_LAUNCH_CHECK("reg_partial_kernel");
+    hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(kWave), 0, st, nparts, (const float*)ws, out);
+    GEOGCN_LAUNCH_CHECK("scalar_final_kernel");
+    return 0;
+}
+
+}  // extern "C"

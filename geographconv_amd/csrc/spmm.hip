@@ -1,0 +1,395 @@
+// CSR x dense SpMM for gfx950 -- replaces Theano's StructuredDot C loop on the GCN hot path
+// (reference gcnmodel.py:39,130,153 and the StructuredDot gradients autodiff derives).
+//
+// HBM-bound gather kernel (AI ~5.6 flop/B): no MFMA, no reshaping into GEMM.
+//   * a GROUP of 16 lanes owns one CSR row; each lane keeps K4 float4 accumulators, so one
+//     nonzero turns into K4 fully coalesced 256-byte reads of the gathered B row per group and a
+//     64-lane wave keeps 4 independent rows (gather streams) in flight;
+//   * (col, val) pairs are read 16 at a time, coalesced, and handed round the group with
+//     width-16 shuffles (ds_bpermute: the LDS crossbar is otherwise idle here);
+//   * accumulation is sequential in stored index order with fmaf -- the same order as the
+//     reference's row loop -- so short rows are bitwise reproducible run to run;
+//   * rows longer than plan->long_row_nnz are cut into fixed chunks, each chunk is a "virtual
+//     row" writing a partial sum to the workspace, and a third kernel adds the partials in chunk
+//     order (no float atomics anywhere);
+//   * bias + tanh/sigmoid epilogue fused into the store (gcnmodel.py:41-42,132-136).
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace geogcn {
+namespace {
+
+constexpr int kGroup = 16;                // lanes per row
+constexpr int kBlock = 256;               // 4 waves = 16 groups
+constexpr int kGroupsPerBlock = kBlock / kGroup;
+
+struct F4 {
+    float x, y, z, w;
+};
+
+__device__ __forceinline__ void fma4(float4& acc, float a, const float4& b) {
+    acc.x = fmaf(a, b.x, acc.x);
+    acc.y = fmaf(a, b.y, acc.y);
+    acc.z = fmaf(a, b.z, acc.z);
+    acc.w = fmaf(a, b.w, acc.w);
+}
+
+// One group walks nonzeros [s, e) and accumulates into acc[K4].
+template <int K4>
+__device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int nF4,
+                                                 const int* __restrict__ colidx,
+                                                 const float* __restrict__ val,
+                                                 const float* __restrict__ B, int64_t ldb,
+                                                 float4 (&acc)[K4]) {
+    for (int base = s; base < e; base += kGroup) {
+        const int j = base + lane16;
+        int c = 0;
+        float a = 0.f;
+        if (j < e) {
+            c = colidx[j];
+            a = val[j];
+        }
+        const int cnt = min(kGroup, e - base);
+        int t = 0;
+        // two nonzeros per trip: 2*K4 independent 16-byte loads in flight per lane
+        for (; t + 1 < cnt; t += 2) {
+            const int c0 = __shfl(c, t, kGroup);
+            const int c1 = __shfl(c, t + 1, kGroup);
+            const float a0 = __shfl(a, t, kGroup);
+            const float a1 = __shfl(a, t + 1, kGroup);
+            const float4* b0 = reinterpret_cast<const float4*>(B + (int64_t)c0 * ldb);
+            const float4* b1 = reinterpret_cast<const float4*>(B + (int64_t)c1 * ldb);
+            float4 v0[K4], v1[K4];
+#pragma unroll
+            for (int k = 0; k < K4; ++k) {
+                const int q = lane16 + kGroup * k;
+                if (q < nF4) {
+                    v0[k] = b0[q];
+                    v1[k] = b1[q];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K4; ++k) {
+                const int q = lane16 + kGroup * k;
+                if (q < nF4) {
+                    fma4(acc[k], a0, v0[k]);
+                    fma4(acc[k], a1, v1[k]);
+                }
+            }
+        }
+        if (t < cnt) {
+            const int c0 = __shfl(c, t, kGroup);
+            const float a0 = __shfl(a, t, kGroup);
+            const float4* b0 = reinterpret_cast<const float4*>(B + (int64_t)c0 * ldb);
+#pragma unroll
+            for (int k = 0; k < K4; ++k) {
+                const int q = lane16 + kGroup * k;
+                if (q < nF4) fma4(acc[k], a0, b0[q]);
+            }
+        }
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ float4 epilogue4(float4 r, int col0, int F, const float* __restrict__ bias) {
+    float o[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = col0 + i;
+        if (col < F) {
+            float x = o[i];
+            if (bias) x += bias[col];
+            o[i] = apply_act<ACT>(x);
+        } else {
+            o[i] = 0.f;             // keep pad columns zero (geogcn.h convention)
+        }
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// rows: one group per CSR row, long rows skipped.
+template <int K4, int ACT>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
+    int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+    const float* __restrict__ val, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz) {
+    const int row = blockIdx.x * kGroupsPerBlock + (threadIdx.x / kGroup);
+    const int lane16 = threadIdx.x % kGroup;
+    if (row >= n_rows) return;
+    const int s = rowptr[row];
+    const int e = rowptr[row + 1];
+    if (e - s > long_row_nnz) return;       // handled by the chunk path
+    const int nF4 = (F + 3) >> 2;
+    float4 acc[K4];
+#pragma unroll
+    for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    group_accumulate<K4>(s, e, lane16, nF4, colidx, val, B, ldb, acc);
+    float4* out = reinterpret_cast<float4*>(C + (int64_t)row * ldc);
+#pragma unroll
+    for (int k = 0; k < K4; ++k) {
+        const int q = lane16 + kGroup * k;
+        if (q < nF4) out[q] = epilogue4<ACT>(acc[k], q * 4, F, bias);
+    }
+}
+
+// chunks of long rows: one group per chunk, raw partial sums into the workspace.
+template <int K4>
+__global__ __launch_bounds__(kBlock) void spmm_chunks_kernel(
+    int n_chunks, const int* __restrict__ chunk_start, const int* __restrict__ chunk_end,
+    const int* __restrict__ colidx, const float* __restrict__ val, const float* __restrict__ B,
+    int64_t ldb, float* __restrict__ P, int64_t ldp, int F) {
+    const int ch = blockIdx.x * kGroupsPerBlock + (threadIdx.x / kGroup);
+    const int lane16 = threadIdx.x % kGroup;
+    if (ch >= n_chunks) return;
+    const int nF4 = (F + 3) >> 2;
+    float4 acc[K4];
+#pragma unroll
+    for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    group_accumulate<K4>(chunk_start[ch], chunk_end[ch], lane16, nF4, colidx, val, B, ldb, acc);
+    float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
+#pragma unroll
+    for (int k = 0; k < K4; ++k) {
+        const int q = lane16 + kGroup * k;
+        if (q < nF4) out[q] = acc[k];
+    }
+}
+
+// long rows: one block per row, thread per output column, partials added in chunk order.
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(
+    const int* __restrict__ long_rows, const int* __restrict__ long_first, const float* __restrict__ P,
+    int64_t ldp, float* __restrict__ C, int64_t ldc, int F, int Fpad, const float* __restrict__ bias) {
+    const int lr = blockIdx.x;
+    const int row = long_rows[lr];
+    const int c0 = long_first[lr];
+    const int c1 = long_first[lr + 1];
+    for (int col = threadIdx.x; col < Fpad; col += kBlock) {
+        float acc = 0.f;
+        int ch = c0;
+        for (; ch + 4 <= c1; ch += 4) {
+            const float p0 = P[(int64_t)(ch + 0) * ldp + col];
+            const float p1 = P[(int64_t)(ch + 1) * ldp + col];
+            const float p2 = P[(int64_t)(ch + 2) * ldp + col];
+            const float p3 = P[(int64_t)(ch + 3) * ldp + col];
+            acc = ((acc + p0) + p1) + p2 + p3;
+        }
+        for (; ch < c1; ++ch) acc += P[(int64_t)ch * ldp + col];
+        float o = 0.f;
+        if (col < F) {
+            if (bias) acc += bias[col];
+            o = apply_act<ACT>(acc);
+        }
+        C[(int64_t)row * ldc + col] = o;
+    }
+}
+
+// Fallback for pitches that are not float4-addressable: one wave per row, scalar lanes.
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
+    int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+    const float* __restrict__ val, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, int F, const float* __restrict__ bias) {
+    const int row = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    if (row >= n_rows) return;
+    const int s = rowptr[row], e = rowptr[row + 1];
+    for (int col = lane; col < F; col += kWave) {
+        float acc = 0.f;
+        for (int j = s; j < e; ++j) acc = fmaf(val[j], B[(int64_t)colidx[j] * ldb + col], acc);
+        if (bias) acc += bias[col];
+        C[(int64_t)row * ldc + col] = apply_act<ACT>(acc);
+    }
+}
+
+template <int K4>
+int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
+              const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
+              const float* bias, int act, float* ws, hipStream_t st);
+
+}  // namespace
+}  // namespace geogcn
+
+struct geogcn_spmm_plan {
+    int32_t n_rows = 0;
+    int32_t long_row_nnz = 0;
+    int32_t chunk_nnz = 0;
+    int64_t n_long = 0;
+    int64_t n_chunks = 0;
+    int* d_long_rows = nullptr;    // [n_long]
+    int* d_long_first = nullptr;   // [n_long + 1] first chunk of each long row
+    int* d_chunk_start = nullptr;  // [n_chunks]
+    int* d_chunk_end = nullptr;    // [n_chunks]
+};
+
+namespace geogcn {
+namespace {
+
+template <int K4>
+int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
+              const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
+              const float* bias, int act, float* ws, hipStream_t st) {
+    const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
+    const dim3 grid((unsigned)cdiv(n_rows, kGroupsPerBlock));
+#define GEOGCN_ROWS(ACT)                                                                         \
+    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
+                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz)
+    if (n_rows > 0) {
+        if (act == GEOGCN_ACT_TANH) GEOGCN_ROWS(GEOGCN_ACT_TANH);
+        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_ROWS(GEOGCN_ACT_SIGMOID);
+        else GEOGCN_ROWS(GEOGCN_ACT_NONE);
+        GEOGCN_LAUNCH_CHECK("spmm_rows_kernel");
+    }
+#undef GEOGCN_ROWS
+    if (plan && plan->n_long > 0) {
+        const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
+        const dim3 cgrid((unsigned)cdiv(plan->n_chunks, kGroupsPerBlock));
+        hipLaunchKernelGGL((spmm_chunks_kernel<K4>), cgrid, dim3(kBlock), 0, st, (int)plan->n_chunks,
+                           plan->d_chunk_start, plan->d_chunk_end, colidx, val, B, ldb, ws, ldp, F);
+        GEOGCN_LAUNCH_CHECK("spmm_chunks_kernel");
+        const int Fpad = (int)std::min<int64_t>(ldc, ldp);
+        const dim3 rgrid((unsigned)plan->n_long);
+#define GEOGCN_RED(ACT)                                                                          \
+    hipLaunchKernelGGL((spmm_long_reduce_kernel<ACT>), rgrid, dim3(kBlock), 0, st,               \
+                       plan->d_long_rows, plan->d_long_first, ws, ldp, C, ldc, F, Fpad, bias)
+        if (act == GEOGCN_ACT_TANH) GEOGCN_RED(GEOGCN_ACT_TANH);
+        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_RED(GEOGCN_ACT_SIGMOID);
+        else GEOGCN_RED(GEOGCN_ACT_NONE);
+#undef GEOGCN_RED
+        GEOGCN_LAUNCH_CHECK("spmm_long_reduce_kernel");
+    }
+    return 0;
+}
+
+}  // namespace
+}  // namespace geogcn
+
+using namespace geogcn;
+
+extern "C" {
+
+int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz,
+                            int32_t chunk_nnz, geogcn_spmm_plan** out) {
+    GEOGCN_REQUIRE(rowptr_host && out, GEOGCN_E_NULL, "spmm_plan_create: null pointer");
+    GEOGCN_REQUIRE(n_rows >= 0 && long_row_nnz > 0 && chunk_nnz > 0, GEOGCN_E_SIZE,
+                   "spmm_plan_create: bad sizes n_rows=%d long=%d chunk=%d", n_rows, long_row_nnz,
+                   chunk_nnz);
+    std::vector<int> long_rows, long_first, cs, ce;
+    for (int r = 0; r < n_rows; ++r) {
+        const int s = rowptr_host[r], e = rowptr_host[r + 1];
+        GEOGCN_REQUIRE(e >= s, GEOGCN_E_SIZE, "spmm_plan_create: rowptr not monotone at row %d", r);
+        if (e - s > long_row_nnz) {
+            long_rows.push_back(r);
+            long_first.push_back((int)cs.size());
+            for (int p = s; p < e; p += chunk_nnz) {
+                cs.push_back(p);
+                ce.push_back(std::min(e, p + chunk_nnz));
+            }
+        }
+    }
+    long_first.push_back((int)cs.size());
+    auto* plan = new geogcn_spmm_plan();
+    plan->n_rows = n_rows;
+    plan->long_row_nnz = long_row_nnz;
+    plan->chunk_nnz = chunk_nnz;
+    plan->n_long = (int64_t)long_rows.size();
+    plan->n_chunks = (int64_t)cs.size();
+    auto upload = [](const std::vector<int>& v, int** d) -> hipError_t {
+        if (v.empty()) return hipSuccess;
+        hipError_t e = hipMalloc((void**)d, v.size() * sizeof(int));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    };
+    if (plan->n_long > 0) {
+        hipError_t e = upload(long_rows, &plan->d_long_rows);
+        if (e == hipSuccess) e = upload(long_first, &plan->d_long_first);
+        if (e == hipSuccess) e = upload(cs, &plan->d_chunk_start);
+        if (e == hipSuccess) e = upload(ce, &plan->d_chunk_end);
+        if (e != hipSuccess) {
+            set_error("spmm_plan_create: %s", hipGetErrorString(e));
+            geogcn_spmm_plan_destroy(plan);
+            return (int)e;
+        }
+    }
+    *out = plan;
+    return 0;
+}
+
+void geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan) {
+    if (!plan) return;
+    if (plan->d_long_rows) (void)hipFree(plan->d_long_rows);
+    if (plan->d_long_first) (void)hipFree(plan->d_long_first);
+    if (plan->d_chunk_start) (void)hipFree(plan->d_chunk_start);
+    if (plan->d_chunk_end) (void)hipFree(plan->d_chunk_end);
+    delete plan;
+}
+
+int64_t geogcn_spmm_plan_num_long_rows(const geogcn_spmm_plan* plan) { return plan ? plan->n_long : 0; }
+int64_t geogcn_spmm_plan_num_chunks(const geogcn_spmm_plan* plan) { return plan ? plan->n_chunks : 0; }
+
+size_t geogcn_spmm_workspace_bytes(const geogcn_spmm_plan* plan, int32_t F) {
+    if (!plan || plan->n_chunks == 0 || F <= 0) return 0;
+    return (size_t)plan->n_chunks * (size_t)((F + 3) / 4) * 4 * sizeof(float);
+}
+
+int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                        const int32_t* rowptr, const int32_t* colidx, const float* val,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                        const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && F >= 0, GEOGCN_E_SIZE,
+                   "spmm_csr_f32: negative size");
+    if (n_rows == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(rowptr && C && (nnz == 0 || (colidx && val && B)), GEOGCN_E_NULL,
+                   "spmm_csr_f32: null pointer");
+    GEOGCN_REQUIRE(ldb >= F && ldc >= F, GEOGCN_E_SIZE, "spmm_csr_f32: ld < F (ldb=%lld ldc=%lld F=%d)",
+                   (long long)ldb, (long long)ldc, F);
+    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG,
+                   "spmm_csr_f32: unknown act %d", act);
+    GEOGCN_REQUIRE(!plan || plan->n_rows == n_rows, GEOGCN_E_ARG,
+                   "spmm_csr_f32: plan built for %d rows, called with %d", plan ? plan->n_rows : 0,
+                   n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    const int F4 = (F + 3) / 4;
+    const bool vec_ok = (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
+                        ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 10;
+    if (!vec_ok) {
+        const dim3 grid((unsigned)cdiv(n_rows, kBlock / kWave));
+#define GEOGCN_SC(ACT)                                                                              \
+    hipLaunchKernelGGL((spmm_scalar_kernel<ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr, colidx, \
+                       val, B, ldb, C, ldc, F, bias)
+        if (act == GEOGCN_ACT_TANH) GEOGCN_SC(GEOGCN_ACT_TANH);
+        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_SC(GEOGCN_ACT_SIGMOID);
+        else GEOGCN_SC(GEOGCN_ACT_NONE);
+#undef GEOGCN_SC
+        GEOGCN_LAUNCH_CHECK("spmm_scalar_kernel");
+        return 0;
+    }
+    const size_t need = geogcn_spmm_workspace_bytes(plan, F);
+    GEOGCN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16(ws)), GEOGCN_E_ARG,
+                   "spmm_csr_f32: workspace too small or misaligned (%zu < %zu)", ws_bytes, need);
+    float* wsf = (float*)ws;
+    const int K4 = (F4 + kGroup - 1) / kGroup;
+    switch (K4) {
+#define GEOGCN_CASE(K)                                                                             \
+    case K:                                                                                        \
+        return launch_k4<K>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st);
+        GEOGCN_CASE(1)
+        GEOGCN_CASE(2)
+        GEOGCN_CASE(3)
+        GEOGCN_CASE(4)
+        GEOGCN_CASE(5)
+        GEOGCN_CASE(6)
+        GEOGCN_CASE(7)
+        GEOGCN_CASE(8)
+        GEOGCN_CASE(9)
+        GEOGCN_CASE(10)
+#undef GEOGCN_CASE
+        default:
+            break;
+    }
+    set_error("spmm_csr_f32: F=%d not supported", F);
+    return GEOGCN_E_ARG;
+}
+
+}  // extern "C"

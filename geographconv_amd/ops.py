@@ -1,0 +1,277 @@
+"""Device containers + thin call wrappers over the C ABI (include/geogcn.h).
+
+torch is used for three things only: device memory (tensors), the current HIP stream, and
+``torch.distributed``.  Every arithmetic op below is a call into libgeogcn.so; if the library or
+a GPU is missing the call raises (no eager / CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sps
+import torch
+
+from . import _ffi
+from ._ffi import ACT_NONE, ACT_SIGMOID, ACT_TANH, check  # noqa: F401
+
+
+def pad4(F: int) -> int:
+    return (int(F) + 3) // 4 * 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _ffi.GeoGcnError("the GCN hot path runs on an MI355X only: no GPU visible "
+                               "(torch.cuda.is_available() is False) and there is no CPU fallback")
+
+
+class DMat:
+    """Row-major fp32 device matrix with a 4-float-aligned pitch; pad columns are kept zero
+    (geogcn.h convention) so a padded matrix is a valid reduction operand."""
+    __slots__ = ('t', 'n', 'F')
+
+    def __init__(self, n, F, device=None, t=None):
+        self.n, self.F = int(n), int(F)
+        if t is None:
+            t = torch.zeros((self.n, pad4(F)), dtype=torch.float32, device=device)
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (self.n, pad4(F))
+        self.t = t
+
+    @property
+    def ld(self):
+        return self.t.shape[1]
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @staticmethod
+    def from_numpy(a, device):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim == 1:
+            a = a[None, :]
+        m = DMat(a.shape[0], a.shape[1], device)
+        m.t[:, :a.shape[1]].copy_(torch.from_numpy(a))
+        return m
+
+    def numpy(self):
+        return self.t[:, :self.F].cpu().numpy()
+
+    def like(self):
+        return DMat(self.n, self.F, self.t.device)
+
+    def rows(self, r0, r1):
+        """View of a row range (shares storage)."""
+        return DMat(r1 - r0, self.F, t=self.t[r0:r1])
+
+
+class Workspace:
+    """Grow-only scratch buffer (split-K slabs, long-row partials, reduction partials)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.t.numel() < nbytes:
+            self.t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self.t
+
+
+class CSR:
+    """Device CSR (int32 indices, fp32 values) + the long-row split plan for the SpMM kernel."""
+
+    def __init__(self, m: sps.spmatrix, device, long_row_nnz=256, chunk_nnz=128):
+        require_gpu()
+        m = sps.csr_matrix(m)
+        if not m.has_sorted_indices:
+            m = m.copy()
+            m.sort_indices()
+        if m.nnz >= 2 ** 31 or max(m.shape) >= 2 ** 31:
+            raise ValueError("CSR too large for int32 indices")
+        self.shape = m.shape
+        self.nnz = int(m.nnz)
+        self.rowptr_host = np.ascontiguousarray(m.indptr, dtype=np.int32)
+        self.rowptr = torch.from_numpy(self.rowptr_host).to(device)
+        self.colidx = torch.from_numpy(np.ascontiguousarray(m.indices, dtype=np.int32)).to(device)
+        self.val = torch.from_numpy(np.ascontiguousarray(m.data, dtype=np.float32)).to(device)
+        self.device = device
+        self._plan = C.c_void_p(0)
+        lib = _ffi.lib()
+        check(lib.geogcn_spmm_plan_create(self.shape[0], self.rowptr_host.ctypes.data_as(C.c_void_p),
+                                          int(long_row_nnz), int(chunk_nnz), C.byref(self._plan)),
+              'spmm_plan_create')
+        self.n_long_rows = int(lib.geogcn_spmm_plan_num_long_rows(self._plan))
+        self.n_chunks = int(lib.geogcn_spmm_plan_num_chunks(self._plan))
+        self._ws = Workspace(device)
+
+    def __del__(self):
+        try:
+            if self._plan:
+                _ffi.lib().geogcn_spmm_plan_destroy(self._plan)
+                self._plan = C.c_void_p(0)
+        except Exception:
+            pass
+
+
+def spmm(A: CSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None):
+    """out = act(A . B + bias)  -- S.structured_dot (reference gcnmodel.py:39,130,153)."""
+    lib = _ffi.lib()
+    F = B.F if F is None else F
+    if B.n != A.shape[1]:
+        raise ValueError("spmm: A is %s but B has %d rows" % (A.shape, B.n))
+    if out is None:
+        out = DMat(A.shape[0], F, B.device)
+    need = lib.geogcn_spmm_workspace_bytes(A._plan, F)
+    ws = A._ws.get(need)
+    check(lib.geogcn_spmm_csr_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx),
+                                  _p(A.val), _p(B.t), B.ld, _p(out.t), out.ld, F, _p(bias), act,
+                                  _p(ws), ws.numel(), _stream()), 'spmm_csr_f32')
+    return out
+
+
+_gemm_ws = {}
+
+
+def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=None, act=ACT_NONE,
+         accumulate=False):
+    """out = act(op(A) . op(B) + bias) [+ out]  -- T.dot / Gemm (reference gcnmodel.py:126,149,285)."""
+    lib = _ffi.lib()
+    M = A.F if transA else A.n
+    K = A.n if transA else A.F
+    N = B.n if transB else B.F
+    Kb = B.F if transB else B.n
+    if Kb != K:
+        raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if out is None:
+        out = DMat(M, N, A.device)
+    dev = A.device
+    ws = _gemm_ws.get(dev)
+    if ws is None:
+        ws = _gemm_ws[dev] = Workspace(dev)
+    need = lib.geogcn_gemm_workspace_bytes(int(transA), int(transB), M, N, K)
+    w = ws.get(need)
+    check(lib.geogcn_gemm_f32(int(transA), int(transB), M, N, K, _p(A.t), A.ld, _p(B.t), B.ld, _p(out.t),
+                              out.ld, _p(bias), act, int(accumulate), _p(w), w.numel(), _stream()),
+          'gemm_f32')
+    return out
+
+
+def bias_act(X: DMat, bias, act, out: DMat = None):
+    out = X.like() if out is None else out
+    check(_ffi.lib().geogcn_bias_act_f32(X.n, X.F, _p(X.t), X.ld, _p(bias), act, _p(out.t), out.ld,
+                                         _stream()), 'bias_act_f32')
+    return out
+
+
+def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
+    out = H.like() if out is None else out
+    check(_ffi.lib().geogcn_highway_fwd_f32(H.n, H.F, _p(T.t), _p(Hc.t), _p(H.t), H.ld, _p(out.t),
+                                            _stream()), 'highway_fwd_f32')
+    return out
+
+
+def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None):
+    dS = G.like() if dS is None else dS
+    dU = G.like() if dU is None else dU
+    dHcarry = G.like() if dHcarry is None else dHcarry
+    check(_ffi.lib().geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t),
+                                            _p(dU.t), _p(dHcarry.t), _stream()), 'highway_bwd_f32')
+    return dS, dU, dHcarry
+
+
+def tanh_bwd(G: DMat, Y: DMat, out: DMat = None, keep_mask=None, scale=1.0):
+    out = G.like() if out is None else out
+    check(_ffi.lib().geogcn_tanh_bwd_f32(G.n, G.F, _p(G.t), _p(Y.t), G.ld, _p(keep_mask), float(scale),
+                                         _p(out.t), _stream()), 'tanh_bwd_f32')
+    return out
+
+
+_misc_ws = {}
+
+
+def _ws_for(dev):
+    ws = _misc_ws.get(dev)
+    if ws is None:
+        ws = _misc_ws[dev] = Workspace(dev)
+    return ws
+
+
+def colsum(X: DMat, out: torch.Tensor = None):
+    lib = _ffi.lib()
+    if out is None:
+        out = torch.zeros(pad4(X.F), dtype=torch.float32, device=X.device)
+    w = _ws_for(X.device).get(lib.geogcn_colsum_workspace_bytes(X.n, X.F))
+    check(lib.geogcn_colsum_f32(X.n, X.F, _p(X.t), X.ld, _p(out), _p(w), w.numel(), _stream()), 'colsum_f32')
+    return out
+
+
+def dropout_mask(n, F, p, seed, offset, device, out=None):
+    if out is None:
+        out = torch.empty((n, F), dtype=torch.uint8, device=device)
+    check(_ffi.lib().geogcn_dropout_mask_philox(n, F, float(p), int(seed), int(offset), _p(out), _stream()),
+          'dropout_mask_philox')
+    return out
+
+
+def dropout_apply(X: DMat, keep_mask, p, out: DMat = None):
+    out = X.like() if out is None else out
+    check(_ffi.lib().geogcn_dropout_apply_f32(X.n, X.F, _p(X.t), X.ld, _p(keep_mask), float(p), _p(out.t),
+                                              _stream()), 'dropout_apply_f32')
+    return out
+
+
+def softmax_rows(L: DMat, out: DMat = None, argmax: torch.Tensor = None):
+    out = L.like() if out is None else out
+    check(_ffi.lib().geogcn_softmax_rows_f32(L.n, L.F, _p(L.t), L.ld, _p(out.t), out.ld, _p(argmax),
+                                             _stream()), 'softmax_rows_f32')
+    return out
+
+
+def ce_metrics(P: DMat, idx: torch.Tensor, y: torch.Tensor, argmax: torch.Tensor = None, out2=None):
+    """-> device tensor [sum of -log P[idx, y], number of argmax hits] (gcnmodel.py:376-382)."""
+    lib = _ffi.lib()
+    if out2 is None:
+        out2 = torch.zeros(2, dtype=torch.float32, device=P.device)
+    w = _ws_for(P.device).get(lib.geogcn_ce_metrics_workspace_bytes(idx.numel()))
+    check(lib.geogcn_ce_metrics_f32(P.F, _p(P.t), P.ld, _p(argmax), _p(idx), idx.numel(), _p(y), _p(out2),
+                                    _p(w), w.numel(), _stream()), 'ce_metrics_f32')
+    return out2
+
+
+def softmax_ce_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, out: DMat = None):
+    out = P.like() if out is None else out
+    check(_ffi.lib().geogcn_softmax_ce_bwd_f32(P.n, P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y),
+                                               _p(out.t), out.ld, _stream()), 'softmax_ce_bwd_f32')
+    return out
+
+
+def gather_rows(X: DMat, idx: torch.Tensor, out: torch.Tensor = None):
+    if out is None:
+        out = torch.empty((idx.numel(), X.F), dtype=torch.float32, device=X.device)
+    check(_ffi.lib().geogcn_gather_rows_f32(X.F, _p(X.t), X.ld, _p(idx), idx.numel(), _p(out), out.shape[1],
+                                            _stream()), 'gather_rows_f32')
+    return out
+
+
+def adam_step(p, g, m, v, regmask, lr, b1, b2, eps, t, l1=0.0, l2=0.0):
+    check(_ffi.lib().geogcn_adam_step_f32(p.numel(), _p(p), _p(g), _p(m), _p(v), _p(regmask), lr, b1, b2, eps,
+                                          int(t), float(l1), float(l2), _stream()), 'adam_step_f32')
+
+
+def reg_penalty(p, regmask, l1, l2, out=None):
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=p.device)
+    w = _ws_for(p.device).get(4096)
+    check(_ffi.lib().geogcn_reg_penalty_f32(p.numel(), _p(p), _p(regmask), float(l1), float(l2), _p(out), _p(w),
+                                            w.numel(), _stream()), 'reg_penalty_f32')
+    return out

@@ -1,0 +1,146 @@
+/* geogcn.h -- C ABI of libgeogcn.so: the MI355X (gfx950) replacement for the native code the
+ * reference's GCN hot path runs in (the C that Theano 1.0.x generates for the ops composed by
+ * /root/reference/gcnmodel.py).  One entry point per Theano op family the path exercises; each
+ * comment cites the reference call site the entry point replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 for an argument error (GEOGCN_E_*), >0 for a
+ *     hipError_t passed through;  geogcn_last_error() gives the text (thread-local).
+ *   - all data pointers are BORROWED DEVICE pointers (the caller -- a torch tensor on the Python
+ *     side -- owns the memory and keeps it alive until the stream is synchronised), except where a
+ *     parameter is named *_host.
+ *   - `stream` is a hipStream_t passed as void*; every launch goes on it; no hidden syncs.
+ *   - dense matrices are row-major fp32 with an explicit leading dimension (`ld*`, in elements).
+ *     Vectorised kernels need ld % 4 == 0 and 16-byte aligned bases; other pitches fall back to a
+ *     scalar kernel (SpMM) or are rejected with GEOGCN_E_ALIGN (GEMM).  Producers keep the pad
+ *     columns [F, ld) ZERO so a padded matrix can be used as a reduction operand.
+ *   - CSR: int32 rowptr[n_rows+1], int32 colidx[nnz], fp32 val[nnz] (scipy layout; reference
+ *     gcnmain.py:172-179 casts X and A to float32 CSR).
+ *   - no C++ exceptions cross this boundary.
+ */
+#ifndef GEOGCN_H
+#define GEOGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOGCN_ABI_VERSION 1
+
+#define GEOGCN_E_NULL   (-1)   /* required pointer is NULL            */
+#define GEOGCN_E_SIZE   (-2)   /* negative / inconsistent size        */
+#define GEOGCN_E_ALIGN  (-3)   /* pitch or base alignment unsupported */
+#define GEOGCN_E_ARG    (-4)   /* bad enum / flag / workspace too small */
+
+/* epilogue selectors (lasagne.nonlinearities used on the path: gcnmodel.py:286,347,374) */
+#define GEOGCN_ACT_NONE    0   /* linear (softmax layers keep logits; softmax is its own entry) */
+#define GEOGCN_ACT_TANH    1   /* lasagne.nonlinearities.tanh     gcnmodel.py:347 */
+#define GEOGCN_ACT_SIGMOID 2   /* T.nnet.sigmoid                  gcnmodel.py:286 */
+
+int         geogcn_version(void);
+const char* geogcn_last_error(void);
+
+/* ---- K1/K2/K3/K4: S.structured_dot(CSR, dense) ---------------------------------------------
+ * C[n_rows x F] = act(A_csr . B + bias)            gcnmodel.py:39 (X.W0), :130, :153 (A_hat.Z)
+ * and, called on CSR(A^T), the gradient Theano derives for them (StructuredDot grad).
+ * Rows are accumulated in stored index order; rows longer than the plan's threshold are split
+ * into fixed chunks whose partial sums are combined in chunk order (deterministic, no atomics).
+ * bias may be NULL.  plan may be NULL (no row splitting: correct, slow on hub rows).          */
+typedef struct geogcn_spmm_plan geogcn_spmm_plan;
+
+int    geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz,
+                               int32_t chunk_nnz, geogcn_spmm_plan** out);
+void   geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan);
+int64_t geogcn_spmm_plan_num_long_rows(const geogcn_spmm_plan* plan);
+int64_t geogcn_spmm_plan_num_chunks(const geogcn_spmm_plan* plan);
+size_t geogcn_spmm_workspace_bytes(const geogcn_spmm_plan* plan, int32_t F);
+
+int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                        const int32_t* rowptr, const int32_t* colidx, const float* val,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                        const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K5/K6: T.dot / Gemm -----------------------------------------------------------------
+ * C[M x N] = act(op(A) . op(B) + bias)   fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate.
+ *   transA=0: A is M x K row-major (lda);  transA=1: A is K x M row-major (C = A^T . B)
+ *   transB=0: B is K x N row-major (ldb);  transB=1: B is N x K row-major (C = A . B^T)
+ * gcnmodel.py:126,149 (T.dot(input, W)), lasagne DenseLayer gate :285, and the Gemm ops autodiff
+ * derives: dW = H^T.dZ (transA=1), dH = dZ.W^T (transB=1).
+ * accumulate=1 adds into C (C += ...), used for dH += dZ.Wh^T + dU.Wt^T.
+ * transA=1 reduces over the long dimension: it runs split-K into `ws` (see
+ * geogcn_gemm_workspace_bytes) and combines the slabs in fixed order (deterministic).         */
+size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K);
+int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, int32_t act, int32_t accumulate,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K7: fused Elemwise ------------------------------------------------------------------- */
+/* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */
+int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const float* bias,
+                        int32_t act, float* Y, int64_t ldy, void* stream);
+/* MultiplicativeGatingLayer: Hout = T*Hc + (1-T)*H          gcnmodel.py:266                    */
+int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc, const float* H,
+                           int64_t ld, float* Hout, void* stream);
+/* its gradient + tanh'/sigmoid' of the two branches (what autodiff derives for :266,:136,:286):
+ *   dS = G*T*(1-Hc^2)   dU = G*(Hc-H)*T*(1-T)   dHcarry = G*(1-T)                               */
+int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
+                           const float* H, int64_t ld, float* dS, float* dU, float* dHcarry,
+                           void* stream);
+/* dS = G * (1 - Y^2) [* keep_mask * scale]   grad of tanh (gcnmodel.py:42,136) optionally through
+ * the dropout that follows layer 0 (gcnmodel.py:357); mask may be NULL                          */
+int geogcn_tanh_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld,
+                        const uint8_t* keep_mask, float scale, float* dS, void* stream);
+/* out[F] = sum over rows of X (bias gradients: Sum{axis=0}); deterministic two-pass            */
+size_t geogcn_colsum_workspace_bytes(int64_t n, int32_t F);
+int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* out,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K10: lasagne DropoutLayer (gcnmodel.py:357) -----------------------------------------
+ * mask generation is counter-based Philox4x32-10 (Theano's MRG31k3p stream cannot be matched;
+ * parity runs inject the mask).  keep_mask[i*F + j] in {0,1}, dense (no pitch).                */
+int geogcn_dropout_mask_philox(int64_t n, int32_t F, float p_drop, uint64_t seed, uint64_t offset,
+                               uint8_t* keep_mask, void* stream);
+/* Y = X * keep_mask / (1-p)  (forward; the backward is the same call on the gradient)          */
+int geogcn_dropout_apply_f32(int64_t n, int32_t F, const float* X, int64_t ld,
+                             const uint8_t* keep_mask, float p_drop, float* Y, void* stream);
+
+/* ---- K8/K9: Softmax, categorical_crossentropy, argmax, row gather / scatter -----------------
+ * probs = softmax_rows(logits) (max-subtracted), argmax = first index of the row maximum
+ * (gcnmodel.py:374,377,379,394); argmax_out may be NULL.                                        */
+int geogcn_softmax_rows_f32(int64_t n, int32_t C, const float* logits, int64_t ldl, float* probs,
+                            int64_t ldp, int32_t* argmax_out, void* stream);
+/* sums over the gathered rows idx[0..n_idx): loss_sum = sum -log P[idx[j], y[j]],
+ * correct = #{argmax P[idx[j]] == y[j]}   (gcnmodel.py:376-382,389); out2 = {loss_sum, correct} */
+size_t geogcn_ce_metrics_workspace_bytes(int64_t n_idx);
+int geogcn_ce_metrics_f32(int32_t C, const float* probs, int64_t ldp, const int32_t* argmax /*nullable:
+                          per-row argmax from geogcn_softmax_rows_f32*/, const int32_t* idx,
+                          int64_t n_idx, const int32_t* y, float* out2, void* ws, size_t ws_bytes,
+                          void* stream);
+/* dlogits = 0; dlogits[idx[j], :] += (P[idx[j], :] - onehot(y[j])) / n_idx  (autodiff of :376,:382) */
+int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t ldp,
+                              const int32_t* idx, int64_t n_idx, const int32_t* y, float* dlogits,
+                              int64_t ldd, void* stream);
+/* out[j, :] = X[idx[j], :]   AdvancedSubtensor1 (gcnmodel.py:376,378,393); dense out (pitch F)  */
+int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t* idx, int64_t n_idx,
+                           float* out, int64_t ldo, void* stream);
+
+/* ---- K11/K12: lasagne.updates.adam (+ l1/l2 penalty gradient), gcnmodel.py:383-387,407 ------
+ * flat arenas of n floats: t is the step index AFTER increment (1 for the first call).
+ *   g' = g + regmask*(l1*sign(p) + 2*l2*p);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
+ *   p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+ * regmask (nullable) is 1.0 on weight matrices ("regularizable") and 0 on biases / padding.     */
+int geogcn_adam_step_f32(int64_t n, float* p, const float* g, float* m, float* v,
+                         const float* regmask, float lr, float b1, float b2, float eps, int32_t t,
+                         float l1, float l2, void* stream);
+/* penalty value: sum regmask*(l1*|p| + l2*p^2) -> out[0] (deterministic two-pass)               */
+int geogcn_reg_penalty_f32(int64_t n, const float* p, const float* regmask, float l1, float l2,
+                           float* out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOGCN_H */

@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: libgeogcn.so builds, loads and exports exactly the
+symbols include/geogcn.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from geographconv_amd import _ffi
+
+
+@pytest.fixture(scope="module")
+def built():
+    from geographconv_amd import build
+    return build.build_library()
+
+
+def test_header_and_binding_agree():
+    assert set(_ffi.header_symbols()) == set(_ffi.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(built):
+    out = subprocess.run(['nm', '-D', '--defined-only', built], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if ' T ' in line}
+    missing = set(_ffi.header_symbols()) - exported
+    assert not missing, missing
+    extra = {s for s in exported if s.startswith('geogcn_')} - set(_ffi.header_symbols())
+    assert not extra, extra
+
+
+def test_library_loads_and_reports_version(built):
+    lib = _ffi.lib()
+    assert lib.geogcn_version() == 1
+    assert isinstance(lib.geogcn_last_error(), bytes)
+
+
+def test_argument_errors_need_no_gpu(built):
+    lib = _ffi.lib()
+    # negative size is rejected before any HIP call
+    rc = lib.geogcn_gemm_f32(0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None)
+    assert rc == -2 and b'negative' in lib.geogcn_last_error()
+    rc = lib.geogcn_spmm_csr_f32(None, 4, 4, 1, None, None, None, None, 4, None, 4, 4, None, 0, None, 0, None)
+    assert rc == -1
+    assert lib.geogcn_gemm_workspace_bytes(0, 0, 1000, 300, 300) == 0
+    assert lib.geogcn_gemm_workspace_bytes(1, 0, 300, 300, 440000) > 0
+    assert lib.geogcn_colsum_workspace_bytes(440000, 300) > 0
+
+
+def test_missing_gpu_fails_loudly():
+    import torch
+    from geographconv_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_ffi.GeoGcnError):
+        ops.require_gpu()
+
+
+def test_no_product_import_of_oracle():
+    """The product package must not import the oracle (it is the checker, not a fallback)."""
+    root = os.path.join(os.path.dirname(_ffi.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f

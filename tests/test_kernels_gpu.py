@@ -1,0 +1,325 @@
+"""Kernel-level parity: every C-ABI entry point of libgeogcn.so vs the NumPy oracle on the same
+seeded inputs (run on the MI355X: pytest -m gpu).  fp32 tolerances are stated per test; integer
+outputs (argmax, masks, hit counts) are compared exactly."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from geographconv_amd import synth
+from oracle import gcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from geographconv_amd import ops
+    ops.require_gpu()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.RandomState(seed).randn(*shape) * scale).astype(np.float32)
+
+
+def _skewed_csr(n_rows, n_cols, seed, hub_nnz=3000, empty_every=7):
+    """Random CSR with empty rows, 1-nnz rows and one hub row far above the split threshold."""
+    rng = np.random.RandomState(seed)
+    rows, cols = [], []
+    for r in range(n_rows):
+        if r % empty_every == 3:
+            k = 0
+        elif r == n_rows // 2:
+            k = min(hub_nnz, n_cols)
+        elif r % 11 == 5:
+            k = min(300, n_cols)               # just above the default long-row threshold (256)
+        else:
+            k = min(n_cols, 1 + rng.poisson(12))
+        c = rng.choice(n_cols, size=k, replace=False)
+        rows += [r] * k
+        cols += list(c)
+    vals = rng.randn(len(rows)).astype(np.float32)
+    m = sps.csr_matrix((vals, (rows, cols)), shape=(n_rows, n_cols), dtype=np.float32)
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("F", [1, 5, 64, 129, 256, 300, 600])
+@pytest.mark.parametrize("act,use_bias", [(0, False), (1, True)])
+def test_spmm_matches_oracle(dev, F, act, use_bias):
+    from geographconv_amd import ops
+    A = _skewed_csr(700, 900, seed=F)
+    B = _rand((900, F), 1)
+    bias = _rand((F,), 2) if use_bias else None
+    ref = O.spmm(A, B)
+    if bias is not None:
+        ref = ref + bias
+    if act == 1:
+        ref = np.tanh(ref)
+    dA = ops.CSR(A, dev)
+    assert dA.n_long_rows >= 1 and dA.n_chunks > dA.n_long_rows
+    dB = ops.DMat.from_numpy(B, dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(F) - F))).to(dev) if use_bias else None
+    out = ops.spmm(dA, dB, bias=db, act=act)
+    got = out.numpy()
+    # row sums of up to 3000 fp32 products: tolerance scales with sum |a||b|
+    mag = np.asarray(abs(A) @ np.abs(B)) + (np.abs(bias) if use_bias else 0)
+    assert np.all(np.abs(got - ref) <= 2e-6 * mag + 1e-6), np.abs(got - ref).max()
+    # pad columns stay zero
+    assert torch.all(out.t[:, F:] == 0)
+    # empty rows give act(bias)
+    empty = np.diff(A.indptr) == 0
+    assert empty.any()
+
+
+def test_spmm_short_rows_bitwise_reproducible_and_sequential(dev):
+    """Rows below the split threshold accumulate in stored order with fmaf: two runs are bitwise
+    equal and equal to a sequential fp32 fma chain (checked via float64 emulation bound)."""
+    from geographconv_amd import ops
+    A, X, Y = synth.small_graph(3000, 8.0, 400, 20, 7, seed=4)
+    B = _rand((3000, 300), 3)
+    dA = ops.CSR(A, dev)
+    dB = ops.DMat.from_numpy(B, dev)
+    o1 = ops.spmm(dA, dB).numpy()
+    o2 = ops.spmm(dA, dB).numpy()
+    assert np.array_equal(o1, o2)
+    ref = O.spmm(A, B)
+    assert np.allclose(o1, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_spmm_scalar_fallback_for_odd_pitch(dev):
+    from geographconv_amd import _ffi, ops
+    import ctypes as C
+    A = _skewed_csr(200, 150, seed=9, hub_nnz=140)
+    B = _rand((150, 7), 5)
+    dA = ops.CSR(A, dev)
+    tB = torch.from_numpy(B).to(dev)                 # pitch 7: not float4-addressable
+    tC = torch.zeros((200, 7), dtype=torch.float32, device=dev)
+    lib = _ffi.lib()
+    rc = lib.geogcn_spmm_csr_f32(None, 200, 150, A.nnz, ops._p(dA.rowptr), ops._p(dA.colidx), ops._p(dA.val),
+                                 ops._p(tB), 7, ops._p(tC), 7, 7, None, 0, None, 0, ops._stream())
+    assert rc == 0
+    assert np.allclose(tC.cpu().numpy(), O.spmm(A, B), rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_argument_errors(dev):
+    from geographconv_amd import _ffi, ops
+    lib = _ffi.lib()
+    A = _skewed_csr(50, 50, seed=1, hub_nnz=40)
+    dA = ops.CSR(A, dev)
+    B = ops.DMat.from_numpy(_rand((50, 8), 1), dev)
+    out = ops.DMat(50, 8, dev)
+    rc = lib.geogcn_spmm_csr_f32(dA._plan, 50, 50, A.nnz, None, ops._p(dA.colidx), ops._p(dA.val), ops._p(B.t), 8,
+                                 ops._p(out.t), 8, 8, None, 0, None, 0, ops._stream())
+    assert rc == -1 and b'null' in lib.geogcn_last_error()
+    rc = lib.geogcn_spmm_csr_f32(dA._plan, 50, 50, A.nnz, ops._p(dA.rowptr), ops._p(dA.colidx), ops._p(dA.val),
+                                 ops._p(B.t), 4, ops._p(out.t), 8, 8, None, 0, None, 0, ops._stream())
+    assert rc == -2
+    with pytest.raises(ValueError):
+        ops.spmm(dA, ops.DMat(49, 8, dev))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 300, 300), (777, 129, 300), (513, 600, 300), (64, 16, 4), (130, 132, 129),
+                                   (2500, 256, 300)])
+def test_gemm_nn_nt_match_oracle(dev, M, N, K):
+    from geographconv_amd import ops
+    A = _rand((M, K), 1)
+    Bnn = _rand((K, N), 2)
+    bias = _rand((N,), 3)
+    dA = ops.DMat.from_numpy(A, dev)
+    dB = ops.DMat.from_numpy(Bnn, dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(N) - N))).to(dev)
+    tol = 2e-6 * (np.abs(A) @ np.abs(Bnn)) + 1e-6
+    got = ops.gemm(dA, dB).numpy()
+    assert np.all(np.abs(got - A @ Bnn) <= tol)
+    got = ops.gemm(dA, dB, bias=db, act=ops.ACT_SIGMOID).numpy()
+    assert np.allclose(got, O.sigmoid(A @ Bnn + bias), rtol=1e-5, atol=1e-6)
+    # NT: C = A . B^T with B given as N x K
+    dBt = ops.DMat.from_numpy(np.ascontiguousarray(Bnn.T), dev)
+    got = ops.gemm(dA, dBt, transB=True).numpy()
+    assert np.all(np.abs(got - A @ Bnn) <= tol)
+    # accumulate
+    C0 = _rand((M, N), 4)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm(dA, dB, out=dC, accumulate=True)
+    assert np.all(np.abs(dC.numpy() - (A @ Bnn + C0)) <= tol + 1e-6)
+
+
+@pytest.mark.parametrize("R,M,N", [(5000, 300, 300), (4097, 300, 129), (333, 300, 600), (20000, 64, 8)])
+def test_gemm_tn_splitk_matches_oracle_and_is_deterministic(dev, R, M, N):
+    from geographconv_amd import ops
+    A = _rand((R, M), 1)           # C = A^T . B, reduction over R rows
+    B = _rand((R, N), 2)
+    dA = ops.DMat.from_numpy(A, dev)
+    dB = ops.DMat.from_numpy(B, dev)
+    g1 = ops.gemm(dA, dB, transA=True).numpy()
+    g2 = ops.gemm(dA, dB, transA=True).numpy()
+    assert np.array_equal(g1, g2)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    tol = 3e-6 * (np.abs(A).T @ np.abs(B)) + 1e-5
+    assert np.all(np.abs(g1 - ref) <= tol), np.abs(g1 - ref).max()
+
+
+def test_gemm_asymmetric_detects_transposes(dev):
+    """A = I check with an asymmetric B (guide rule: symmetric inputs hide row/col swaps)."""
+    from geographconv_amd import ops
+    K = 96
+    A = np.eye(K, dtype=np.float32)
+    B = (np.arange(K * 80).reshape(K, 80) % 97).astype(np.float32)
+    got = ops.gemm(ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)).numpy()
+    assert np.array_equal(got, B)
+    got = ops.gemm(ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev), transA=True).numpy()
+    assert np.array_equal(got, B)
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    from geographconv_amd import _ffi, ops
+    lib = _ffi.lib()
+    A = ops.DMat.from_numpy(_rand((8, 8), 1), dev)
+    rc = lib.geogcn_gemm_f32(1, 1, 8, 8, 8, ops._p(A.t), 8, ops._p(A.t), 8, ops._p(A.t), 8, None, 0, 0, None, 0,
+                             ops._stream())
+    assert rc == -4
+    rc = lib.geogcn_gemm_f32(0, 0, 8, 8, 8, ops._p(A.t), 6, ops._p(A.t), 8, ops._p(A.t), 8, None, 0, 0, None, 0,
+                             ops._stream())
+    assert rc in (-2, -3)
+
+
+@pytest.mark.parametrize("n,F", [(1000, 300), (257, 129), (3, 5)])
+def test_highway_and_tanh_kernels(dev, n, F):
+    from geographconv_amd import ops
+    T = O.sigmoid(_rand((n, F), 1)).astype(np.float32)
+    Hc = np.tanh(_rand((n, F), 2))
+    H = _rand((n, F), 3)
+    G = _rand((n, F), 4)
+    d = lambda a: ops.DMat.from_numpy(a, dev)
+    out = ops.highway_fwd(d(T), d(Hc), d(H)).numpy()
+    ref = T * Hc + (np.float32(1) - T) * H
+    assert np.allclose(out, ref, rtol=1e-6, atol=1e-7)
+    dS, dU, dHc = ops.highway_bwd(d(G), d(T), d(Hc), d(H))
+    assert np.allclose(dS.numpy(), G * T * (1 - Hc * Hc), rtol=1e-5, atol=1e-7)
+    assert np.allclose(dU.numpy(), G * (Hc - H) * T * (1 - T), rtol=1e-5, atol=1e-7)
+    assert np.allclose(dHc.numpy(), G * (1 - T), rtol=1e-6, atol=1e-7)
+    assert torch.all(dS.t[:, F:] == 0)
+    # tanh backward, with and without the dropout mask folded in
+    got = ops.tanh_bwd(d(G), d(Hc)).numpy()
+    assert np.allclose(got, G * (1 - Hc * Hc), rtol=1e-5, atol=1e-7)
+    mask = (np.random.RandomState(5).rand(n, F) < 0.5).astype(np.uint8)
+    tm = torch.from_numpy(mask).to(dev)
+    got = ops.tanh_bwd(d(G), d(Hc), keep_mask=tm, scale=2.0).numpy()
+    assert np.allclose(got, G * mask * 2.0 * (1 - Hc * Hc), rtol=1e-5, atol=1e-7)
+    # bias + act
+    b = _rand((F,), 6)
+    tb = torch.from_numpy(np.pad(b, (0, ops.pad4(F) - F))).to(dev)
+    got = ops.bias_act(d(H), tb, ops.ACT_TANH)
+    assert np.allclose(got.numpy(), np.tanh(H + b), rtol=1e-5, atol=1e-6)
+    assert torch.all(got.t[:, F:] == 0)
+    # dropout apply == x * mask / (1-p)
+    got = ops.dropout_apply(d(H), tm, 0.5).numpy()
+    assert np.array_equal(got, H * mask * np.float32(2.0))
+
+
+def test_colsum_gather_deterministic(dev):
+    from geographconv_amd import ops
+    X = _rand((70001, 300), 1)
+    dX = ops.DMat.from_numpy(X, dev)
+    s1 = ops.colsum(dX).cpu().numpy()[:300]
+    s2 = ops.colsum(dX).cpu().numpy()[:300]
+    assert np.array_equal(s1, s2)
+    ref = X.astype(np.float64).sum(axis=0)
+    assert np.all(np.abs(s1 - ref) <= 1e-6 * np.abs(X).sum(axis=0) + 1e-5)
+    idx = torch.from_numpy(np.random.RandomState(2).randint(0, 70001, 999).astype(np.int32)).to(dev)
+    got = ops.gather_rows(dX, idx).cpu().numpy()
+    assert np.array_equal(got, X[idx.cpu().numpy()])
+
+
+def test_philox_mask_statistics_and_reproducibility(dev):
+    from geographconv_amd import ops
+    m1 = ops.dropout_mask(4000, 300, 0.5, seed=77, offset=0, device=dev).cpu().numpy()
+    m2 = ops.dropout_mask(4000, 300, 0.5, seed=77, offset=0, device=dev).cpu().numpy()
+    m3 = ops.dropout_mask(4000, 300, 0.5, seed=78, offset=0, device=dev).cpu().numpy()
+    assert np.array_equal(m1, m2) and not np.array_equal(m1, m3)
+    assert set(np.unique(m1)) <= {0, 1}
+    assert abs(m1.mean() - 0.5) < 5e-3
+    m4 = ops.dropout_mask(4000, 300, 0.2, seed=1, offset=0, device=dev).cpu().numpy()
+    assert abs(m4.mean() - 0.8) < 5e-3
+    # no visible row/column structure
+    assert abs(np.corrcoef(m1[:, 0], m1[:, 1])[0, 1]) < 0.06
+
+
+@pytest.mark.parametrize("n,Cc", [(3000, 129), (1000, 256), (50, 930), (7, 2)])
+def test_softmax_ce_head(dev, n, Cc):
+    from geographconv_amd import ops
+    L = _rand((n, Cc), 1, scale=3.0)
+    L[0, :] = 0.0                                   # all-ties row: argmax must be the FIRST index
+    L[1, 5 % Cc] = L[1].max() + 1
+    dL = ops.DMat.from_numpy(L, dev)
+    am = torch.zeros(n, dtype=torch.int32, device=dev)
+    P = ops.softmax_rows(dL, argmax=am)
+    ref = O.softmax_rows(L)
+    assert np.allclose(P.numpy(), ref, rtol=2e-6, atol=1e-9)
+    assert np.array_equal(am.cpu().numpy(), L.argmax(-1))
+    assert am[0].item() == 0
+    assert torch.all(P.t[:, Cc:] == 0)
+    rng = np.random.RandomState(3)
+    idx = rng.choice(n, size=max(1, n // 2), replace=False).astype(np.int32)
+    y = rng.randint(0, Cc, len(idx)).astype(np.int32)
+    y[: len(y) // 3] = ref[idx[: len(y) // 3]].argmax(-1)        # make some hits
+    ti, ty = torch.from_numpy(idx).to(dev), torch.from_numpy(y).to(dev)
+    for amx in (am, None):
+        out2 = ops.ce_metrics(P, ti, ty, argmax=amx).cpu().numpy()
+        loss_ref, acc_ref, _ = O.metrics(ref.astype(np.float64), idx, y)
+        assert abs(out2[0] / len(idx) - loss_ref) <= 2e-6 * abs(loss_ref) + 1e-6
+        assert out2[1] == round(acc_ref * len(idx))
+    D = ops.softmax_ce_bwd(P, ti, ty)
+    refD = np.zeros_like(ref)
+    refD[idx] = ref[idx]
+    refD[idx, y] -= 1
+    refD /= len(idx)
+    assert np.allclose(D.numpy(), refD, rtol=1e-5, atol=1e-9)
+    untouched = np.setdiff1d(np.arange(n), idx)
+    assert np.all(D.numpy()[untouched] == 0)
+
+
+def test_adam_matches_lasagne_formula(dev):
+    from geographconv_amd import ops
+    n = 100003
+    p = _rand((n,), 1)
+    regmask = (np.arange(n) % 3 != 0).astype(np.float32)
+    st = O.AdamState([p])
+    tp = torch.from_numpy(p.copy()).to(dev)
+    tm, tv = torch.zeros_like(tp), torch.zeros_like(tp)
+    tr = torch.from_numpy(regmask).to(dev)
+    cur = [p.copy()]
+    for t in range(1, 4):
+        g = _rand((n,), 10 + t, scale=0.1)
+        reg = 1e-3
+        g_ref = g + regmask * np.float32(reg) * (np.sign(cur[0]) + np.float32(2) * cur[0])
+        cur = O.adam_step(cur, [g_ref.astype(np.float32)], st)
+        ops.adam_step(tp, torch.from_numpy(g).to(dev), tm, tv, tr, 2e-3, 0.9, 0.999, 1e-8, t, l1=reg, l2=reg)
+        assert np.allclose(tp.cpu().numpy(), cur[0], rtol=1e-5, atol=1e-7)
+    pen = ops.reg_penalty(tp, tr, 1e-3, 1e-3).item()
+    pc = tp.cpu().numpy().astype(np.float64)
+    ref = 1e-3 * (np.abs(pc) * regmask).sum() + 1e-3 * (pc * pc * regmask).sum()
+    assert abs(pen - ref) <= 1e-5 * ref
+
+
+def test_cmu_shape_spmm_full_size(dev):
+    """Config 2 operand sizes (CMU shape), all three SpMM flavours of the path."""
+    from geographconv_amd import ops
+    s = synth.CMU
+    A = synth.powerlaw_ahat(s.N, s.E_target)
+    X = synth.bow_x(s.N, s.V, s.mean_nnz)
+    H = np.random.RandomState(1).randn(s.N, 300).astype(np.float32)
+    W0 = _rand((s.V, 300), 2, scale=0.05)
+    dA, dX = ops.CSR(A, dev), ops.CSR(X, dev)
+    dXt = ops.CSR(sps.csr_matrix(X.T), dev)
+    assert dA.n_long_rows > 0
+    got = ops.spmm(dA, ops.DMat.from_numpy(H, dev)).numpy()
+    assert np.allclose(got, O.spmm(A, H), rtol=1e-5, atol=2e-6)
+    got = ops.spmm(dX, ops.DMat.from_numpy(W0, dev)).numpy()
+    assert np.allclose(got, O.spmm(X, W0), rtol=1e-5, atol=2e-6)
+    got = ops.spmm(dXt, ops.DMat.from_numpy(H, dev)).numpy()
+    ref = O.spmm_t(X, H)
+    assert np.allclose(got, ref, rtol=1e-4, atol=2e-5)
