@@ -34,7 +34,8 @@ SIGNATURES = {
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
                                        c_ptr, c_ptr]),
-    'geogcn_tanh_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr]),
+    'geogcn_act_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_f32, c_ptr, c_ptr]),
+    'geogcn_add_inplace_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr]),
     'geogcn_colsum_workspace_bytes': (c_sz, [c_i64, c_i32]),
     'geogcn_colsum_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_dropout_mask_philox': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_u64, c_ptr, c_ptr]),
@@ -43,8 +44,8 @@ SIGNATURES = {
     'geogcn_ce_metrics_workspace_bytes': (c_sz, [c_i64]),
     'geogcn_ce_metrics_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
                                       c_sz, c_ptr]),
-    'geogcn_softmax_ce_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
-                                          c_ptr]),
+    'geogcn_softmax_ce_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr,
+                                          c_i64, c_ptr]),
     'geogcn_gather_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_ptr]),

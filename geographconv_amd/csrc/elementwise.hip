@@ -93,7 +93,8 @@ __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t total4, const 
     }
 }
 
-__global__ __launch_bounds__(TPB) void tanh_bwd_kernel(int64_t n, int F, int F4, const float* __restrict__ G,
+template <int ACT>
+__global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, const float* __restrict__ G,
                                                        const float* __restrict__ Y, int64_t ld,
                                                        const uint8_t* __restrict__ mask, float scale,
                                                        float* __restrict__ dS) {
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(TPB) void tanh_bwd_kernel(int64_t n, int F, int F4,
         for (int i = 0; i < 4; ++i) {
             float gg = go[i];
             if (mask) gg = (c0 + i < F) ? gg * ((float)mask[row * F + c0 + i] * scale) : 0.f;
-            o[i] = gg * (1.0f - yo[i] * yo[i]);
+            if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = gg * (1.0f - yo[i] * yo[i]);
+            else if constexpr (ACT == GEOGCN_ACT_SIGMOID) o[i] = gg * (yo[i] * (1.0f - yo[i]));
+            else o[i] = gg;
         }
         *reinterpret_cast<float4*>(dS + row * ld + c0) = mask_pad(make_float4(o[0], o[1], o[2], o[3]), c0, F);
     }
@@ -205,6 +208,16 @@ __global__ __launch_bounds__(TPB) void gather_rows_kernel(int F, const float* __
     }
 }
 
+__global__ __launch_bounds__(TPB) void add_inplace_kernel(int64_t total4, const float4* __restrict__ X,
+                                                          float4* __restrict__ Y) {
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total4; e += (int64_t)gridDim.x * TPB) {
+        const float4 x = X[e];
+        float4 y = Y[e];
+        y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+        Y[e] = y;
+    }
+}
+
 int64_t colsum_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(n, 64))); }
 
 }  // namespace
@@ -273,15 +286,25 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
     return 0;
 }
 
-int geogcn_tanh_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, const uint8_t* keep_mask,
-                        float scale, float* dS, void* stream) {
-    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "tanh_bwd_f32: negative size");
+int geogcn_act_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
+                       const uint8_t* keep_mask, float scale, float* dS, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "act_bwd_f32: negative size");
     if (n == 0 || F == 0) return 0;
-    CHECK_VEC("tanh_bwd_f32", ld, G, Y, dS);
+    CHECK_VEC("act_bwd_f32", ld, G, Y, dS);
     const int F4 = (F + 3) / 4;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(stream_grid(n * F4)), dim3(TPB), 0, (hipStream_t)stream, n, F, F4, G, Y,
-                       ld, keep_mask, scale, dS);
-    GEOGCN_LAUNCH_CHECK("tanh_bwd_kernel");
+    const dim3 grid(stream_grid(n * F4));
+    hipStream_t st = (hipStream_t)stream;
+    if (act == GEOGCN_ACT_TANH)
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_TANH>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS);
+    else if (act == GEOGCN_ACT_SIGMOID)
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_SIGMOID>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS);
+    else if (act == GEOGCN_ACT_NONE)
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_NONE>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS);
+    else {
+        set_error("act_bwd_f32: unknown act %d", act);
+        return GEOGCN_E_ARG;
+    }
+    GEOGCN_LAUNCH_CHECK("act_bwd_kernel");
     return 0;
 }
 
@@ -337,6 +360,18 @@ int geogcn_dropout_apply_f32(int64_t n, int32_t F, const float* X, int64_t ld, c
     hipLaunchKernelGGL(dropout_apply_kernel, dim3(stream_grid(n * F4)), dim3(TPB), 0, (hipStream_t)stream, n, F, F4, X,
                        ld, keep_mask, 1.0f / (1.0f - p_drop), Y);
     GEOGCN_LAUNCH_CHECK("dropout_apply_kernel");
+    return 0;
+}
+
+int geogcn_add_inplace_f32(int64_t n_floats, const float* X, float* Y, void* stream) {
+    GEOGCN_REQUIRE(n_floats >= 0, GEOGCN_E_SIZE, "add_inplace_f32: negative size");
+    if (n_floats == 0) return 0;
+    GEOGCN_REQUIRE(X && Y, GEOGCN_E_NULL, "add_inplace_f32: null pointer");
+    GEOGCN_REQUIRE(n_floats % 4 == 0 && aligned16(X) && aligned16(Y), GEOGCN_E_ALIGN,
+                   "add_inplace_f32: needs 16-byte aligned operands and n %% 4 == 0");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(stream_grid(n_floats / 4)), dim3(TPB), 0, (hipStream_t)stream,
+                       n_floats / 4, (const float4*)X, (float4*)Y);
+    GEOGCN_LAUNCH_CHECK("add_inplace_kernel");
     return 0;
 }
 

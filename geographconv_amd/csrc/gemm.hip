@@ -119,17 +119,24 @@ __global__ __launch_bounds__(TPB) void gemm_kernel(int64_t M, int64_t N, int64_t
                                                    const float* __restrict__ B, int64_t ldb,
                                                    float* __restrict__ C, int64_t ldc,
                                                    const float* __restrict__ bias, int accumulate,
-                                                   int64_t kchunk, int n_mt, int n_nt) {
+                                                   int64_t kchunk, int n_mt, int n_nt, int xcd_order) {
     using Cfg = GemmCfg<BM, BN, AT, BT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // XCD-aware tile order: consecutive blocks on one XCD (b, b+8, ...) walk the N tiles of one
     // M tile so the A panel is re-read from that XCD's L2.
+    // (few M tiles -- the split-K case -- use the plain order so that every XCD gets work.)
     const int b = blockIdx.x;
-    const int xcd = b % kNumXCD;
-    const int j = b / kNumXCD;
-    const int mt = (j / n_nt) * kNumXCD + xcd;
-    const int nt = j % n_nt;
+    int mt, nt;
+    if (xcd_order) {
+        const int xcd = b % kNumXCD;
+        const int j = b / kNumXCD;
+        mt = (j / n_nt) * kNumXCD + xcd;
+        nt = j % n_nt;
+    } else {
+        mt = b / n_nt;
+        nt = b % n_nt;
+    }
     if (mt >= n_mt) return;
     const int64_t m0 = (int64_t)mt * BM;
     const int64_t n0 = (int64_t)nt * BN;
@@ -276,7 +283,8 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
                 hipStream_t st) {
     using Cfg = GemmCfg<BM, BN, AT, BT>;
     const int n_mt = (int)cdiv(M, BM), n_nt = (int)cdiv(N, BN);
-    const unsigned gx = (unsigned)(cdiv(n_mt, kNumXCD) * kNumXCD * n_nt);
+    const int xcd_order = (n_mt >= 4 * kNumXCD) ? 1 : 0;
+    const unsigned gx = xcd_order ? (unsigned)(cdiv(n_mt, kNumXCD) * kNumXCD * n_nt) : (unsigned)(n_mt * n_nt);
 #define GEOGCN_GEMM_LAUNCH(ACT, MODE, grid, Cptr, ldC, kch)                                              \
     do {                                                                                                  \
         auto kern = gemm_kernel<BM, BN, AT, BT, ACT, MODE>;                                               \
@@ -287,7 +295,7 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
             attr_done = true;                                                                             \
         }                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(TPB), Cfg::kLdsBytes, st, M, N, K, A, lda, B, ldb, Cptr, ldC, \
-                           bias, accumulate, kch, n_mt, n_nt);                                            \
+                           bias, accumulate, kch, n_mt, n_nt, xcd_order);                                          \
         GEOGCN_LAUNCH_CHECK("gemm_kernel");                                                               \
     } while (0)
 

@@ -212,7 +212,8 @@ int geogcn_ce_metrics_f32(int32_t C, const float* probs, int64_t ldp, const int3
 }
 
 int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t ldp, const int32_t* idx,
-                              int64_t n_idx, const int32_t* y, float* dlogits, int64_t ldd, void* stream) {
+                              int64_t n_idx, const int32_t* y, float inv_n, float* dlogits, int64_t ldd,
+                              void* stream) {
     GEOGCN_REQUIRE(n >= 0 && C >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "softmax_ce_bwd_f32: negative size");
     if (n == 0 || C == 0) return 0;
     GEOGCN_REQUIRE(dlogits, GEOGCN_E_NULL, "softmax_ce_bwd_f32: null dlogits");
@@ -222,7 +223,7 @@ int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t 
     if (n_idx == 0) return 0;
     GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "softmax_ce_bwd_f32: null pointer");
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv(n_idx, kWavesPerBlock)), dim3(TPB), 0, st, C, probs, ldp, idx,
-                       n_idx, y, 1.0f / (float)n_idx, dlogits, ldd);
+                       n_idx, y, inv_n, dlogits, ldd);
     GEOGCN_LAUNCH_CHECK("ce_bwd_kernel");
     return 0;
 }

@@ -1,0 +1,472 @@
+"""Drop-in for /root/reference/gcnmodel.py on MI355X: the same layer classes, ``highway_dense``
+and ``GraphConv`` object protocol (build_model / fit / predict / reset / save / load / get_gates),
+with Theano+Lasagne replaced by the gfx950 kernels of libgeogcn.so.
+
+Where the reference builds a symbolic graph and lets ``theano.function`` compile f_train / f_val
+(gcnmodel.py:401-411), this module builds the same layer graph and runs it eagerly: forward with
+a tape, the hand-written reverse sweep (nn.layers.backward), one fused Adam kernel over the flat
+parameter arena.  X and A arrive as scipy CSR float32 host matrices exactly as gcnmain.py passes
+them (gcnmain.py:172-179,221,226) and are uploaded once per distinct matrix."""
+from __future__ import annotations
+
+import logging
+import sys
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import backend
+from .dist import Comm
+from .nn import init as _init
+from .nn import layers as L
+from .nn import nonlinearities as NL
+from .nn.layers import DenseLayer, DropoutLayer  # noqa: F401  (names the reference imports)
+
+logging.basicConfig(format='%(asctime)s %(message)s', datefmt='%m/%d/%Y %I:%M:%S %p', level=logging.INFO)
+
+
+def _is_sparse_operand(x):
+    K = backend.active()
+    return isinstance(x, K.SparseOperand)
+
+
+# --------------------------------------------------------------------------------------------
+# layer zoo (reference gcnmodel.py:29-249)
+# --------------------------------------------------------------------------------------------
+class SparseInputDenseLayer(DenseLayer):
+    """tanh(X_csr . W + b): sparse input, dense output (reference gcnmodel.py:29-42)."""
+
+    def _check_input(self, input):
+        if not _is_sparse_operand(input):
+            raise ValueError("Input for this layer must be sparse")
+
+
+class ConvolutionDenseLayer2(DenseLayer):
+    """act(A . (H . W) + b), A passed through get_output (reference gcnmodel.py:114-136)."""
+
+    def __init__(self, incoming, use_target_indices=False, **kwargs):
+        super().__init__(incoming, **kwargs)
+        self.use_target_indices = use_target_indices
+        if use_target_indices:
+            raise NotImplementedError("use_target_indices is never enabled by the reference (gcnmodel.py:121)")
+
+    def _uses_graph(self, kwargs):
+        return kwargs.get('A') is not None
+
+
+class ConvolutionDenseLayer3(DenseLayer):
+    """Same without the row gather; the softmax output layer (reference gcnmodel.py:138-157,374)."""
+
+    def _uses_graph(self, kwargs):
+        return kwargs.get('A') is not None
+
+
+class SparseConvolutionDenseLayer2(DenseLayer):
+    """act(A . (X_csr . W) + b): sparse input AND graph convolution (reference gcnmodel.py:224-249)."""
+
+    def _check_input(self, input):
+        if not _is_sparse_operand(input):
+            raise ValueError("Input for this layer must be sparse")
+
+    def _uses_graph(self, kwargs):
+        return kwargs.get('A') is not None
+
+    def _matmul(self, input, out):
+        return backend.active().spmm(input.fwd, self.W.data, out=out)
+
+
+class _BoundA(DenseLayer):
+    """Variants that take A at construction instead of through get_output."""
+
+    def __init__(self, incoming, A=None, **kwargs):
+        super().__init__(incoming, **kwargs)
+        self.A = A
+
+    def _uses_graph(self, kwargs):
+        return True
+
+    def forward(self, input, tape, **kwargs):
+        kwargs = dict(kwargs, A=self.A)
+        return super().forward(input, tape, **kwargs)
+
+    def backward(self, grad, tape, into, **kwargs):
+        kwargs = dict(kwargs, A=self.A)
+        return super().backward(grad, tape, into, **kwargs)
+
+
+class ConvolutionDenseLayer_zero(_BoundA):
+    """reference gcnmodel.py:159-179"""
+
+
+class SparseConvolutionDenseLayer(_BoundA):
+    """reference gcnmodel.py:72-92"""
+
+    def _check_input(self, input):
+        if not _is_sparse_operand(input):
+            raise ValueError("Input for this layer must be sparse")
+
+    def _matmul(self, input, out):
+        return backend.active().spmm(input.fwd, self.W.data, out=out)
+
+
+class DenseLayer2(DenseLayer):
+    """Plain dense layer with the (never enabled) row gather flag (reference gcnmodel.py:203-221)."""
+
+    def __init__(self, incoming, use_target_indices=False, **kwargs):
+        super().__init__(incoming, **kwargs)
+        self.use_target_indices = use_target_indices
+
+
+class MultiplicativeGatingLayer(L.MergeLayer):
+    """y = t * h1 + (1 - t) * h2 (reference gcnmodel.py:252-266)."""
+
+    def __init__(self, gate, input1, input2, **kwargs):
+        incomings = [gate, input1, input2]
+        super().__init__(incomings, **kwargs)
+        assert gate.output_shape == input1.output_shape == input2.output_shape
+
+    def get_output_shape_for(self, input_shapes):
+        return input_shapes[0]
+
+    def forward(self, inputs, tape, **kwargs):
+        K = backend.active()
+        t, h1, h2 = inputs
+        y = K.highway_fwd(t, h1, h2)
+        if tape is not None:
+            tape[self] = {'t': t, 'h1': h1, 'h2': h2}
+        return y
+
+    def backward(self, grad, tape, into, **kwargs):
+        K = backend.active()
+        s = tape[self]
+        t, h1, h2 = s['t'], s['h1'], s['h2']
+        gate_l, h1_l, _ = self.input_layers
+        fusable = (into[0] is None and into[1] is None
+                   and isinstance(gate_l, DenseLayer) and gate_l.nonlinearity is NL.sigmoid
+                   and isinstance(h1_l, DenseLayer) and h1_l.nonlinearity is NL.tanh)
+        if not fusable:
+            raise NotImplementedError("gating backward is implemented for the highway pattern "
+                                      "(sigmoid gate, tanh branch) the reference builds (gcnmodel.py:268-288)")
+        # one pass: gradients w.r.t. both PRE-activations and the carry
+        dS, dU, dH = K.highway_bwd(grad, t, h1, h2)
+        if into[2] is not None:
+            K.add_inplace(dH, into[2])
+            dH = into[2]
+        return [L.PreAct(dU), L.PreAct(dS), dH]
+
+
+def highway_dense(incoming, gconv=False, Wh=_init.GlorotUniform(), bh=_init.Constant(0.0),
+                  Wt=_init.GlorotUniform(), bt=_init.Constant(-4.0), nonlinearity=NL.sigmoid, **kwargs):
+    """Highway block (reference gcnmodel.py:268-288): branch l_h (graph conv if gconv), gate l_t =
+    sigmoid dense with bt=-4, output MultiplicativeGatingLayer(l_t, l_h, incoming).  Construction
+    order l_h then l_t is kept: it fixes the order of the initialiser draws."""
+    num_inputs = int(np.prod(incoming.output_shape[1:]))
+    if gconv:
+        l_h = ConvolutionDenseLayer2(incoming, num_units=num_inputs, W=Wh, b=bh, nonlinearity=nonlinearity)
+    else:
+        l_h = DenseLayer(incoming, num_units=num_inputs, W=Wh, b=bh, nonlinearity=nonlinearity)
+    l_t = DenseLayer(incoming, num_units=num_inputs, W=Wt, b=bt, nonlinearity=NL.sigmoid)
+    return MultiplicativeGatingLayer(gate=l_t, input1=l_h, input2=incoming), l_t
+
+
+def np_softmax(x):
+    e_x = np.exp(x - np.max(x))
+    return e_x / e_x.sum()
+
+
+class LazyArray:
+    """The N x C probability matrix f_train hands back every epoch (reference gcnmodel.py:410,430
+    -- fit() discards it).  Stays on the device until somebody looks."""
+
+    def __init__(self, fetch, shape):
+        self._fetch, self.shape, self._v = fetch, shape, None
+
+    def get(self):
+        if self._v is None:
+            self._v = self._fetch()
+        return self._v
+
+    def __array__(self, dtype=None, copy=None):
+        v = self.get()
+        return v if dtype is None else v.astype(dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# GraphConv (reference gcnmodel.py:316-477)
+# --------------------------------------------------------------------------------------------
+class GraphConv():
+    '''
+    Graph convolutional network (Kipf 2016 style) with sparse BoW input -- same constructor and
+    methods as the reference class; `device` and `comm` are the only additions.
+    '''
+
+    def __init__(self, input_size, output_size, hid_size_list, regul_coef, drop_out, dtype='float32',
+                 batchnorm=False, highway=True, device=None, comm=None):
+        self.input_size = int(input_size)
+        self.output_size = int(output_size)
+        self.hid_size_list = list(hid_size_list)
+        self.regul_coef = regul_coef
+        self.drop_out = drop_out
+        if dtype != 'float32':
+            raise ValueError("the reference path is float32 (gcnmain.py:167); got %r" % dtype)
+        self.dtype = dtype
+        self.dtypeint = 'int32'
+        self.fitted = False
+        self.batchnorm = batchnorm
+        self.highway = highway
+        self.device = device
+        self.comm = comm
+        self._graph_cache = {}
+        self._idx_cache = {}
+        self._injected_mask = None
+        self.best_params = None
+        logging.info('highway is {}'.format(self.highway))
+
+    # -- construction (reference gcnmodel.py:335-416) -----------------------------------------
+    def build_model(self, A=None, use_text=True, use_labels=True, seed=77):
+        K = backend.active()
+        K.require_gpu()
+        import torch
+        if self.device is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        np.random.seed(seed)
+        logging.info('Graphconv model input size {}, output size {} and hidden layers {} regul {} dropout {}.'.format(
+            self.input_size, self.output_size, str(self.hid_size_list), self.regul_coef, self.drop_out))
+        nonlinearity = NL.tanh
+        Wh = _init.GlorotUniform(gain=1)
+
+        self.l_in = l_in = L.InputLayer(shape=(None, self.input_size))
+        l_hid = SparseInputDenseLayer(l_in, num_units=self.hid_size_list[0], nonlinearity=nonlinearity)
+        self.l_drop = l_hid = L.dropout(l_hid, p=self.drop_out)
+        Wt_txt = _init.Orthogonal()
+        self.gate_layers = []
+        logging.info('{} gconv layers'.format(len(self.hid_size_list)))
+        if len(self.hid_size_list) > 1:
+            for i, hid_size in enumerate(self.hid_size_list):
+                if i == 0:
+                    continue        # the first hidden layer is the non-convolutional one above
+                if self.highway:
+                    l_hid, l_t_hid = highway_dense(l_hid, gconv=True, nonlinearity=nonlinearity, Wt=Wt_txt, Wh=Wh)
+                    self.gate_layers.append(l_t_hid)
+                else:
+                    l_hid = ConvolutionDenseLayer2(l_hid, num_units=hid_size, nonlinearity=nonlinearity)
+        self.l_out = ConvolutionDenseLayer3(l_hid, num_units=self.output_size, nonlinearity=NL.softmax)
+
+        # "compile": put the parameters on the device in one arena
+        self.parameters = L.get_all_params(self.l_out, trainable=True)
+        self.store = L.ParamStore(L.get_all_params(self.l_out), self.device)
+        self.adam_t = 0
+        self.lr, self.beta1, self.beta2, self.epsilon = 2e-3, 0.9, 0.999, 1e-8      # gcnmodel.py:407
+        self.f_gates = [self._make_f_gate(l) for l in self.gate_layers]
+        self.init_params = L.get_all_param_values(self.l_out)
+        self._scal = torch.zeros(8, dtype=torch.float32, device=self.device)
+        return self.l_out
+
+    # -- device residency of the constant inputs ------------------------------------------------
+    def _comm_for(self, N):
+        if self.comm is None:
+            return Comm(N, self.device)
+        if self.comm.part is None or self.comm.part.N != N:
+            raise ValueError("communicator was built for N=%r, graph has N=%d" % (
+                None if self.comm.part is None else self.comm.part.N, N))
+        return self.comm
+
+    def _device_graph(self, X, A):
+        """Upload (X, A) once per distinct pair of host matrices; row-partition when distributed."""
+        K = backend.active()
+        key = (id(X), id(A))
+        hit = self._graph_cache.get(key)
+        if hit is not None and hit['X_ref'] is X and hit['A_ref'] is A:
+            return hit
+        if not sps.issparse(X):
+            raise ValueError("Input for this layer must be sparse")
+        N = X.shape[0]
+        comm = self._comm_for(N)
+        part = comm.part
+        if comm.world > 1:
+            A_csr = sps.csr_matrix(A)
+            At = sps.csr_matrix(A_csr.T)
+            A_loc = part.local_rows_csr(A_csr, part.n_gathered)
+            At_loc = part.local_rows_csr(At, part.n_gathered)
+            same = (A_loc != At_loc).nnz == 0
+            fwd = K.CSR(A_loc, self.device)
+            bwd = fwd if same else K.CSR(At_loc, self.device)
+            dA = K.SparseOperand(fwd, bwd, same)
+            dX = K.SparseOperand.from_scipy(part.local_rows(sps.csr_matrix(X)), self.device)
+        else:
+            dA = K.SparseOperand.from_scipy(A, self.device)
+            dX = K.SparseOperand.from_scipy(X, self.device)
+        hit = {'X_ref': X, 'A_ref': A, 'X': dX, 'A': dA, 'N': N, 'comm': comm}
+        self._graph_cache = {key: hit}          # one graph resident at a time
+        self._idx_cache = {}
+        return hit
+
+    def _device_indices(self, comm, idx, y=None):
+        """Index / label vectors on the device (local share when distributed) + the global count."""
+        import torch
+        idx = np.asarray(idx)
+        ya = None if y is None else np.asarray(y)
+        key = (idx.ctypes.data, len(idx), int(idx.sum()), None if ya is None else (ya.ctypes.data, int(ya.sum())))
+        hit = self._idx_cache.get(key)
+        if hit is not None and np.array_equal(hit[3], idx[:16]):
+            return hit[:3]
+        if idx.size and (idx.min() < 0 or idx.max() >= comm.part.N):
+            raise IndexError("index out of bounds for %d nodes" % comm.part.N)
+        loc, yloc, _ = comm.part.split_indices(idx, y)
+        t_idx = torch.from_numpy(np.ascontiguousarray(loc, dtype=np.int32)).to(self.device)
+        t_y = None if y is None else torch.from_numpy(np.ascontiguousarray(yloc, dtype=np.int32)).to(self.device)
+        out = (t_idx, t_y, len(idx))
+        if len(self._idx_cache) > 8:
+            self._idx_cache.clear()
+        self._idx_cache[key] = out + (idx[:16].copy(),)
+        return out
+
+    # -- f_train (reference gcnmodel.py:375-389, 406-410) ----------------------------------------
+    def inject_dropout_mask(self, mask):
+        """Parity hook: use this keep-mask (N x hid[0], 0/1) in the next f_train calls instead of
+        the Philox stream (Theano's MRG31k3p draws cannot be reproduced)."""
+        self._injected_mask = None if mask is None else np.ascontiguousarray(mask).astype(np.uint8)
+
+    def f_train(self, X, y_train, y_dev, A, train_indices, dev_indices):
+        """One full-graph forward + backward + Adam step.  -> [train_loss, train_acc, dev_loss,
+        dev_acc, output(N x C)]; dev metrics come from the same dropout-ON pass (gcnmodel.py:378)."""
+        K = backend.active()
+        import torch
+        g = self._device_graph(X, A)
+        comm = g['comm']
+        tr_idx, tr_y, n_tr = self._device_indices(comm, train_indices, y_train)
+        dv_idx, dv_y, n_dv = self._device_indices(comm, dev_indices, y_dev)
+        mask = None
+        if self._injected_mask is not None and self.drop_out > 0:
+            m = self._injected_mask
+            if comm.world > 1:
+                m = m[comm.part.r0:comm.part.r1]
+            mask = torch.from_numpy(np.ascontiguousarray(m)).to(self.device)
+        tape = {}
+        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if comm.world > 1 else None)
+        P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
+        amax = tape[self.l_out]['argmax']
+        sc = self._scal
+        K.ce_metrics(P, tr_idx, tr_y, argmax=amax, out2=sc[0:2])
+        K.ce_metrics(P, dv_idx, dv_y, argmax=amax, out2=sc[2:4])
+        if self.regul_coef > 0:
+            K.reg_penalty(self.store.p, self.store.regmask, self.regul_coef, self.regul_coef, out=sc[4:5])
+        # backward: d(mean CE over train rows)/d logits, then the reverse sweep
+        dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr))
+        L.backward(self.l_out, L.PreAct(dlogits), tape, **kw)
+        if comm.world > 1:
+            comm.all_reduce_sum_(self.store.g)
+            comm.all_reduce_sum_(sc[0:4])
+        self.adam_t += 1
+        K.adam_step(self.store.p, self.store.g, self.store.m, self.store.v, self.store.regmask, self.lr,
+                    self.beta1, self.beta2, self.epsilon, self.adam_t, l1=self.regul_coef, l2=self.regul_coef)
+        s = sc.cpu().numpy()                     # the one host sync of the step
+        l_tr = s[0] / max(1, n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
+        out = [np.float32(l_tr), np.float64(s[1] / max(1, n_tr)), np.float32(s[2] / max(1, n_dv)),
+               np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm)]
+        return out
+
+    def _lazy_output(self, P, comm):
+        def fetch():
+            if comm.world > 1:
+                buf, loc = comm.gather_buffer(P.F, tag='out')
+                loc.t.copy_(P.t)
+                comm.all_gather_rows_(buf)
+                return buf.numpy()[:comm.part.N]
+            return P.numpy()
+        return LazyArray(fetch, (comm.part.N, P.F))
+
+    # -- f_val (reference gcnmodel.py:392-394, 411) ------------------------------------------------
+    def f_val(self, X, A, test_indices):
+        K = backend.active()
+        import torch
+        g = self._device_graph(X, A)
+        comm = g['comm']
+        kw = dict(A=g['A'], deterministic=True, comm=comm if comm.world > 1 else None)
+        tape = {}
+        P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
+        amax = tape[self.l_out]['argmax']
+        idx = np.asarray(test_indices)
+        if comm.world > 1:
+            full = self._lazy_output(P, comm).get()
+            rows = full[idx]
+            return rows.argmax(-1).astype(np.int64), rows
+        t_idx, _, _ = self._device_indices(comm, idx)
+        rows = K.gather_rows(P, t_idx).cpu().numpy()
+        pred = amax[t_idx.long()].cpu().numpy().astype(np.int64)
+        return pred, rows
+
+    def _make_f_gate(self, layer):
+        def f_gate(X, A):
+            g = self._device_graph(X, A)
+            comm = g['comm']
+            kw = dict(A=g['A'], deterministic=True, comm=comm if comm.world > 1 else None)
+            T = L.get_output(layer, {self.l_in: g['X']}, **kw)
+            return T.numpy()
+        return f_gate
+
+    # -- training loop (reference gcnmodel.py:418-450) -------------------------------------------
+    def fit(self, X, H, Y, train_indices, val_indices, n_epochs=10000, batch_size=1000, max_down=10,
+            pseudolikelihood_thresh=0.2, verbose=True, seed=77):
+        np.random.seed(seed)
+        logging.info('training for {} epochs with batch size {}'.format(n_epochs, batch_size))
+        best_params = None
+        best_val_loss = sys.maxsize
+        best_val_acc = 0.0
+        n_validation_down = 0
+        report_k_epoch = 1
+
+        X_train, y_train = X, Y[train_indices]
+        y_dev = Y[val_indices]
+        for n in range(n_epochs):
+            l_train, acc_train, l_val, acc_val, all_probs = self.f_train(X_train, y_train, y_dev, H, train_indices,
+                                                                         val_indices)
+            l_train, acc_train = l_train.item(), acc_train.item()
+            l_val, acc_val = l_val.item(), acc_val.item()
+
+            if l_val < best_val_loss:
+                best_val_loss = l_val
+                best_val_acc = acc_val
+                best_params = self.store.p.clone()      # device snapshot (reference: get_all_param_values)
+                n_validation_down = 0
+            else:
+                n_validation_down += 1
+            if verbose:
+                if n % report_k_epoch == 0:
+                    logging.info('epoch {} train loss {:.2f} train acc {:.2f} val loss {:.2f} val acc {:.2f} best val acc {:.2f} maxdown {}'.format(
+                        n, l_train, acc_train, l_val, acc_val, best_val_acc, n_validation_down))
+            if n_validation_down > max_down and n > 2 * report_k_epoch * max_down:
+                logging.info('validation results went down. early stopping ...')
+                break
+        if best_params is not None:
+            self.store.p.copy_(best_params)
+        self.best_params = L.get_all_param_values(self.l_out)
+        self.fitted = True
+
+    def predict(self, X, A, test_indices):
+        preds_test, prob_test = self.f_val(X, A, test_indices)
+        return preds_test, prob_test
+
+    def reset(self):
+        # parameters only: Adam's m / v / t live on, as in the reference (gcnmodel.py:456-457)
+        L.set_all_param_values(self.l_out, self.init_params)
+
+    def save(self, dumper, filename='./model.pkl'):
+        if self.fitted:
+            logging.info('dumping model params in {}'.format(filename))
+            dumper(self.best_params, filename)
+        else:
+            logging.warning('The model is not trained yet!')
+
+    def load(self, loader, filename):
+        logging.info('loading the model from {}'.format(filename))
+        self.best_params = loader(filename)
+        L.set_all_param_values(self.l_out, self.best_params)
+        self.fitted = True
+
+    def get_gates(self, X, A):
+        return [fn(X, A) for fn in self.f_gates]
+
+    # -- introspection used by the parity tests ---------------------------------------------------
+    def get_grads(self):
+        return [self.store.read_grad(p) for p in self.store.params]

@@ -1,0 +1,524 @@
+"""Lasagne-like layers over the gfx950 kernels.
+
+The constructors, ``get_output_for`` protocol, parameter tags and helper functions follow what
+the reference uses from ``lasagne.layers`` (reference gcnmodel.py:8-14, :29-294, :351-414).  What
+differs from Lasagne -- by necessity, there is no Theano here -- is that evaluation is eager on the
+device and that every layer carries a hand-written ``backward`` (Theano's autodiff derived those
+for the reference).  Values flowing between layers are backend ``DMat`` (dense, row-major fp32 on
+the GPU) or ``SparseOperand`` (constant CSR input such as X)."""
+from __future__ import annotations
+
+from collections import OrderedDict, deque
+
+import numpy as np
+
+from .. import backend
+from . import init as _init
+from . import nonlinearities as _nl
+
+
+# --------------------------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------------------------
+class Param:
+    """Stand-in for a Theano shared variable: host value until bound to a device arena by
+    ``ParamStore`` (then ``data``/``grad`` are views of the flat p / g arenas)."""
+
+    def __init__(self, value: np.ndarray, name: str, tags: set):
+        self.value = np.asarray(value, dtype=np.float32)
+        self.shape = self.value.shape
+        self.name = name
+        self.tags = set(tags)
+        self.data = None      # DMat (matrix) or 1-D tensor (vector) once bound
+        self.grad = None
+        self._store = None
+
+    def get_value(self):
+        if self._store is not None:
+            return self._store.read(self)
+        return self.value.copy()
+
+    def set_value(self, v):
+        v = np.asarray(v, dtype=np.float32)
+        if v.shape != self.shape:
+            raise ValueError("mismatch: parameter %s has shape %r but value to set has shape %r"
+                             % (self.name, self.shape, v.shape))
+        if self._store is not None:
+            self._store.write(self, v)
+        else:
+            self.value = v.copy()
+
+    def __repr__(self):
+        return "<Param %s %r>" % (self.name, self.shape)
+
+
+class ParamStore:
+    """Flat device arenas for all parameters of a network: values p, gradients g, Adam m / v and
+    the `regularizable` mask -- so the optimiser (lasagne.updates.adam, gcnmodel.py:407) is ONE
+    kernel over one array and the multi-GPU gradient all-reduce is ONE collective."""
+
+    def __init__(self, params, device):
+        K = backend.active()
+        import torch
+        self.device = device
+        self.params = list(params)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            if len(p.shape) == 2:
+                off += p.shape[0] * K.pad4(p.shape[1])
+            else:
+                off += K.pad4(p.shape[0])
+        self.n = off
+        z = lambda: torch.zeros(max(off, 4), dtype=torch.float32, device=device)
+        self.p, self.g, self.m, self.v, self.regmask = z(), z(), z(), z(), z()
+        for p, o in zip(self.params, self.offsets):
+            if len(p.shape) == 2:
+                r, c = p.shape
+                ld = K.pad4(c)
+                p.data = K.DMat(r, c, t=self.p[o:o + r * ld].view(r, ld))
+                p.grad = K.DMat(r, c, t=self.g[o:o + r * ld].view(r, ld))
+                if 'regularizable' in p.tags:
+                    self.regmask[o:o + r * ld].view(r, ld)[:, :c] = 1.0
+            else:
+                c = p.shape[0]
+                p.data = self.p[o:o + K.pad4(c)]
+                p.grad = self.g[o:o + K.pad4(c)]
+            p._store = self
+            self.write(p, p.value)
+
+    def write(self, p, v):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.device)
+        if len(p.shape) == 2:
+            p.data.t[:, :p.shape[1]].copy_(t)
+        else:
+            p.data[:p.shape[0]].copy_(t)
+
+    def read(self, p):
+        if len(p.shape) == 2:
+            return p.data.t[:, :p.shape[1]].cpu().numpy()
+        return p.data[:p.shape[0]].cpu().numpy()
+
+    def read_grad(self, p):
+        if len(p.shape) == 2:
+            return p.grad.t[:, :p.shape[1]].cpu().numpy()
+        return p.grad[:p.shape[0]].cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# gradient token: "this is already the gradient w.r.t. the PRE-activation"
+# --------------------------------------------------------------------------------------------
+class PreAct:
+    def __init__(self, m):
+        self.m = m
+
+
+# --------------------------------------------------------------------------------------------
+# base classes (lasagne.layers.base)
+# --------------------------------------------------------------------------------------------
+class Layer:
+    def __init__(self, incoming, name=None):
+        if isinstance(incoming, tuple):
+            self.input_shape = incoming
+            self.input_layer = None
+        else:
+            self.input_shape = incoming.output_shape
+            self.input_layer = incoming
+        self.name = name
+        self.params = OrderedDict()
+
+    @property
+    def output_shape(self):
+        return self.get_output_shape_for(self.input_shape)
+
+    def get_params(self, unwrap_shared=True, **tags):
+        result = list(self.params.keys())
+        only = set(tag for tag, value in tags.items() if value)
+        if only:
+            result = [p for p in result if not (only - self.params[p])]
+        exclude = set(tag for tag, value in tags.items() if not value)
+        if exclude:
+            result = [p for p in result if not (self.params[p] & exclude)]
+        return result
+
+    def get_output_shape_for(self, input_shape):
+        return input_shape
+
+    def add_param(self, spec, shape, name=None, **tags):
+        if name is not None and self.name is not None:
+            name = "%s.%s" % (self.name, name)
+        tags['trainable'] = tags.get('trainable', True)
+        tags['regularizable'] = tags.get('regularizable', True)
+        if isinstance(spec, Param):
+            param = spec
+        else:
+            value = spec(shape) if callable(spec) else np.asarray(spec, dtype=np.float32)
+            if tuple(value.shape) != tuple(shape):
+                raise ValueError("parameter %s: initialiser gave shape %r, expected %r" % (name, value.shape, shape))
+            param = Param(value, name, set())
+        self.params[param] = set(tag for tag, value in tags.items() if value)
+        param.tags = self.params[param]
+        return param
+
+    # -- evaluation ---------------------------------------------------------------------------
+    def get_output_for(self, input, **kwargs):
+        """Lasagne's per-layer forward; here eager on the device."""
+        return self.forward(input, None, **kwargs)
+
+    def forward(self, input, tape, **kwargs):
+        raise NotImplementedError
+
+    def backward(self, grad, tape, into, **kwargs):
+        """-> [grad wrt each input].  `into[i]` is an existing gradient buffer of input i to
+        accumulate into (or None)."""
+        raise NotImplementedError
+
+
+class MergeLayer(Layer):
+    def __init__(self, incomings, name=None):
+        self.input_shapes = [inc if isinstance(inc, tuple) else inc.output_shape for inc in incomings]
+        self.input_layers = [None if isinstance(inc, tuple) else inc for inc in incomings]
+        self.name = name
+        self.params = OrderedDict()
+
+    @property
+    def output_shape(self):
+        return self.get_output_shape_for(self.input_shapes)
+
+
+class InputLayer(Layer):
+    def __init__(self, shape, input_var=None, name=None):
+        self.shape = tuple(shape)
+        self.input_var = input_var
+        self.name = name
+        self.params = OrderedDict()
+
+    @property
+    def output_shape(self):
+        return self.shape
+
+
+def _accumulate(dst, src):
+    backend.active().add_inplace(src, dst)
+    return dst
+
+
+# --------------------------------------------------------------------------------------------
+# dense / dropout (lasagne.layers.dense, lasagne.layers.noise)
+# --------------------------------------------------------------------------------------------
+class DenseLayer(Layer):
+    """y = nonlinearity(x . W + b)   (lasagne DenseLayer; the highway gate, gcnmodel.py:285)."""
+
+    def __init__(self, incoming, num_units, W=_init.GlorotUniform(), b=_init.Constant(0.), nonlinearity=_nl.rectify,
+                 name=None, **kwargs):
+        super().__init__(incoming, name)
+        self.nonlinearity = _nl.resolve(nonlinearity)
+        self.num_units = int(num_units)
+        num_inputs = int(np.prod(self.input_shape[1:]))
+        self.W = self.add_param(W, (num_inputs, self.num_units), name="W")
+        self.b = None if b is None else self.add_param(b, (self.num_units,), name="b", regularizable=False)
+
+    def get_output_shape_for(self, input_shape):
+        return (input_shape[0], self.num_units)
+
+    # the graph-convolution subclasses override these three hooks -----------------------------
+    def _uses_graph(self, kwargs):
+        return False
+
+    def _check_input(self, input):
+        K = backend.active()
+        if not isinstance(input, K.DMat):
+            raise ValueError("Input for this layer must be dense")
+
+    def _matmul(self, input, out):
+        return backend.active().gemm(input, self.W.data, out=out)
+
+    def _fused_act(self):
+        if self.nonlinearity.act is None and self.nonlinearity is not _nl.softmax:
+            raise NotImplementedError("nonlinearity %s has no gfx950 epilogue yet" % self.nonlinearity.name)
+        return 0 if self.nonlinearity is _nl.softmax else self.nonlinearity.act
+
+    def forward(self, input, tape, **kwargs):
+        K = backend.active()
+        self._check_input(input)
+        if self.W.data is None:
+            raise RuntimeError("parameters are not on the device yet: bind them with ParamStore")
+        bias = None if self.b is None else self.b.data
+        act = self._fused_act()
+        A = kwargs.get('A') if self._uses_graph(kwargs) else None
+        saved = {'x': input}
+        if A is None:
+            if isinstance(input, K.DMat):
+                y = K.gemm(input, self.W.data, bias=bias, act=act)        # bias + act fused in the epilogue
+            else:
+                y = K.spmm(input.fwd, self.W.data, bias=bias, act=act)    # sparse input: X.W0
+        else:
+            comm = kwargs.get('comm')
+            if comm is None:
+                z = self._matmul(input, None)
+                zf = z
+            else:
+                zf, zloc = comm.gather_buffer(self.num_units, tag='fwd')
+                self._matmul(input, zloc)
+                comm.all_gather_rows_(zf)
+            y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
+        if self.nonlinearity is _nl.softmax:
+            import torch
+            amax = torch.empty(y.n, dtype=torch.int32, device=y.device)
+            saved['logits'] = y
+            y = K.softmax_rows(y, argmax=amax)
+            saved['argmax'] = amax
+        saved['y'] = y
+        if tape is not None:
+            tape[self] = saved
+        return y
+
+    def backward(self, grad, tape, into, need_input_grad=True, **kwargs):
+        K = backend.active()
+        s = tape[self]
+        x, y = s['x'], s['y']
+        if isinstance(grad, PreAct):
+            dS = grad.m
+        elif self.nonlinearity is _nl.softmax:
+            raise NotImplementedError("softmax output expects the fused CE gradient (PreAct)")
+        elif self.nonlinearity.act == 0:
+            dS = grad
+        else:
+            dS = K.act_bwd(grad, y, self.nonlinearity.act)
+        if self.b is not None:
+            K.colsum(dS, out=self.b.grad)
+        A = kwargs.get('A') if self._uses_graph(kwargs) else None
+        if A is not None:
+            comm = kwargs.get('comm')
+            if comm is None:
+                dZ = K.spmm(A.bwd, dS)
+            else:
+                gf, gloc = comm.gather_buffer(self.num_units, tag='bwd')
+                gloc.t.copy_(dS.t)
+                comm.all_gather_rows_(gf)
+                dZ = K.spmm(A.bwd, gf, F=self.num_units)
+        else:
+            dZ = dS
+        if isinstance(x, K.DMat):
+            K.gemm(x, dZ, out=self.W.grad, transA=True)                    # dW = H^T . dZ
+            if not need_input_grad:
+                return [None]
+            if into[0] is not None:
+                return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True)]
+            return [K.gemm(dZ, self.W.data, transB=True)]                  # dH = dZ . W^T
+        K.spmm(x.bwd, dZ, out=self.W.grad)                                 # dW0 = X^T . dS0
+        return [None]
+
+
+class DropoutLayer(Layer):
+    """x / (1-p) * Bernoulli(1-p) mask; identity if deterministic or p == 0 (lasagne DropoutLayer,
+    reference gcnmodel.py:357).  The mask comes from a counter-based Philox stream seeded like
+    Lasagne seeds its MRG stream (one np.random.randint at construction); pass `dropout_mask=`
+    (uint8 keep-mask on the device) through get_output to inject a mask for parity runs."""
+
+    def __init__(self, incoming, p=0.5, rescale=True, name=None, **kwargs):
+        super().__init__(incoming, name)
+        self._seed = int(np.random.randint(1, 2147462579))
+        self._calls = 0
+        self.p = p
+        self.rescale = rescale
+
+    def forward(self, input, tape, deterministic=False, dropout_mask=None, **kwargs):
+        K = backend.active()
+        if deterministic or self.p == 0:
+            if tape is not None:
+                tape[self] = {'mask': None}
+            return input
+        if not self.rescale:
+            raise NotImplementedError("rescale=False is not used by the reference path")
+        mask = dropout_mask
+        if mask is None:
+            comm = kwargs.get('comm')
+            r0 = 0 if comm is None or comm.part is None else comm.part.r0
+            # counter offset: rows are numbered globally so every rank draws its own slice of the
+            # same stream; successive calls advance the stream by N_total * F elements
+            # (rank-consistent when F % 4 == 0: Philox yields 4 values per counter)
+            F = input.F
+            N_total = input.n if comm is None or comm.part is None else comm.part.N
+            offset_quads = ((self._calls * N_total + r0) * F) // 4
+            mask = K.dropout_mask(input.n, F, self.p, self._seed, offset_quads, input.device)
+            self._calls += 1
+        y = K.dropout_apply(input, mask, self.p)
+        if tape is not None:
+            tape[self] = {'mask': mask}
+        return y
+
+    def backward(self, grad, tape, into, **kwargs):
+        K = backend.active()
+        mask = tape[self]['mask']
+        g = grad if mask is None else K.dropout_apply(grad, mask, self.p)
+        if into[0] is not None:
+            return [_accumulate(into[0], g)]
+        return [g]
+
+
+dropout = DropoutLayer
+
+
+class NonlinearityLayer(Layer):
+    def __init__(self, incoming, nonlinearity=_nl.rectify, name=None, **kwargs):
+        super().__init__(incoming, name)
+        self.nonlinearity = _nl.resolve(nonlinearity)
+
+    def forward(self, input, tape, **kwargs):
+        K = backend.active()
+        if self.nonlinearity.act is None:
+            raise NotImplementedError("nonlinearity %s has no gfx950 kernel yet" % self.nonlinearity.name)
+        y = K.bias_act(input, None, self.nonlinearity.act)
+        if tape is not None:
+            tape[self] = {'y': y}
+        return y
+
+    def backward(self, grad, tape, into, **kwargs):
+        K = backend.active()
+        g = K.act_bwd(grad, tape[self]['y'], self.nonlinearity.act)
+        return [_accumulate(into[0], g) if into[0] is not None else g]
+
+
+class ElemwiseSumLayer(MergeLayer):
+    def __init__(self, incomings, coeffs=1, cropping=None, name=None, **kwargs):
+        super().__init__(incomings, name)
+        if coeffs != 1 or cropping is not None:
+            raise NotImplementedError("only coeffs=1, cropping=None (reference gcnmodel.py:293)")
+
+    def get_output_shape_for(self, input_shapes):
+        return input_shapes[0]
+
+    def forward(self, inputs, tape, **kwargs):
+        K = backend.active()
+        out = inputs[0].like()
+        out.t.copy_(inputs[0].t)
+        for x in inputs[1:]:
+            K.add_inplace(x, out)
+        return out
+
+    def backward(self, grad, tape, into, **kwargs):
+        outs = []
+        for k, b in enumerate(into):
+            if b is not None:
+                outs.append(_accumulate(b, grad))
+            elif k == 0:
+                outs.append(grad)
+            else:                       # each input needs its own buffer (later accumulations are in place)
+                c = grad.like()
+                c.t.copy_(grad.t)
+                outs.append(c)
+        return outs
+
+
+# --------------------------------------------------------------------------------------------
+# graph helpers (lasagne.layers.helper)
+# --------------------------------------------------------------------------------------------
+def get_all_layers(layer, treat_as_input=None):
+    """Topological order, inputs before the layer that consumes them (lasagne helper.py)."""
+    try:
+        queue = deque(layer)
+    except TypeError:
+        queue = deque([layer])
+    seen, done, result = set(), set(), []
+    if treat_as_input is not None:
+        seen.update(treat_as_input)
+    while queue:
+        layer = queue[0]
+        if layer is None:
+            queue.popleft()
+        elif layer not in seen:
+            seen.add(layer)
+            if hasattr(layer, 'input_layers'):
+                queue.extendleft(reversed(layer.input_layers))
+            elif hasattr(layer, 'input_layer'):
+                queue.appendleft(layer.input_layer)
+        else:
+            queue.popleft()
+            if layer not in done:
+                result.append(layer)
+                done.add(layer)
+    return result
+
+
+def get_output(layer_or_layers, inputs=None, tape=None, **kwargs):
+    """Evaluate the network.  `inputs` maps InputLayers to values (as the reference calls it:
+    get_output(l_out, {l_in: X}, A=A, deterministic=...), gcnmodel.py:375,392,400); every kwarg is
+    forwarded to every layer's forward / get_output_for, as in Lasagne."""
+    all_layers = get_all_layers(layer_or_layers)
+    values = {}
+    if isinstance(inputs, dict):
+        values.update(inputs)
+    elif inputs is not None:
+        ins = [l for l in all_layers if isinstance(l, InputLayer)]
+        if len(ins) != 1:
+            raise ValueError("a bare input value needs a network with exactly one InputLayer")
+        values[ins[0]] = inputs
+    for layer in all_layers:
+        if layer in values:
+            continue
+        if isinstance(layer, InputLayer):
+            if layer.input_var is None:
+                raise ValueError("no value for InputLayer %r" % layer.name)
+            values[layer] = layer.input_var
+            continue
+        if hasattr(layer, 'input_layers'):
+            x = [values[l] for l in layer.input_layers]
+        else:
+            x = values[layer.input_layer]
+        values[layer] = layer.forward(x, tape, **kwargs)
+    if tape is not None:
+        tape['__values__'] = values
+    try:
+        return [values[l] for l in layer_or_layers]
+    except TypeError:
+        return values[layer_or_layers]
+
+
+def backward(layer, grad, tape, **kwargs):
+    """Reverse sweep over the layer DAG (what theano.grad did for the reference).  `grad` is the
+    gradient at `layer`'s output (or a PreAct token); parameter gradients land in Param.grad."""
+    all_layers = get_all_layers(layer)
+    grads = {layer: grad}
+    # which layers lie on a path from a parameterised/needed layer: all of them need grads except
+    # pure inputs
+    for l in reversed(all_layers):
+        if isinstance(l, InputLayer) or l not in grads:
+            continue
+        g = grads.pop(l)
+        ins = l.input_layers if hasattr(l, 'input_layers') else [l.input_layer]
+        into = [grads.get(i) if not isinstance(i, InputLayer) else None for i in ins]
+        need = [not isinstance(i, InputLayer) for i in ins]
+        outs = l.backward(g, tape, into, need_input_grad=any(need), **kwargs)
+        for i, o in zip(ins, outs):
+            if o is not None and not isinstance(i, InputLayer):
+                grads[i] = o
+    return grads
+
+
+def get_all_params(layer, unwrap_shared=True, **tags):
+    seen, out = set(), []
+    for l in get_all_layers(layer):
+        for p in l.get_params(**tags):
+            if p not in seen:
+                seen.add(p)
+                out.append(p)
+    return out
+
+
+def count_params(layer, **tags):
+    return int(sum(np.prod(p.shape) for p in get_all_params(layer, **tags)))
+
+
+def get_all_param_values(layer, **tags):
+    return [p.get_value() for p in get_all_params(layer, **tags)]
+
+
+def set_all_param_values(layer, values, **tags):
+    params = get_all_params(layer, **tags)
+    if len(params) != len(values):
+        raise ValueError("mismatch: got %d values to set %d parameters" % (len(values), len(params)))
+    for p, v in zip(params, values):
+        p.set_value(v)

@@ -66,7 +66,15 @@ class DMat:
         return self.t[:, :self.F].cpu().numpy()
 
     def like(self):
-        return DMat(self.n, self.F, self.t.device)
+        return DMat.empty(self.n, self.F, self.t.device)
+
+    @staticmethod
+    def empty(n, F, device):
+        """Uninitialised when there are no pad columns (the producer writes every element);
+        zero-filled otherwise so the pads honour the zero convention."""
+        if pad4(F) == int(F):
+            return DMat(n, F, t=torch.empty((int(n), int(F)), dtype=torch.float32, device=device))
+        return DMat(n, F, device)
 
     def rows(self, r0, r1):
         """View of a row range (shares storage)."""
@@ -130,7 +138,7 @@ def spmm(A: CSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_N
     if B.n != A.shape[1]:
         raise ValueError("spmm: A is %s but B has %d rows" % (A.shape, B.n))
     if out is None:
-        out = DMat(A.shape[0], F, B.device)
+        out = DMat.empty(A.shape[0], F, B.device)
     need = lib.geogcn_spmm_workspace_bytes(A._plan, F)
     ws = A._ws.get(need)
     check(lib.geogcn_spmm_csr_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx),
@@ -153,7 +161,7 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     if Kb != K:
         raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, Kb))
     if out is None:
-        out = DMat(M, N, A.device)
+        out = DMat.empty(M, N, A.device)
     dev = A.device
     ws = _gemm_ws.get(dev)
     if ws is None:
@@ -189,11 +197,23 @@ def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat =
     return dS, dU, dHcarry
 
 
-def tanh_bwd(G: DMat, Y: DMat, out: DMat = None, keep_mask=None, scale=1.0):
+def act_bwd(G: DMat, Y: DMat, act, out: DMat = None, keep_mask=None, scale=1.0):
+    """dS = G [* mask * scale] * act'(Y)  (act' through the layer output Y)."""
     out = G.like() if out is None else out
-    check(_ffi.lib().geogcn_tanh_bwd_f32(G.n, G.F, _p(G.t), _p(Y.t), G.ld, _p(keep_mask), float(scale),
-                                         _p(out.t), _stream()), 'tanh_bwd_f32')
+    check(_ffi.lib().geogcn_act_bwd_f32(G.n, G.F, _p(G.t), _p(Y.t), G.ld, int(act), _p(keep_mask), float(scale),
+                                        _p(out.t), _stream()), 'act_bwd_f32')
     return out
+
+
+def tanh_bwd(G: DMat, Y: DMat, out: DMat = None, keep_mask=None, scale=1.0):
+    return act_bwd(G, Y, ACT_TANH, out, keep_mask, scale)
+
+
+def add_inplace(X: DMat, Y: DMat):
+    """Y += X (same shape / pitch)."""
+    assert X.t.shape == Y.t.shape
+    check(_ffi.lib().geogcn_add_inplace_f32(X.t.numel(), _p(X.t), _p(Y.t), _stream()), 'add_inplace_f32')
+    return Y
 
 
 _misc_ws = {}
@@ -248,9 +268,11 @@ def ce_metrics(P: DMat, idx: torch.Tensor, y: torch.Tensor, argmax: torch.Tensor
     return out2
 
 
-def softmax_ce_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, out: DMat = None):
+def softmax_ce_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, out: DMat = None, inv_n=None):
     out = P.like() if out is None else out
-    check(_ffi.lib().geogcn_softmax_ce_bwd_f32(P.n, P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y),
+    if inv_n is None:
+        inv_n = 1.0 / max(1, idx.numel())
+    check(_ffi.lib().geogcn_softmax_ce_bwd_f32(P.n, P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y), float(inv_n),
                                                _p(out.t), out.ld, _stream()), 'softmax_ce_bwd_f32')
     return out
 
@@ -275,3 +297,33 @@ def reg_penalty(p, regmask, l1, l2, out=None):
     check(_ffi.lib().geogcn_reg_penalty_f32(p.numel(), _p(p), _p(regmask), float(l1), float(l2), _p(out), _p(w),
                                             w.numel(), _stream()), 'reg_penalty_f32')
     return out
+
+
+class SparseOperand:
+    """A constant sparse matrix as the path uses it: ``fwd`` multiplies it (A . B) and ``bwd``
+    multiplies its transpose (A^T . G, the StructuredDot gradient).  For the normalised adjacency
+    of an unweighted graph A^T == A exactly in fp32 (checked here, not assumed), so
+    one CSR serves both directions; otherwise CSR(A^T) is built once on the host."""
+
+    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool):
+        self.fwd, self.bwd, self.symmetric = fwd, bwd, symmetric
+        self.shape = fwd.shape
+
+    @staticmethod
+    def from_scipy(m, device, need_transpose=True, long_row_nnz=256, chunk_nnz=128):
+        m = sps.csr_matrix(m).astype(np.float32)
+        m.sort_indices()
+        fwd = CSR(m, device, long_row_nnz, chunk_nnz)
+        if not need_transpose:
+            return SparseOperand(fwd, None, False)
+        sym = False
+        if m.shape[0] == m.shape[1]:
+            mt = sps.csr_matrix(m.T)
+            mt.sort_indices()
+            sym = (np.array_equal(mt.indptr, m.indptr) and np.array_equal(mt.indices, m.indices)
+                   and np.array_equal(mt.data, m.data))
+        else:
+            mt = sps.csr_matrix(m.T)
+            mt.sort_indices()
+        bwd = fwd if sym else CSR(mt, device, long_row_nnz, chunk_nnz)
+        return SparseOperand(fwd, bwd, sym)

@@ -90,10 +90,14 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
                            const float* H, int64_t ld, float* dS, float* dU, float* dHcarry,
                            void* stream);
-/* dS = G * (1 - Y^2) [* keep_mask * scale]   grad of tanh (gcnmodel.py:42,136) optionally through
- * the dropout that follows layer 0 (gcnmodel.py:357); mask may be NULL                          */
-int geogcn_tanh_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld,
-                        const uint8_t* keep_mask, float scale, float* dS, void* stream);
+/* dS = G [* keep_mask * scale] * act'(Y) with act' expressed through the layer OUTPUT Y:
+ * tanh: 1 - Y^2 (gcnmodel.py:42,136), sigmoid: Y(1-Y) (gcnmodel.py:286), none: 1.  The optional
+ * mask folds in the dropout that follows layer 0 (gcnmodel.py:357); mask may be NULL.           */
+int geogcn_act_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
+                       const uint8_t* keep_mask, float scale, float* dS, void* stream);
+/* Y += X over n_floats contiguous floats (gradient accumulation where a layer output feeds
+ * several consumers: Theano's Elemwise{add} in the autodiff graph of gcnmodel.py:266,288)      */
+int geogcn_add_inplace_f32(int64_t n_floats, const float* X, float* Y, void* stream);
 /* out[F] = sum over rows of X (bias gradients: Sum{axis=0}); deterministic two-pass            */
 size_t geogcn_colsum_workspace_bytes(int64_t n, int32_t F);
 int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* out,
@@ -120,10 +124,12 @@ int geogcn_ce_metrics_f32(int32_t C, const float* probs, int64_t ldp, const int3
                           per-row argmax from geogcn_softmax_rows_f32*/, const int32_t* idx,
                           int64_t n_idx, const int32_t* y, float* out2, void* ws, size_t ws_bytes,
                           void* stream);
-/* dlogits = 0; dlogits[idx[j], :] += (P[idx[j], :] - onehot(y[j])) / n_idx  (autodiff of :376,:382) */
+/* dlogits = 0; dlogits[idx[j], :] += (P[idx[j], :] - onehot(y[j])) * inv_n  (autodiff of :376,:382;
+ * inv_n = 1/len(train_indices) -- passed explicitly because a row-partitioned rank holds only
+ * its share of the indices while the mean runs over all of them)                                */
 int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t ldp,
-                              const int32_t* idx, int64_t n_idx, const int32_t* y, float* dlogits,
-                              int64_t ldd, void* stream);
+                              const int32_t* idx, int64_t n_idx, const int32_t* y, float inv_n,
+                              float* dlogits, int64_t ldd, void* stream);
 /* out[j, :] = X[idx[j], :]   AdvancedSubtensor1 (gcnmodel.py:376,378,393); dense out (pitch F)  */
 int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t* idx, int64_t n_idx,
                            float* out, int64_t ldo, void* stream);
