@@ -27,6 +27,10 @@ SIGNATURES = {
     'geogcn_spmm_workspace_bytes': (c_sz, [c_ptr, c_i32]),
     'geogcn_spmm_csr_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                     c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_timer_create': (c_i32, [c_i32, C.POINTER(c_ptr)]),
+    'geogcn_timer_destroy': (None, [c_ptr]),
+    'geogcn_timer_attach_spmm': (c_i32, [c_ptr, c_i32, c_i64]),
+    'geogcn_timer_read_ms': (c_i32, [c_ptr, c_ptr, c_i32, C.POINTER(c_i32)]),
     'geogcn_gemm_workspace_bytes': (c_sz, [c_i32, c_i32, c_i64, c_i64, c_i64]),
     'geogcn_gemm_f32': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                                 c_i64, c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TPB) void ce_bwd_kernel(int C, const float* __restr
     }
 }
 
-__global__ __launch_bounds__(TPB) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(TPB) void adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ regmask, float a_t, float b1, float b2,
                                                    float eps, float l1, float l2) {
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(int64_t n, float* __restrict_
         if (regmask) {
             const float sgn = (pi > 0.f) ? 1.f : ((pi < 0.f) ? -1.f : 0.f);
             gi += regmask[i] * (l1 * sgn + 2.0f * l2 * pi);
+            g[i] = gi;              // g now holds d(train_loss)/dp including the penalty
         }
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
@@ -228,7 +229,7 @@ int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t 
     return 0;
 }
 
-int geogcn_adam_step_f32(int64_t n, float* p, const float* g, float* m, float* v, const float* regmask, float lr,
+int geogcn_adam_step_f32(int64_t n, float* p, float* g, float* m, float* v, const float* regmask, float lr,
                          float b1, float b2, float eps, int32_t t, float l1, float l2, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && t >= 1, GEOGCN_E_SIZE, "adam_step_f32: n=%lld t=%d", (long long)n, t);
     if (n == 0) return 0;

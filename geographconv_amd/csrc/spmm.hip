@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
 template <int K4>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
               const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
-              const float* bias, int act, float* ws, hipStream_t st);
+              const float* bias, int act, float* ws, hipStream_t st, int64_t nnz);
 
 }  // namespace
 }  // namespace geogcn
@@ -223,15 +223,29 @@ struct geogcn_spmm_plan {
     int* d_chunk_end = nullptr;    // [n_chunks]
 };
 
+struct geogcn_timer {
+    std::vector<hipEvent_t> begin, end;
+    int used = 0;
+};
+
 namespace geogcn {
 namespace {
+
+geogcn_timer* g_spmm_timer = nullptr;
+int g_spmm_timer_F = 0;
+int64_t g_spmm_timer_nnz = 0;
 
 template <int K4>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
               const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
-              const float* bias, int act, float* ws, hipStream_t st) {
+              const float* bias, int act, float* ws, hipStream_t st, int64_t nnz) {
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const dim3 grid((unsigned)cdiv(n_rows, kGroupsPerBlock));
+    geogcn_timer* tm = g_spmm_timer;
+    const bool timed = tm && (g_spmm_timer_F == 0 || g_spmm_timer_F == F) &&
+                       (g_spmm_timer_nnz == 0 || g_spmm_timer_nnz == nnz) && tm->used < (int)tm->begin.size() &&
+                       n_rows > 0;
+    if (timed) GEOGCN_HIP(hipEventRecord(tm->begin[tm->used], st));
 #define GEOGCN_ROWS(ACT)                                                                         \
     hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz)
@@ -240,6 +254,10 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_ROWS(GEOGCN_ACT_SIGMOID);
         else GEOGCN_ROWS(GEOGCN_ACT_NONE);
         GEOGCN_LAUNCH_CHECK("spmm_rows_kernel");
+    }
+    if (timed) {
+        GEOGCN_HIP(hipEventRecord(tm->end[tm->used], st));
+        tm->used++;
     }
 #undef GEOGCN_ROWS
     if (plan && plan->n_long > 0) {
@@ -268,6 +286,51 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
 using namespace geogcn;
 
 extern "C" {
+
+int geogcn_timer_create(int32_t capacity, geogcn_timer** out) {
+    GEOGCN_REQUIRE(out && capacity > 0, GEOGCN_E_ARG, "timer_create: bad arguments");
+    auto* t = new geogcn_timer();
+    t->begin.resize(capacity);
+    t->end.resize(capacity);
+    for (int i = 0; i < capacity; ++i) {
+        hipError_t e = hipEventCreate(&t->begin[i]);
+        if (e == hipSuccess) e = hipEventCreate(&t->end[i]);
+        if (e != hipSuccess) {
+            set_error("timer_create: %s", hipGetErrorString(e));
+            delete t;
+            return (int)e;
+        }
+    }
+    *out = t;
+    return 0;
+}
+
+void geogcn_timer_destroy(geogcn_timer* t) {
+    if (!t) return;
+    if (g_spmm_timer == t) g_spmm_timer = nullptr;
+    for (auto& e : t->begin) (void)hipEventDestroy(e);
+    for (auto& e : t->end) (void)hipEventDestroy(e);
+    delete t;
+}
+
+int geogcn_timer_attach_spmm(geogcn_timer* t, int32_t only_F, int64_t only_nnz) {
+    g_spmm_timer = t;
+    g_spmm_timer_F = only_F;
+    g_spmm_timer_nnz = only_nnz;
+    if (t) t->used = 0;
+    return 0;
+}
+
+int geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32_t* n_out) {
+    GEOGCN_REQUIRE(t && out_ms && n_out, GEOGCN_E_NULL, "timer_read_ms: null pointer");
+    const int n = std::min<int>(t->used, max_out);
+    for (int i = 0; i < n; ++i) {
+        GEOGCN_HIP(hipEventSynchronize(t->end[i]));
+        GEOGCN_HIP(hipEventElapsedTime(&out_ms[i], t->begin[i], t->end[i]));
+    }
+    *n_out = n;
+    return 0;
+}
 
 int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz,
                             int32_t chunk_nnz, geogcn_spmm_plan** out) {
@@ -373,7 +436,7 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
     switch (K4) {
 #define GEOGCN_CASE(K)                                                                             \
     case K:                                                                                        \
-        return launch_k4<K>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st);
+        return launch_k4<K>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
         GEOGCN_CASE(1)
         GEOGCN_CASE(2)
         GEOGCN_CASE(3)

@@ -360,7 +360,7 @@ class GraphConv():
         self.adam_t += 1
         K.adam_step(self.store.p, self.store.g, self.store.m, self.store.v, self.store.regmask, self.lr,
                     self.beta1, self.beta2, self.epsilon, self.adam_t, l1=self.regul_coef, l2=self.regul_coef)
-        s = sc.cpu().numpy()                     # the one host sync of the step
+        s = [float(v) for v in sc.cpu().numpy()]   # the one host sync of the step
         l_tr = s[0] / max(1, n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
         out = [np.float32(l_tr), np.float64(s[1] / max(1, n_tr)), np.float32(s[2] / max(1, n_dv)),
                np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm)]

@@ -327,3 +327,34 @@ class SparseOperand:
             mt.sort_indices()
         bwd = fwd if sym else CSR(mt, device, long_row_nnz, chunk_nnz)
         return SparseOperand(fwd, bwd, sym)
+
+
+class SpmmTimer:
+    """hipEvent pairs around the SpMM row kernel, recorded by the library on the launch stream
+    (bench.py's roofline leg; torch.cuda.Event would also do, the library pool avoids per-call
+    Python work inside the timed region)."""
+
+    def __init__(self, capacity=4096):
+        self._h = C.c_void_p(0)
+        check(_ffi.lib().geogcn_timer_create(int(capacity), C.byref(self._h)), 'timer_create')
+        self.capacity = int(capacity)
+
+    def attach(self, only_F=0, only_nnz=0):
+        check(_ffi.lib().geogcn_timer_attach_spmm(self._h, int(only_F), int(only_nnz)), 'timer_attach_spmm')
+
+    def detach(self):
+        check(_ffi.lib().geogcn_timer_attach_spmm(None, 0, 0), 'timer_attach_spmm')
+
+    def read_ms(self):
+        buf = (C.c_float * self.capacity)()
+        n = C.c_int32(0)
+        check(_ffi.lib().geogcn_timer_read_ms(self._h, buf, self.capacity, C.byref(n)), 'timer_read_ms')
+        return [buf[i] for i in range(n.value)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().geogcn_timer_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass

@@ -63,6 +63,18 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
                         const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
                         const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
 
+/* profiling aid (bench.py's roofline leg): a pool of hipEvent pairs owned by the library.  While a
+ * timer is attached, every geogcn_spmm_csr_f32 call whose F equals `only_F` and whose nnz equals
+ * `only_nnz` (0 = any) records one
+ * (begin, end) pair immediately around its main row kernel (spmm_rows_kernel) on the call's stream,
+ * until the pool is full.  geogcn_timer_read_ms synchronises the recorded events and returns the
+ * per-launch durations.  Detach with geogcn_timer_attach_spmm(NULL, 0, 0).                          */
+typedef struct geogcn_timer geogcn_timer;
+int  geogcn_timer_create(int32_t capacity, geogcn_timer** out);
+void geogcn_timer_destroy(geogcn_timer* t);
+int  geogcn_timer_attach_spmm(geogcn_timer* t, int32_t only_F, int64_t only_nnz);
+int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32_t* n_out);
+
 /* ---- K5/K6: T.dot / Gemm -----------------------------------------------------------------
  * C[M x N] = act(op(A) . op(B) + bias)   fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate.
  *   transA=0: A is M x K row-major (lda);  transA=1: A is K x M row-major (C = A^T . B)
@@ -139,7 +151,7 @@ int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t
  *   g' = g + regmask*(l1*sign(p) + 2*l2*p);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
  *   p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
  * regmask (nullable) is 1.0 on weight matrices ("regularizable") and 0 on biases / padding.     */
-int geogcn_adam_step_f32(int64_t n, float* p, const float* g, float* m, float* v,
+int geogcn_adam_step_f32(int64_t n, float* p, float* g /* updated to g' when l1|l2 != 0 */, float* m, float* v,
                          const float* regmask, float lr, float b1, float b2, float eps, int32_t t,
                          float l1, float l2, void* stream);
 /* penalty value: sum regmask*(l1*|p| + l2*p^2) -> out[0] (deterministic two-pass)               */
