@@ -188,13 +188,24 @@ __global__ __launch_bounds__(TPB) void colsum_partial_kernel(int64_t n, int F, c
         P[(int64_t)blockIdx.x * F + col] = (a0 + a1) + (a2 + a3);
     }
 }
+// 16 columns x 16 part-groups per block: group g adds parts g, g+16, ... in order, then the 16 group
+// sums are added in group order (fixed tree => deterministic)
 __global__ __launch_bounds__(TPB) void colsum_final_kernel(int nparts, int F, const float* __restrict__ P,
                                                            float* __restrict__ out) {
-    const int col = blockIdx.x * TPB + threadIdx.x;
-    if (col >= F) return;
+    __shared__ float s[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
     float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += P[(int64_t)p * F + col];
-    out[col] = a;
+    if (col < F)
+        for (int p = g; p < nparts; p += 16) a += P[(int64_t)p * F + col];
+    s[g][c] = a;
+    __syncthreads();
+    if (g == 0 && col < F) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s[i][c];
+        out[col] = t;
+    }
 }
 
 __global__ __launch_bounds__(TPB) void gather_rows_kernel(int F, const float* __restrict__ X, int64_t ldx,
@@ -330,7 +341,7 @@ int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* 
     const int nparts = (int)cdiv(n, rpb);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, F, X, ldx, rpb, (float*)ws);
     GEOGCN_LAUNCH_CHECK("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, TPB)), dim3(TPB), 0, st, nparts, F,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F,
                        (const float*)ws, out);
     GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
     return 0;

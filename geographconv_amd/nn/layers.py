@@ -97,14 +97,15 @@ class ParamStore:
             p.data[:p.shape[0]].copy_(t)
 
     def read(self, p):
+        # .copy(): on a CPU device (gloo tests) .cpu().numpy() would alias the arena
         if len(p.shape) == 2:
-            return p.data.t[:, :p.shape[1]].cpu().numpy()
-        return p.data[:p.shape[0]].cpu().numpy()
+            return p.data.t[:, :p.shape[1]].cpu().numpy().copy()
+        return p.data[:p.shape[0]].cpu().numpy().copy()
 
     def read_grad(self, p):
         if len(p.shape) == 2:
-            return p.grad.t[:, :p.shape[1]].cpu().numpy()
-        return p.grad[:p.shape[0]].cpu().numpy()
+            return p.grad.t[:, :p.shape[1]].cpu().numpy().copy()
+        return p.grad[:p.shape[0]].cpu().numpy().copy()
 
 
 # --------------------------------------------------------------------------------------------

@@ -63,7 +63,8 @@ class DMat:
         return m
 
     def numpy(self):
-        return self.t[:, :self.F].cpu().numpy()
+        a = self.t[:, :self.F].cpu().numpy()
+        return a.copy() if self.t.device.type == 'cpu' else a      # never alias a reusable buffer
 
     def like(self):
         return DMat.empty(self.n, self.F, self.t.device)

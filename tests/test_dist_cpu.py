@@ -1,0 +1,105 @@
+"""N>1 path on CPU: world_size-2 gloo run of GraphConv (row partition + in-place all-gather +
+gradient all-reduce) with the NumPy test double standing in for the HIP kernels; results must
+equal the single-process oracle on the same inputs.  Plus single-process checks of the partition
+arithmetic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from geographconv_amd import synth
+from geographconv_amd.dist import RowPartition
+from oracle import gcn_oracle as O
+
+
+def test_row_partition_covers_rows_once():
+    for N, w in [(10, 3), (440000, 8), (7, 8), (16, 4)]:
+        seen = np.zeros(N, int)
+        for r in range(w):
+            p = RowPartition(N, w, r)
+            seen[p.r0:p.r1] += 1
+            assert p.n_gathered >= N and p.n_gathered == p.R * w
+            assert p.r0 == min(N, r * p.R)
+        assert np.all(seen == 1)
+
+
+def test_partition_split_indices_and_csr_padding():
+    p = RowPartition(10, 2, 1)             # rows 5..9
+    idx = np.array([9, 1, 5, 4, 7], dtype=np.int32)
+    y = np.array([0, 1, 2, 3, 4], dtype=np.int32)
+    loc, yl, sel = p.split_indices(idx, y)
+    assert list(loc) == [4, 0, 2] and list(yl) == [0, 2, 4] and sel.sum() == 3
+    A = sps.random(10, 10, density=0.3, format='csr', dtype=np.float32, random_state=0)
+    blk = RowPartition(10, 3, 2).local_rows_csr(A, 12)
+    assert blk.shape == (2, 12) and (blk[:, :10] != A[8:10]).nnz == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from geographconv_amd import backend
+        from geographconv_amd.dist import TorchDistComm
+        from geographconv_amd.nn import layers as L
+        from tests import cpu_backend_double
+        from tests.helpers import load_case, make_clf
+        backend.use(cpu_backend_double)
+        out = {}
+        for name in ('tiny_highway', 'tiny_plain_reg'):
+            z, A, X, params, cfg = load_case(name)
+            comm = TorchDistComm(cfg['N'], torch.device('cpu'))
+            clf = make_clf(cfg, params, device=torch.device('cpu'), comm=comm)
+            clf.inject_dropout_mask(z['mask'])
+            res = []
+            for step in range(2):
+                o = clf.f_train(X, z['Y'][z['tr']], z['Y'][z['dev']], A, z['tr'], z['dev'])
+                res.append(([float(v) for v in o[:4]], np.asarray(o[4]), clf.get_grads(),
+                            L.get_all_param_values(clf.l_out)))
+            pred, probs = clf.predict(X, A, z['te'])
+            out[name] = (res, pred, probs)
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process_oracle():
+    import torch.multiprocessing as mp
+    from tests.helpers import load_case
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name, (res, pred, probs) in out.items():
+        z, A, X, params, cfg = load_case(name)
+        for step, (sc, P, grads, pv) in enumerate(res):
+            ref = z['step%d_scalars' % step]
+            assert np.allclose(sc, ref, rtol=1e-5, atol=1e-6), (name, step, sc, ref)
+            assert np.allclose(P, z['step%d_P' % step], rtol=1e-4, atol=2e-6)
+            for i, g in enumerate(grads):
+                r = z['step%d_grad%d' % (step, i)]
+                assert np.allclose(g, r, rtol=2e-4, atol=2e-7 + 1e-5 * np.abs(r).max()), (name, step, i)
+            for i, q_ in enumerate(pv):
+                assert np.allclose(q_, z['step%d_param%d' % (step, i)], atol=2e-5), (name, step, i)
+        assert np.array_equal(pred, z['val_pred'])
+        assert np.allclose(probs, z['val_probs'], rtol=1e-3, atol=5e-5)
