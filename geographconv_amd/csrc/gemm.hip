@@ -37,13 +37,13 @@ struct KStrided {                   // BK rows x Ccols floats, pitch Ccols + 4
     static constexpr int kIters = (BK * kF4PerRow) / TPB;   // Ccols multiple of 32 => exact
 };
 
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64_t idx, int64_t lim) {
-    // loads p[idx..idx+3] with elements >= lim replaced by 0 (p + idx is 16-B aligned)
-    if (idx + 3 < lim) return *reinterpret_cast<const float4*>(p + idx);
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64_t idx, int64_t lim4, bool row_ok) {
+    // One predicated 16-byte load, no scalar tail: `lim4` is the limit of the contiguous dimension
+    // rounded UP to a multiple of 4 (<= ld), so a float4 is either wholly inside or wholly outside.
+    // Elements in [lim, lim4) are pad columns, which are zero by the geogcn.h convention.
+    // (A branchy tail here made hipcc put s_waitcnt vmcnt(0) in front of every load of the tile.)
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < lim) r.x = p[idx];
-    if (idx + 1 < lim) r.y = p[idx + 1];
-    if (idx + 2 < lim) r.z = p[idx + 2];
+    if (row_ok && idx < lim4) r = *reinterpret_cast<const float4*>(p + idx);
     return r;
 }
 
@@ -58,8 +58,7 @@ __device__ __forceinline__ void gload_kcontig(float4 (&reg)[KContig<R>::kIters],
 #pragma unroll
     for (int i = 0; i < KContig<R>::kIters; ++i) {
         const int64_t row = r0 + rr + 32 * i;
-        if (row < Rtot) reg[i] = load4_guard(P + row * ld, k0 + f4 * 4, Kend);
-        else reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reg[i] = load4_guard(P + row * ld, k0 + f4 * 4, (Kend + 3) & ~(int64_t)3, row < Rtot);
     }
 }
 template <int R>
@@ -83,8 +82,7 @@ __device__ __forceinline__ void gload_kstrided(float4 (&reg)[KStrided<Ccols>::kI
         const int kr = e / F4R;
         const int c4 = e % F4R;
         const int64_t k = k0 + kr;
-        if (k < Kend) reg[i] = load4_guard(P + k * ld, c0 + c4 * 4, Ctot);
-        else reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reg[i] = load4_guard(P + k * ld, c0 + c4 * 4, (Ctot + 3) & ~(int64_t)3, k < Kend);
     }
 }
 template <int Ccols>
@@ -112,36 +110,63 @@ struct GemmCfg {
     static constexpr int NR = BN / 32;
 };
 
-// MODE 0: C = act(acc + bias) [+ C if accumulate];  MODE 1: split-K slab (raw partial sums)
+struct GemmArgs {
+    int64_t M, N, K;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    const float* bias;
+    int accumulate;
+    int64_t kchunk;
+    int n_mt, n_nt, n_split, xcd_order;
+};
+
+struct TileCoord {
+    int64_t m0, n0, kbeg, kend;
+    int nk, z;
+    bool valid;
+};
+
+// Persistent blocks: block p walks its tile list p, p+G, ... (XCD-aware: the blocks of one XCD walk the
+// N tiles / K slices of the same M tiles concurrently, so the A panel is shared through that XCD's L2).
+__device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int BM, int BN, int p, int G, int j) {
+    TileCoord t;
+    int mt, nt, z;
+    if (a.xcd_order) {
+        const int x = p % kNumXCD, q = p / kNumXCD, Q = G / kNumXCD;
+        const int64_t u = (int64_t)q + (int64_t)j * Q;
+        nt = (int)(u % a.n_nt);
+        const int64_t rest = u / a.n_nt;
+        z = (int)(rest % a.n_split);
+        mt = (int)(rest / a.n_split) * kNumXCD + x;
+    } else {
+        const int64_t u = (int64_t)p + (int64_t)j * G;
+        nt = (int)(u % a.n_nt);
+        const int64_t rest = u / a.n_nt;
+        mt = (int)(rest % a.n_mt);
+        z = (int)(rest / a.n_mt);
+        if (z >= a.n_split) mt = a.n_mt;           // past the end
+    }
+    t.valid = mt < a.n_mt;
+    t.m0 = (int64_t)mt * BM;
+    t.n0 = (int64_t)nt * BN;
+    t.z = z;
+    t.kbeg = (int64_t)z * a.kchunk;
+    t.kend = min(a.K, t.kbeg + a.kchunk);
+    t.nk = t.valid ? (int)((t.kend - t.kbeg + BK - 1) / BK) : 0;
+    if (t.nk <= 0) t.valid = false;
+    return t;
+}
+
+// MODE 0: C = act(acc + bias) [+ C if accumulate];  MODE 1: split-K slab z (raw partial sums)
+// The k-loop is FLATTENED across the block's tiles: the global loads of stage s+1 are always in
+// flight during the MFMAs of stage s, also across a tile boundary, so the short K = 300 contractions
+// of the GCN (10 stages per tile) pay no per-tile prologue.
 template <int BM, int BN, bool AT, bool BT, int ACT, int MODE>
-__global__ __launch_bounds__(TPB) void gemm_kernel(int64_t M, int64_t N, int64_t K,
-                                                   const float* __restrict__ A, int64_t lda,
-                                                   const float* __restrict__ B, int64_t ldb,
-                                                   float* __restrict__ C, int64_t ldc,
-                                                   const float* __restrict__ bias, int accumulate,
-                                                   int64_t kchunk, int n_mt, int n_nt, int xcd_order) {
+__global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
     using Cfg = GemmCfg<BM, BN, AT, BT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    // XCD-aware tile order: consecutive blocks on one XCD (b, b+8, ...) walk the N tiles of one
-    // M tile so the A panel is re-read from that XCD's L2.
-    // (few M tiles -- the split-K case -- use the plain order so that every XCD gets work.)
-    const int b = blockIdx.x;
-    int mt, nt;
-    if (xcd_order) {
-        const int xcd = b % kNumXCD;
-        const int j = b / kNumXCD;
-        mt = (j / n_nt) * kNumXCD + xcd;
-        nt = j % n_nt;
-    } else {
-        mt = b / n_nt;
-        nt = b % n_nt;
-    }
-    if (mt >= n_mt) return;
-    const int64_t m0 = (int64_t)mt * BM;
-    const int64_t n0 = (int64_t)nt * BN;
-    const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
-    const int64_t kend = min(K, kbeg + kchunk);
+    const int p = blockIdx.x, G = gridDim.x;
 
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -155,11 +180,12 @@ __global__ __launch_bounds__(TPB) void gemm_kernel(int64_t M, int64_t N, int64_t
         for (int jn = 0; jn < Cfg::NR; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float4 ra[Cfg::kAIters], rb[Cfg::kBIters];
-    auto gload = [&](int64_t k0) {
-        if constexpr (AT) gload_kstrided<BM>(ra, A, lda, m0, M, k0, kend);
-        else gload_kcontig<BM>(ra, A, lda, m0, M, k0, kend);
-        if constexpr (BT) gload_kcontig<BN>(rb, B, ldb, n0, N, k0, kend);
-        else gload_kstrided<BN>(rb, B, ldb, n0, N, k0, kend);
+    auto gload = [&](const TileCoord& t, int kt) {
+        const int64_t k0 = t.kbeg + (int64_t)kt * BK;
+        if constexpr (AT) gload_kstrided<BM>(ra, a.A, a.lda, t.m0, a.M, k0, t.kend);
+        else gload_kcontig<BM>(ra, a.A, a.lda, t.m0, a.M, k0, t.kend);
+        if constexpr (BT) gload_kcontig<BN>(rb, a.B, a.ldb, t.n0, a.N, k0, t.kend);
+        else gload_kstrided<BN>(rb, a.B, a.ldb, t.n0, a.N, k0, t.kend);
     };
     auto sstore = [&](int buf) {
         float* As = smem + buf * Cfg::kStageFloats;
@@ -170,19 +196,25 @@ __global__ __launch_bounds__(TPB) void gemm_kernel(int64_t M, int64_t N, int64_t
         else sstore_kstrided<BN>(Bs, rb);
     };
 
-    const int64_t nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-    if (nk > 0) {
-        gload(kbeg);
-        sstore(0);
-    }
+    int cj = 0, ckt = 0;                     // compute cursor (tile index in my list, stage)
+    TileCoord ct = decode_tile(a, BM, BN, p, G, 0);
+    if (!ct.valid) return;
+    int lj = 0, lkt = 0;                     // load cursor
+    TileCoord lt = ct;
+    gload(lt, 0);
+    sstore(0);
+    if (++lkt == lt.nk) { lt = decode_tile(a, BM, BN, p, G, ++lj); lkt = 0; }
     __syncthreads();
     int cur = 0;
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+    while (true) {
+        const bool have_next = lt.valid;
+        if (have_next) gload(lt, lkt);
         const float* As = smem + cur * Cfg::kStageFloats;
         const float* Bs = As + Cfg::kAFloats;
+        const int64_t k_stage = ct.kbeg + (int64_t)ckt * BK;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
+            if (kk > 0 && k_stage + kk >= ct.kend) break;      // K tail: nothing but zero padding left
             float af[Cfg::MR][4], bf[Cfg::NR][4];
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
@@ -214,33 +246,61 @@ __global__ __launch_bounds__(TPB) void gemm_kernel(int64_t M, int64_t N, int64_t
                     for (int jn = 0; jn < Cfg::NR; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[jn][t], acc[i][jn], 0, 0, 0);
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
-    float* Cout = C;
-    if constexpr (MODE == 1) Cout = C + (int64_t)blockIdx.y * M * ldc;
+        if (ckt == ct.nk - 1) {
+            // epilogue of this tile: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+            float* Cout = a.C;
+            if constexpr (MODE == 1) Cout = a.C + (int64_t)ct.z * a.M * a.ldc;
+            // all loads of the epilogue (bias, old C when accumulating) are issued as independent
+            // batches before their first use -- no load/wait/store chains
+            float bcol[Cfg::NR];
 #pragma unroll
-    for (int i = 0; i < Cfg::MR; ++i) {
+            for (int jn = 0; jn < Cfg::NR; ++jn) {
+                const int64_t col = ct.n0 + wn * (BN / 2) + jn * 16 + li;
+                bcol[jn] = 0.f;
+                if constexpr (MODE == 0) {
+                    if (a.bias && col < a.N) bcol[jn] = a.bias[col];
+                }
+            }
 #pragma unroll
-        for (int jn = 0; jn < Cfg::NR; ++jn) {
-            const int64_t col = n0 + wn * (BN / 2) + jn * 16 + li;
+            for (int i = 0; i < Cfg::MR; ++i) {
+                const int64_t row0 = ct.m0 + wm * (BM / 2) + i * 16 + lg * 4;
+                float oldv[Cfg::NR][4];
+                if constexpr (MODE == 0) {
+                    if (a.accumulate) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = m0 + wm * (BM / 2) + i * 16 + lg * 4 + r;
-                if (row < M && col < N) {
-                    float x = acc[i][jn][r];
-                    if constexpr (MODE == 0) {
-                        if (bias) x += bias[col];
-                        x = apply_act<ACT>(x);
-                        if (accumulate) x += Cout[row * ldc + col];
+                        for (int jn = 0; jn < Cfg::NR; ++jn) {
+                            const int64_t col = ct.n0 + wn * (BN / 2) + jn * 16 + li;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                oldv[jn][r] = (row0 + r < a.M && col < a.N) ? Cout[(row0 + r) * a.ldc + col] : 0.f;
+                        }
                     }
-                    Cout[row * ldc + col] = x;
+                }
+#pragma unroll
+                for (int jn = 0; jn < Cfg::NR; ++jn) {
+                    const int64_t col = ct.n0 + wn * (BN / 2) + jn * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[i][jn][r];
+                        if constexpr (MODE == 0) {
+                            x = apply_act<ACT>(x + bcol[jn]);
+                            if (a.accumulate) x += oldv[jn][r];
+                        }
+                        if (row0 + r < a.M && col < a.N) Cout[(row0 + r) * a.ldc + col] = x;
+                    }
+                    acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
+        if (have_next) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        if (++ckt == ct.nk) {
+            ct = decode_tile(a, BM, BN, p, G, ++cj);
+            ckt = 0;
+            if (!ct.valid) break;
+        }
+        if (have_next && ++lkt == lt.nk) { lt = decode_tile(a, BM, BN, p, G, ++lj); lkt = 0; }
     }
 }
 
@@ -264,17 +324,28 @@ __global__ __launch_bounds__(TPB) void splitk_reduce_kernel(int64_t M, int64_t N
 struct SplitPlan {
     int nsplit;
     int64_t kchunk;
+    int grid;
 };
 
-template <int BM, int BN>
-SplitPlan plan_split(int64_t M, int64_t N, int64_t K) {
+template <int BM, int BN, bool AT, bool BT>
+constexpr int blocks_per_cu() { return (2 * GemmCfg<BM, BN, AT, BT>::kLdsBytes <= 160 * 1024) ? 2 : 1; }
+
+// grid = resident persistent blocks; transA additionally slices K so that (tiles x slices) fills the grid
+template <int BM, int BN, bool AT, bool BT>
+SplitPlan plan_grid(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
-    int64_t ns = cdiv(3 * kNumCU, tiles);                 // ~3 blocks per CU
-    const int64_t max_ns = std::max<int64_t>(1, K / (BK * 16));
-    ns = std::max<int64_t>(1, std::min(ns, max_ns));
-    int64_t kchunk = cdiv(cdiv(K, ns), BK) * BK;
-    ns = cdiv(K, kchunk);
-    return {(int)ns, kchunk};
+    const int G = kNumCU * blocks_per_cu<BM, BN, AT, BT>();
+    SplitPlan sp{1, cdiv(K, BK) * BK, 0};
+    if (AT) {
+        int64_t ns = std::max<int64_t>(1, G / tiles);
+        const int64_t max_ns = std::max<int64_t>(1, K / (BK * 16));
+        ns = std::min(ns, max_ns);
+        sp.kchunk = cdiv(cdiv(K, ns), BK) * BK;
+        sp.nsplit = (int)cdiv(K, sp.kchunk);
+    }
+    const int64_t total = tiles * sp.nsplit;
+    sp.grid = (int)std::min<int64_t>(G, cdiv(total, kNumXCD) * kNumXCD);
+    return sp;
 }
 
 template <int BM, int BN, bool AT, bool BT>
@@ -282,10 +353,12 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
                 float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
                 hipStream_t st) {
     using Cfg = GemmCfg<BM, BN, AT, BT>;
-    const int n_mt = (int)cdiv(M, BM), n_nt = (int)cdiv(N, BN);
-    const int xcd_order = (n_mt >= 4 * kNumXCD) ? 1 : 0;
-    const unsigned gx = xcd_order ? (unsigned)(cdiv(n_mt, kNumXCD) * kNumXCD * n_nt) : (unsigned)(n_mt * n_nt);
-#define GEOGCN_GEMM_LAUNCH(ACT, MODE, grid, Cptr, ldC, kch)                                              \
+    const SplitPlan sp = plan_grid<BM, BN, AT, BT>(M, N, K);
+    GemmArgs a{M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, sp.kchunk, (int)cdiv(M, BM), (int)cdiv(N, BN),
+               sp.nsplit, 0};
+    a.xcd_order = (a.n_mt >= 4 * kNumXCD) ? 1 : 0;
+    const dim3 grid((unsigned)sp.grid);
+#define GEOGCN_GEMM_LAUNCH(ACT, MODE)                                                                    \
     do {                                                                                                  \
         auto kern = gemm_kernel<BM, BN, AT, BT, ACT, MODE>;                                               \
         static bool attr_done = false;                                                                    \
@@ -294,37 +367,27 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
                                            (int)Cfg::kLdsBytes));                                         \
             attr_done = true;                                                                             \
         }                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(TPB), Cfg::kLdsBytes, st, M, N, K, A, lda, B, ldb, Cptr, ldC, \
-                           bias, accumulate, kch, n_mt, n_nt, xcd_order);                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(TPB), Cfg::kLdsBytes, st, a);                                 \
         GEOGCN_LAUNCH_CHECK("gemm_kernel");                                                               \
     } while (0)
 
-    if (!AT) {
-        const dim3 grid(gx, 1);
-        const int64_t kch = cdiv(K, BK) * BK;
-        if (act == GEOGCN_ACT_TANH) GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_TANH, 0, grid, C, ldc, kch);
-        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_SIGMOID, 0, grid, C, ldc, kch);
-        else GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 0, grid, C, ldc, kch);
-        return 0;
-    }
-    // transA: split-K over the long reduction
-    const SplitPlan sp = plan_split<BM, BN>(M, N, K);
     if (sp.nsplit == 1) {
-        const dim3 grid(gx, 1);
-        if (act == GEOGCN_ACT_TANH) GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_TANH, 0, grid, C, ldc, sp.kchunk);
-        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_SIGMOID, 0, grid, C, ldc, sp.kchunk);
-        else GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 0, grid, C, ldc, sp.kchunk);
+        if (act == GEOGCN_ACT_TANH) GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_TANH, 0);
+        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_SIGMOID, 0);
+        else GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 0);
         return 0;
     }
+    // split-K slabs into the workspace, then the ordered combine
     const int64_t ldw = N;
     const size_t need = (size_t)sp.nsplit * (size_t)M * (size_t)ldw * sizeof(float);
     GEOGCN_REQUIRE(ws && ws_bytes >= need, GEOGCN_E_ARG, "gemm_f32: split-K workspace too small (%zu < %zu)",
                    ws_bytes, need);
     float* W = (float*)ws;
-    {
-        const dim3 grid(gx, (unsigned)sp.nsplit);
-        GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1, grid, W, ldw, sp.kchunk);
-    }
+    a.C = W;
+    a.ldc = ldw;
+    a.bias = nullptr;
+    a.accumulate = 0;
+    GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1);
     const dim3 rgrid((unsigned)cdiv(M * N, TPB));
 #define GEOGCN_RED(ACT)                                                                                 \
     hipLaunchKernelGGL((splitk_reduce_kernel<ACT>), rgrid, dim3(TPB), 0, st, M, N, sp.nsplit, W, ldw, C, \
@@ -338,7 +401,37 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
 #undef GEOGCN_GEMM_LAUNCH
 }
 
-constexpr int kBM = 128, kBN = 128;
+// ---- tile selection ------------------------------------------------------------------------------
+// 128 or 160 per dimension, whichever wastes fewer MFMA columns on padding (300 -> 2x160, 256 -> 2x128,
+// 600 -> 4x160).  The long dimension of NN / NT always uses BM = 128 (thousands of tiles).
+inline int pick_tile(int64_t n) {
+    const int64_t w128 = cdiv(n, 128) * 128, w160 = cdiv(n, 160) * 160;
+    return (w160 < w128) ? 160 : 128;
+}
+
+template <bool AT, bool BT>
+int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                   int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws,
+                   size_t ws_bytes, hipStream_t st) {
+#define GEOGCN_T(BM_, BN_)                                                                                   \
+    if (bm == BM_ && bn == BN_)                                                                              \
+        return launch_gemm<BM_, BN_, AT, BT>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+    GEOGCN_T(128, 128)
+    GEOGCN_T(128, 160)
+    if constexpr (AT) {
+        GEOGCN_T(160, 128)
+        GEOGCN_T(160, 160)
+    }
+#undef GEOGCN_T
+    set_error("gemm_f32: no kernel for tile %dx%d", bm, bn);
+    return GEOGCN_E_ARG;
+}
+
+template <int BM, int BN>
+size_t splitk_ws_bytes(int64_t M, int64_t N, int64_t K) {
+    const SplitPlan sp = plan_grid<BM, BN, true, false>(M, N, K);
+    return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)N * sizeof(float);
+}
 
 }  // namespace
 }  // namespace geogcn
@@ -350,9 +443,11 @@ extern "C" {
 size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K) {
     (void)transB;
     if (!transA || M <= 0 || N <= 0 || K <= 0) return 0;
-    const SplitPlan sp = plan_split<kBM, kBN>(M, N, K);
-    if (sp.nsplit <= 1) return 0;
-    return (size_t)sp.nsplit * (size_t)M * (size_t)N * sizeof(float);
+    const int bm = pick_tile(M), bn = pick_tile(N);
+    if (bm == 128 && bn == 128) return splitk_ws_bytes<128, 128>(M, N, K);
+    if (bm == 128 && bn == 160) return splitk_ws_bytes<128, 160>(M, N, K);
+    if (bm == 160 && bn == 128) return splitk_ws_bytes<160, 128>(M, N, K);
+    return splitk_ws_bytes<160, 160>(M, N, K);
 }
 
 int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
@@ -371,9 +466,13 @@ int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
                    "gemm_f32: operands need 16-byte aligned bases and ld %% 4 == 0 (lda=%lld ldb=%lld)",
                    (long long)lda, (long long)ldb);
     hipStream_t st = (hipStream_t)stream;
-    if (transA) return launch_gemm<kBM, kBN, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
-    if (transB) return launch_gemm<kBM, kBN, false, true>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
-    return launch_gemm<kBM, kBN, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+    const int bn = pick_tile(N);
+    if (transA)
+        return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
+                                           ws_bytes, st);
+    if (transB)
+        return dispatch_tiles<false, true>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+    return dispatch_tiles<false, false>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
 }
 
 }  // extern "C"

@@ -82,6 +82,9 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  * gcnmodel.py:126,149 (T.dot(input, W)), lasagne DenseLayer gate :285, and the Gemm ops autodiff
  * derives: dW = H^T.dZ (transA=1), dH = dZ.W^T (transB=1).
  * accumulate=1 adds into C (C += ...), used for dH += dZ.Wh^T + dU.Wt^T.
+ * Operands are read in whole float4s: when a contiguous dimension (K for a non-transposed A or a
+ * transposed B) is not a multiple of 4, its pad columns up to the next multiple of 4 MUST be zero
+ * (the convention every producer in this library keeps).
  * transA=1 reduces over the long dimension: it runs split-K into `ws` (see
  * geogcn_gemm_workspace_bytes) and combines the slabs in fixed order (deterministic).         */
 size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K);

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--long', type=int, default=256)
     ap.add_argument('--chunk', type=int, default=128)
+    ap.add_argument('--only', default='all', choices=['all', 'gemm', 'spmm', 'stream'])
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     s = synth.SHAPES[args.shape]
@@ -43,10 +44,11 @@ def main():
     print('generated in %.1fs' % (time.time() - t0), flush=True)
     N, E = s.N, A.nnz
     res = {'shape': args.shape, 'N': N, 'nnz_A': int(E), 'nnz_X': int(X.nnz)}
+    do = lambda k: args.only in ('all', k)
     dA = ops.CSR(A, dev, args.long, args.chunk)
     print('long rows', dA.n_long_rows, 'chunks', dA.n_chunks, flush=True)
     rng = np.random.RandomState(1)
-    for F in (300, s.C):
+    for F in ((300, s.C) if do('spmm') else ()):
         H = ops.DMat.from_numpy(rng.randn(N, F).astype(np.float32), dev)
         out = ops.DMat(N, F, dev)
         med, mn = timeit(lambda: ops.spmm(dA, H, out=out), args.reps)
@@ -55,23 +57,24 @@ def main():
                                  'alg_GBps': bytes_alg / med / 1e6, 'frac_8TBps': bytes_alg / med / 1e6 / 8000}
         print('spmm A F=%d: %.3f ms (min %.3f)  %.2e edges/s  alg %.0f GB/s (%.1f%% of 8 TB/s)' %
               (F, med, mn, E / med * 1e3, bytes_alg / med / 1e6, bytes_alg / med / 1e6 / 80), flush=True)
-    dX = ops.CSR(X, dev, args.long, args.chunk)
-    W0 = ops.DMat.from_numpy((rng.randn(s.V, 300) * 0.05).astype(np.float32), dev)
-    out = ops.DMat(N, 300, dev)
-    med, mn = timeit(lambda: ops.spmm(dX, W0, out=out), args.reps)
-    res['spmm_X'] = {'ms': med}
-    print('spmm X.W0: %.3f ms' % med, flush=True)
-    import scipy.sparse as sps
-    dXt = ops.CSR(sps.csr_matrix(X.T), dev, args.long, args.chunk)
-    print('Xt long rows', dXt.n_long_rows, 'chunks', dXt.n_chunks, flush=True)
-    G = ops.DMat.from_numpy(rng.randn(N, 300).astype(np.float32), dev)
-    outw = ops.DMat(s.V, 300, dev)
-    med, mn = timeit(lambda: ops.spmm(dXt, G, out=outw), args.reps)
-    res['spmm_Xt'] = {'ms': med}
-    print('spmm Xt.G: %.3f ms' % med, flush=True)
+    if do('spmm'):
+      dX = ops.CSR(X, dev, args.long, args.chunk)
+      W0 = ops.DMat.from_numpy((rng.randn(s.V, 300) * 0.05).astype(np.float32), dev)
+      out = ops.DMat(N, 300, dev)
+      med, mn = timeit(lambda: ops.spmm(dX, W0, out=out), args.reps)
+      res['spmm_X'] = {'ms': med}
+      print('spmm X.W0: %.3f ms' % med, flush=True)
+      import scipy.sparse as sps
+      dXt = ops.CSR(sps.csr_matrix(X.T), dev, args.long, args.chunk)
+      print('Xt long rows', dXt.n_long_rows, 'chunks', dXt.n_chunks, flush=True)
+      G = ops.DMat.from_numpy(rng.randn(N, 300).astype(np.float32), dev)
+      outw = ops.DMat(s.V, 300, dev)
+      med, mn = timeit(lambda: ops.spmm(dXt, G, out=outw), args.reps)
+      res['spmm_Xt'] = {'ms': med}
+      print('spmm Xt.G: %.3f ms' % med, flush=True)
     # GEMMs
     H = ops.DMat.from_numpy(rng.randn(N, 300).astype(np.float32), dev)
-    for Fo in (300, 600, s.C):
+    for Fo in ((300, 600, s.C) if do('gemm') else ()):
         W = ops.DMat.from_numpy((rng.randn(300, Fo) * 0.05).astype(np.float32), dev)
         Z = ops.DMat(N, Fo, dev)
         med, mn = timeit(lambda: ops.gemm(H, W, out=Z), args.reps)
@@ -87,6 +90,8 @@ def main():
         res['gemm_tn_%d' % Fo] = {'ms': med, 'TFLOPs': fl / med / 1e9}
         print('gemm TN (dW) %d: %.3f ms  %.1f TF' % (Fo, med, fl / med / 1e9), flush=True)
     # streaming kernels
+    if not do('stream'):
+        return
     T = ops.DMat.from_numpy(rng.rand(N, 300).astype(np.float32), dev)
     Hc = ops.DMat.from_numpy(rng.randn(N, 300).astype(np.float32), dev)
     o = ops.DMat(N, 300, dev)
