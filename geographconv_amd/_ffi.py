@@ -51,6 +51,7 @@ SIGNATURES = {
     'geogcn_softmax_ce_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr,
                                           c_i64, c_ptr]),
     'geogcn_gather_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'geogcn_scatter_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_ptr]),
     'geogcn_reg_penalty_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_sz, c_ptr]),

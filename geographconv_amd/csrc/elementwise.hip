@@ -229,6 +229,17 @@ __global__ __launch_bounds__(TPB) void add_inplace_kernel(int64_t total4, const 
     }
 }
 
+__global__ __launch_bounds__(TPB) void scatter_rows_kernel(int F, const float* __restrict__ S, int64_t lds,
+                                                           const int* __restrict__ idx, int64_t n_idx,
+                                                           float* __restrict__ out, int64_t ldo) {
+    const int64_t total = n_idx * F;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t j = e / F;
+        const int col = (int)(e - j * F);
+        out[(int64_t)idx[j] * ldo + col] = S[j * lds + col];
+    }
+}
+
 int64_t colsum_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(n, 64))); }
 
 }  // namespace
@@ -371,6 +382,18 @@ int geogcn_dropout_apply_f32(int64_t n, int32_t F, const float* X, int64_t ld, c
     hipLaunchKernelGGL(dropout_apply_kernel, dim3(stream_grid(n * F4)), dim3(TPB), 0, (hipStream_t)stream, n, F, F4, X,
                        ld, keep_mask, 1.0f / (1.0f - p_drop), Y);
     GEOGCN_LAUNCH_CHECK("dropout_apply_kernel");
+    return 0;
+}
+
+int geogcn_scatter_rows_f32(int32_t F, const float* src, int64_t lds, const int32_t* idx, int64_t n_idx, float* out,
+                            int64_t ldo, void* stream) {
+    GEOGCN_REQUIRE(F >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "scatter_rows_f32: negative size");
+    if (F == 0 || n_idx == 0) return 0;
+    GEOGCN_REQUIRE(src && idx && out, GEOGCN_E_NULL, "scatter_rows_f32: null pointer");
+    GEOGCN_REQUIRE(lds >= F && ldo >= F, GEOGCN_E_SIZE, "scatter_rows_f32: ld < F");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(stream_grid(n_idx * F)), dim3(TPB), 0, (hipStream_t)stream, F, src, lds,
+                       idx, n_idx, out, ldo);
+    GEOGCN_LAUNCH_CHECK("scatter_rows_kernel");
     return 0;
 }
 

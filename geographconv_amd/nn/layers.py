@@ -309,7 +309,7 @@ class DenseLayer(Layer):
             if into[0] is not None:
                 return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True)]
             return [K.gemm(dZ, self.W.data, transB=True)]                  # dH = dZ . W^T
-        K.spmm(x.bwd, dZ, out=self.W.grad)                                 # dW0 = X^T . dS0
+        K.spmm_t(x, dZ, out=self.W.grad)                                   # dW0 = X^T . dS0
         return [None]
 
 

@@ -286,6 +286,13 @@ def gather_rows(X: DMat, idx: torch.Tensor, out: torch.Tensor = None):
     return out
 
 
+def scatter_rows(src: DMat, idx: torch.Tensor, out: DMat):
+    """out[idx[j], :] = src[j, :]"""
+    check(_ffi.lib().geogcn_scatter_rows_f32(src.F, _p(src.t), src.ld, _p(idx), idx.numel(), _p(out.t), out.ld,
+                                             _stream()), 'scatter_rows_f32')
+    return out
+
+
 def adam_step(p, g, m, v, regmask, lr, b1, b2, eps, t, l1=0.0, l2=0.0):
     check(_ffi.lib().geogcn_adam_step_f32(p.numel(), _p(p), _p(g), _p(m), _p(v), _p(regmask), lr, b1, b2, eps,
                                           int(t), float(l1), float(l2), _stream()), 'adam_step_f32')
@@ -300,34 +307,72 @@ def reg_penalty(p, regmask, l1, l2, out=None):
     return out
 
 
+# A column of X whose density exceeds this is cheaper to multiply as part of a DENSE panel on the MFMA
+# pipe (2*N*F flop at ~100 TFLOP/s) than as nnz row gathers (nnz * 4F bytes at the ~7 TB/s beyond-L2
+# ceiling): break-even nnz/N = 2 * 7e12 / (4 * 1e14) = 3.5 %.
+DENSE_HEAD_DENSITY = 0.035
+DENSE_HEAD_MAX_COLS = 512
+
+
 class SparseOperand:
     """A constant sparse matrix as the path uses it: ``fwd`` multiplies it (A . B) and ``bwd``
     multiplies its transpose (A^T . G, the StructuredDot gradient).  For the normalised adjacency
     of an unweighted graph A^T == A exactly in fp32 (checked here, not assumed), so
-    one CSR serves both directions; otherwise CSR(A^T) is built once on the host."""
+    one CSR serves both directions; otherwise CSR(A^T) is built once on the host.
 
-    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool):
+    For a bag-of-words X (Zipfian columns) the transpose product X^T . G is split: the few columns
+    denser than DENSE_HEAD_DENSITY become a dense N x K panel multiplied by the split-K MFMA GEMM,
+    the long tail stays a CSR gather (`bwd` then holds only the tail rows of X^T)."""
+
+    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool, head_idx=None, head_dense=None):
         self.fwd, self.bwd, self.symmetric = fwd, bwd, symmetric
+        self.head_idx, self.head_dense = head_idx, head_dense
         self.shape = fwd.shape
 
     @staticmethod
-    def from_scipy(m, device, need_transpose=True, long_row_nnz=256, chunk_nnz=128):
+    def from_scipy(m, device, need_transpose=True, long_row_nnz=256, chunk_nnz=128, dense_head=True):
         m = sps.csr_matrix(m).astype(np.float32)
         m.sort_indices()
         fwd = CSR(m, device, long_row_nnz, chunk_nnz)
         if not need_transpose:
             return SparseOperand(fwd, None, False)
         sym = False
+        mt = sps.csr_matrix(m.T)
+        mt.sort_indices()
         if m.shape[0] == m.shape[1]:
-            mt = sps.csr_matrix(m.T)
-            mt.sort_indices()
             sym = (np.array_equal(mt.indptr, m.indptr) and np.array_equal(mt.indices, m.indices)
                    and np.array_equal(mt.data, m.data))
-        else:
-            mt = sps.csr_matrix(m.T)
-            mt.sort_indices()
-        bwd = fwd if sym else CSR(mt, device, long_row_nnz, chunk_nnz)
-        return SparseOperand(fwd, bwd, sym)
+        if sym:
+            return SparseOperand(fwd, fwd, True)
+        head_idx = head_dense = None
+        if dense_head and m.shape[0] > 0:
+            col_nnz = np.diff(mt.indptr)
+            cand = np.nonzero(col_nnz >= DENSE_HEAD_DENSITY * m.shape[0])[0]
+            if len(cand) > DENSE_HEAD_MAX_COLS:
+                cand = cand[np.argsort(-col_nnz[cand], kind='stable')[:DENSE_HEAD_MAX_COLS]]
+            cand = np.sort(cand)
+            if len(cand) >= 16:
+                panel = DMat(m.shape[0], len(cand), device)
+                panel.t[:, :len(cand)].copy_(torch.from_numpy(np.ascontiguousarray(m[:, cand].toarray())))
+                head_dense = panel
+                head_idx = torch.from_numpy(cand.astype(np.int32)).to(device)
+                keep = np.ones(mt.shape[0], dtype=bool)
+                keep[cand] = False
+                mt = sps.diags(keep.astype(np.float32)).tocsr() @ mt     # empty the head rows of X^T
+                mt = sps.csr_matrix(mt)
+                mt.eliminate_zeros()
+                mt.sort_indices()
+        bwd = CSR(mt, device, long_row_nnz, chunk_nnz)
+        return SparseOperand(fwd, bwd, False, head_idx, head_dense)
+
+
+def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
+    """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff)."""
+    out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)
+    if x.head_dense is not None:
+        head = gemm(x.head_dense, G, transA=True)  # K x F on the MFMA pipe, deterministic split-K
+        scatter_rows(head, x.head_idx, out)
+    return out
 
 
 class SpmmTimer:

@@ -149,6 +149,10 @@ int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t 
 int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t* idx, int64_t n_idx,
                            float* out, int64_t ldo, void* stream);
 
+/* out[idx[j], :] = src[j, :]  (rows of a small result placed into a larger matrix; idx unique)   */
+int geogcn_scatter_rows_f32(int32_t F, const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
+                            float* out, int64_t ldo, void* stream);
+
 /* ---- K11/K12: lasagne.updates.adam (+ l1/l2 penalty gradient), gcnmodel.py:383-387,407 ------
  * flat arenas of n floats: t is the step index AFTER increment (1 for the first call).
  *   g' = g + regmask*(l1*sign(p) + 2*l2*p);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2

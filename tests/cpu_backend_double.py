@@ -58,6 +58,10 @@ def spmm(A, B, out=None, bias=None, act=ACT_NONE, F=None):
     return out
 
 
+def spmm_t(x, G, out=None):
+    return spmm(x.bwd, G, out=out)
+
+
 def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False):
     a = _v(A).T if transA else _v(A)
     b = _v(B).T if transB else _v(B)

@@ -326,3 +326,13 @@ def test_cmu_shape_spmm_full_size(dev):
     got = ops.spmm(dXt, ops.DMat.from_numpy(H, dev)).numpy()
     ref = O.spmm_t(X, H)
     assert np.allclose(got, ref, rtol=1e-4, atol=2e-5)
+    # the hybrid transpose product the model uses: dense head panel (MFMA) + sparse tail (gather)
+    sx = ops.SparseOperand.from_scipy(X, dev)
+    assert sx.head_dense is not None and 16 <= sx.head_dense.F <= ops.DENSE_HEAD_MAX_COLS
+    assert sx.bwd.nnz + int((X[:, sx.head_idx.cpu().numpy()]).nnz) == X.nnz
+    ref64 = (X.T.astype(np.float64) @ H.astype(np.float64))
+    got = ops.spmm_t(sx, ops.DMat.from_numpy(H, dev)).numpy()
+    mag = np.asarray(abs(X).T @ np.abs(H))
+    assert np.all(np.abs(got - ref64) <= 3e-6 * mag + 1e-5), np.abs(got - ref64).max()
+    got2 = ops.spmm_t(sx, ops.DMat.from_numpy(H, dev)).numpy()
+    assert np.array_equal(got, got2)                     # deterministic
