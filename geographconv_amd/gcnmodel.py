@@ -109,6 +109,36 @@ class SparseConvolutionDenseLayer(_BoundA):
         return backend.active().spmm(input.fwd, self.W.data, out=out)
 
 
+class ConvolutionLayer(L.Layer):
+    """A . H only -- no weights (reference gcnmodel.py:181-201); A bound at construction."""
+
+    def __init__(self, incoming, use_target_indices=False, A=None, nonlinearity=NL.linear, **kwargs):
+        super().__init__(incoming, **kwargs)
+        if use_target_indices:
+            raise NotImplementedError("use_target_indices is never enabled by the reference")
+        self.use_target_indices = use_target_indices
+        self.A = A
+        self.nonlinearity = NL.resolve(nonlinearity)
+        if self.nonlinearity.act is None:
+            raise NotImplementedError("nonlinearity %s has no gfx950 epilogue yet" % self.nonlinearity.name)
+
+    def forward(self, input, tape, **kwargs):
+        K = backend.active()
+        y = K.spmm(self.A.fwd, input, act=self.nonlinearity.act)
+        if tape is not None:
+            tape[self] = {'y': y}
+        return y
+
+    def backward(self, grad, tape, into, **kwargs):
+        K = backend.active()
+        g = grad if self.nonlinearity.act == 0 else K.act_bwd(grad, tape[self]['y'], self.nonlinearity.act)
+        dx = K.spmm(self.A.bwd, g)
+        if into[0] is not None:
+            K.add_inplace(dx, into[0])
+            dx = into[0]
+        return [dx]
+
+
 class DenseLayer2(DenseLayer):
     """Plain dense layer with the (never enabled) row gather flag (reference gcnmodel.py:203-221)."""
 
@@ -169,6 +199,15 @@ def highway_dense(incoming, gconv=False, Wh=_init.GlorotUniform(), bh=_init.Cons
     return MultiplicativeGatingLayer(gate=l_t, input1=l_h, input2=incoming), l_t
 
 
+def residual_dense(incoming, nonlinearity=NL.selu):
+    """Residual block of the reference (gcnmodel.py:290-294) -- never used by GraphConv; its SELU has no
+    gfx950 epilogue yet, so evaluating it raises NotImplementedError (SURVEY.md §8f "next")."""
+    num_inputs = int(np.prod(incoming.output_shape[1:]))
+    convX = ConvolutionDenseLayer2(incoming, num_units=num_inputs, nonlinearity=None)
+    convX_plus_X = L.ElemwiseSumLayer([convX, incoming], coeffs=1, cropping=None)
+    return L.NonlinearityLayer(convX_plus_X, nonlinearity=nonlinearity)
+
+
 def np_softmax(x):
     e_x = np.exp(x - np.max(x))
     return e_x / e_x.sum()
@@ -219,6 +258,7 @@ class GraphConv():
         self._graph_cache = {}
         self._idx_cache = {}
         self._injected_mask = None
+        self._force_dist = False          # tests: run the partitioned code path at world_size 1
         self.best_params = None
         logging.info('highway is {}'.format(self.highway))
 
@@ -262,6 +302,9 @@ class GraphConv():
         self._scal = torch.zeros(8, dtype=torch.float32, device=self.device)
         return self.l_out
 
+    def _dist(self, comm):
+        return comm.world > 1 or (self._force_dist and hasattr(comm, 'dist'))
+
     # -- device residency of the constant inputs ------------------------------------------------
     def _comm_for(self, N):
         if self.comm is None:
@@ -283,7 +326,7 @@ class GraphConv():
         N = X.shape[0]
         comm = self._comm_for(N)
         part = comm.part
-        if comm.world > 1:
+        if self._dist(comm):
             A_csr = sps.csr_matrix(A)
             At = sps.csr_matrix(A_csr.T)
             A_loc = part.local_rows_csr(A_csr, part.n_gathered)
@@ -339,11 +382,11 @@ class GraphConv():
         mask = None
         if self._injected_mask is not None and self.drop_out > 0:
             m = self._injected_mask
-            if comm.world > 1:
+            if self._dist(comm):
                 m = m[comm.part.r0:comm.part.r1]
             mask = torch.from_numpy(np.ascontiguousarray(m)).to(self.device)
         tape = {}
-        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if comm.world > 1 else None)
+        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if self._dist(comm) else None)
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
         sc = self._scal
@@ -354,7 +397,7 @@ class GraphConv():
         # backward: d(mean CE over train rows)/d logits, then the reverse sweep
         dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr))
         L.backward(self.l_out, L.PreAct(dlogits), tape, **kw)
-        if comm.world > 1:
+        if self._dist(comm):
             comm.all_reduce_sum_(self.store.g)
             comm.all_reduce_sum_(sc[0:4])
         self.adam_t += 1
@@ -368,7 +411,7 @@ class GraphConv():
 
     def _lazy_output(self, P, comm):
         def fetch():
-            if comm.world > 1:
+            if self._dist(comm):
                 buf, loc = comm.gather_buffer(P.F, tag='out')
                 loc.t.copy_(P.t)
                 comm.all_gather_rows_(buf)
@@ -382,12 +425,12 @@ class GraphConv():
         import torch
         g = self._device_graph(X, A)
         comm = g['comm']
-        kw = dict(A=g['A'], deterministic=True, comm=comm if comm.world > 1 else None)
+        kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None)
         tape = {}
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
         idx = np.asarray(test_indices)
-        if comm.world > 1:
+        if self._dist(comm):
             full = self._lazy_output(P, comm).get()
             rows = full[idx]
             return rows.argmax(-1).astype(np.int64), rows
@@ -400,7 +443,7 @@ class GraphConv():
         def f_gate(X, A):
             g = self._device_graph(X, A)
             comm = g['comm']
-            kw = dict(A=g['A'], deterministic=True, comm=comm if comm.world > 1 else None)
+            kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None)
             T = L.get_output(layer, {self.l_in: g['X']}, **kw)
             return T.numpy()
         return f_gate

@@ -148,3 +148,47 @@ def test_fit_trains_and_early_stops(cmu):
     clf2.build_model(c['A'], seed=77)
     a = clf2.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])[0]
     assert a == l0
+
+
+def test_layer_zoo_variants_match_oracle(cmu):
+    """The layer classes GraphConv does not instantiate but the reference module exports
+    (gcnmodel.py:72-112,159-249): same kernels, different wiring."""
+    import torch
+    from geographconv_amd import gcnmodel as M, ops
+    from geographconv_amd.nn import layers as L, nonlinearities as NL
+    c = cmu
+    dev = torch.device('cuda:0')
+    A = ops.SparseOperand.from_scipy(c['A'], dev)
+    X = ops.SparseOperand.from_scipy(c['X'], dev)
+    rng = np.random.RandomState(0)
+    W = (rng.randn(c['X'].shape[1], 64) * 0.05).astype(np.float32)
+    b = (rng.randn(64) * 0.1).astype(np.float32)
+    # SparseConvolutionDenseLayer2: tanh(A.(X.W) + b), A through get_output
+    l_in = L.InputLayer((None, c['X'].shape[1]))
+    l = M.SparseConvolutionDenseLayer2(l_in, num_units=64, W=W, b=b, nonlinearity=NL.tanh)
+    L.ParamStore(L.get_all_params(l), dev)
+    y = L.get_output(l, {l_in: X}, A=A).numpy()
+    ref = np.tanh(O.spmm(c['A'], O.spmm(c['X'], W)) + b)
+    assert np.abs(y - ref).max() < 2e-5
+    # SparseConvolutionDenseLayer / ConvolutionDenseLayer_zero: A bound at construction
+    l2 = M.SparseConvolutionDenseLayer(l_in, A=A, num_units=64, W=W, b=b, nonlinearity=NL.tanh)
+    L.ParamStore(L.get_all_params(l2), dev)
+    assert np.abs(L.get_output(l2, {l_in: X}).numpy() - ref).max() < 2e-5
+    d_in = L.InputLayer((None, 64))
+    W2 = (rng.randn(64, 32) * 0.1).astype(np.float32)
+    l3 = M.ConvolutionDenseLayer_zero(d_in, A=A, num_units=32, W=W2, b=None, nonlinearity=NL.sigmoid)
+    L.ParamStore(L.get_all_params(l3), dev)
+    H = ops.DMat.from_numpy(ref, dev)
+    y3 = L.get_output(l3, {d_in: H}).numpy()
+    assert np.abs(y3 - O.sigmoid(O.spmm(c['A'], ref @ W2))).max() < 2e-5
+    # ConvolutionLayer: A.H only
+    l4 = M.ConvolutionLayer(d_in, A=A)
+    assert np.abs(L.get_output(l4, {d_in: H}).numpy() - O.spmm(c['A'], ref)).max() < 2e-5
+    # sparse-input layers reject dense input like the reference (gcnmodel.py:34-36,82-84,236-238)
+    with pytest.raises(ValueError):
+        L.get_output(l, {l_in: H}, A=A)
+    # residual_dense builds, but its SELU has no kernel yet
+    r = M.residual_dense(d_in)
+    L.ParamStore(L.get_all_params(r), dev)
+    with pytest.raises(NotImplementedError):
+        L.get_output(r, {d_in: H}, A=A)

@@ -1,0 +1,161 @@
+"""Host-side logic that needs no GPU: Lasagne-like graph helpers, initialisers, parameter order,
+gcnmain's data plumbing (dump.pkl format, geo_eval, haversine, flag parsing)."""
+import gzip
+import os
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from geographconv_amd import gcnmain
+from geographconv_amd.nn import init, layers as L, nonlinearities as NL
+
+
+def test_glorot_uniform_bounds_and_draw_order():
+    np.random.seed(77)
+    W = init.GlorotUniform(gain=1)((300, 200))
+    a = np.sqrt(3) * np.sqrt(2.0 / 500)
+    assert W.dtype == np.float32 and W.shape == (300, 200)
+    assert np.abs(W).max() <= a and np.abs(W).max() > 0.98 * a
+    np.random.seed(77)
+    ref = np.random.uniform(-a, a, size=(300, 200)).astype(np.float32)     # Lasagne: one uniform draw
+    assert np.array_equal(W, ref)
+    assert np.all(init.Constant(-4.0)((7,)) == -4)
+    with pytest.raises(RuntimeError):
+        init.GlorotUniform()((5,))
+
+
+def test_orthogonal_is_orthogonal():
+    np.random.seed(1)
+    Q = init.Orthogonal()((64, 64))
+    assert np.allclose(Q.T @ Q, np.eye(64), atol=1e-5)
+    R = init.Orthogonal()((32, 64))
+    assert np.allclose(R @ R.T, np.eye(32), atol=1e-5)
+
+
+def _graph(highway=True, hid=(8, 8, 8)):
+    from geographconv_amd import gcnmodel as M
+    np.random.seed(5)
+    l_in = L.InputLayer((None, 20))
+    l = M.SparseInputDenseLayer(l_in, num_units=hid[0], nonlinearity=NL.tanh)
+    l = L.dropout(l, p=0.5)
+    gates = []
+    for h in hid[1:]:
+        if highway:
+            l, g = M.highway_dense(l, gconv=True, nonlinearity=NL.tanh, Wt=init.Orthogonal(), Wh=init.GlorotUniform(gain=1))
+            gates.append(g)
+        else:
+            l = M.ConvolutionDenseLayer2(l, num_units=h, nonlinearity=NL.tanh)
+    l_out = M.ConvolutionDenseLayer3(l, num_units=5, nonlinearity=NL.softmax)
+    return l_in, l_out, gates
+
+
+def test_param_order_matches_lasagne_get_all_params():
+    l_in, l_out, gates = _graph(True)
+    shapes = [p.shape for p in L.get_all_params(l_out)]
+    # [W0,b0,(Wt,bt,Wh,bh)x2,Wo,bo]: gate before conv inside a block
+    assert shapes == [(20, 8), (8,), (8, 8), (8,), (8, 8), (8,), (8, 8), (8,), (8, 8), (8,), (8, 5), (5,)]
+    vals = L.get_all_param_values(l_out)
+    assert np.all(vals[3] == -4.0) and np.all(vals[5] == 0.0)           # bt = -4, bh = 0
+    assert np.allclose(vals[2].T @ vals[2], np.eye(8), atol=1e-5)       # Wt orthogonal, Wh not
+    assert not np.allclose(vals[4].T @ vals[4], np.eye(8), atol=1e-2)
+    # tags: biases are not regularizable
+    assert len(L.get_all_params(l_out, regularizable=True)) == 6
+    assert len(L.get_all_params(l_out, trainable=True)) == 12
+    assert L.count_params(l_out) == 20 * 8 + 8 + 4 * (64 + 8) + 8 * 5 + 5
+    l_in, l_out, _ = _graph(False, hid=(8, 6, 7))
+    assert [p.shape for p in L.get_all_params(l_out)] == [(20, 8), (8,), (8, 6), (6,), (6, 7), (7,), (7, 5), (5,)]
+
+
+def test_set_all_param_values_validates():
+    l_in, l_out, _ = _graph(True)
+    vals = L.get_all_param_values(l_out)
+    vals[0] = vals[0] * 0 + 1
+    L.set_all_param_values(l_out, vals)
+    assert np.all(L.get_all_param_values(l_out)[0] == 1)
+    with pytest.raises(ValueError):
+        L.set_all_param_values(l_out, vals[:-1])
+    vals[1] = np.zeros(9, np.float32)
+    with pytest.raises(ValueError):
+        L.set_all_param_values(l_out, vals)
+
+
+def test_get_all_layers_topological_and_shapes():
+    l_in, l_out, gates = _graph(True)
+    layers = L.get_all_layers(l_out)
+    assert layers[0] is l_in and layers[-1] is l_out
+    pos = {l: i for i, l in enumerate(layers)}
+    for l in layers:
+        ins = getattr(l, 'input_layers', None) or ([l.input_layer] if getattr(l, 'input_layer', None) else [])
+        assert all(pos[i] < pos[l] for i in ins)
+    assert l_out.output_shape == (None, 5)
+    assert gates[0].output_shape == (None, 8)
+
+
+def test_gating_layer_asserts_equal_shapes():
+    from geographconv_amd import gcnmodel as M
+    a = L.InputLayer((None, 4))
+    b = L.InputLayer((None, 5))
+    with pytest.raises(AssertionError):
+        M.MultiplicativeGatingLayer(a, a, b)
+
+
+def test_haversine_known_distances():
+    assert gcnmain.haversine((0, 0), (0, 0)) == 0
+    # one degree of longitude on the equator
+    assert abs(gcnmain.haversine((0, 0), (0, 1)) - 111.195) < 0.01
+    # Lyon - Paris, the example of the `haversine` package the reference imports
+    assert abs(gcnmain.haversine((45.7597, 4.8422), (48.8567, 2.3508)) - 392.217) < 0.05
+
+
+def test_geo_eval_metrics():
+    users = ['a', 'b', 'c']
+    loc = {'a': '0,0', 'b': '0,0', 'c': '10,10'}
+    lat = {'0': 0.0, '1': 0.0, '2': 50.0}
+    lon = {'0': 0.0, '1': 1.0, '2': 50.0}
+    mean, median, acc, dist, t, p = gcnmain.geo_eval(None, np.array([0, 1, 2]), users, lat, lon, loc)
+    assert dist[0] == 0 and abs(dist[1] - 111.195) < 0.01 and dist[2] > 161
+    assert abs(acc - 200.0 / 3) < 1e-9 and median == dist[1]
+    with pytest.raises(AssertionError):
+        gcnmain.geo_eval(None, np.array([0]), users, lat, lon, loc)
+
+
+def test_dump_pkl_roundtrip_and_preprocess(tmp_path, monkeypatch):
+    d = tmp_path / 'data'
+    d.mkdir()
+    A = sps.identity(4, format='csr', dtype=np.float32)
+    X = sps.random(4, 6, density=0.5, format='csr', dtype=np.float32, random_state=0)
+    Y = np.array([0, 1, 0, 1])
+    data = (A, X[:2], Y[:2], X[2:3], Y[2:3], X[3:], Y[3:], ['u0', 'u1'], ['u2'], ['u3'], {'0': 1.0, '1': 2.0},
+            {'0': 3.0, '1': 4.0}, {'u%d' % i: '1,1' for i in range(4)})
+    gcnmain.dump_obj(data, str(d / 'dump.pkl'))
+    with gzip.open(str(d / 'dump.pkl'), 'rb') as f:          # the reference's format: gzip + pickle (data.py:28-34)
+        assert len(pickle.load(f)) == 13
+    args = gcnmain.parse_args(['-d', str(d), '-hid', '300', '300', '300', '-highway', '-dropout', '0.5', '-reg', '0.0'])
+    monkeypatch.setattr(gcnmain, 'model_args', args)
+    back = gcnmain.preprocess_data(str(d))
+    assert len(back) == 13 and (back[0] != A).nnz == 0 and back[7] == ['u0', 'u1']
+    # no dump and no --synthetic: a clear error, not a silent fallback
+    args2 = gcnmain.parse_args(['-d', str(tmp_path / 'nope')])
+    monkeypatch.setattr(gcnmain, 'model_args', args2)
+    with pytest.raises(FileNotFoundError):
+        gcnmain.preprocess_data(str(tmp_path / 'nope'))
+
+
+def test_reference_flag_set_is_accepted():
+    # README.md:167,173 commands of the reference
+    a = gcnmain.parse_args('-hid 300 300 300 -bucket 50 -batch 500 -d ./data/cmu -mindf 10 -reg 0.0 -dropout 0.5 -cel 5 -highway'.split())
+    assert a.hid == [300, 300, 300] and a.highway and a.dropout == 0.5 and a.regularization == 0.0 and a.bucket == 50
+    a = gcnmain.parse_args('-hid 600 600 600 -bucket 2400 -batch 500 -d ./data/na -mindf 10 -reg 0.0 -dropout 0.5 -cel 15 -highway'.split())
+    assert a.hid == [600, 600, 600] and a.celebrity == 15
+    a = gcnmain.parse_args([])
+    assert a.hid == [100] and a.seed == 77 and a.lblfraction == [1.0] and a.maxdown == 10 and not a.highway
+
+
+def test_synthetic_data_tuple_shape():
+    data = gcnmain.synthetic_data('cmu')
+    A, Xtr, Ytr, Xdv, Ydv, Xte, Yte, Utr, Udv, Ute, clat, clon, uloc = data
+    assert A.shape == (9475, 9475) and Xtr.shape[0] + Xdv.shape[0] + Xte.shape[0] == 9475
+    assert len(Utr) == Xtr.shape[0] and set(clat) == set(str(c) for c in range(129))
+    assert all(u in uloc for u in Ute[:5])
