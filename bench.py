@@ -153,11 +153,11 @@ def main():
         csr = g['A'].fwd
         rp = csr.rowptr_host
         deg = np.diff(rp)
-        short = deg <= 256
         F = args.hid[-1]
-        e_short, n_short = int(deg[short].sum()), int(short.sum())
-        # one launch of spmm_rows_kernel: all short rows of the local block; B (= gathered Z) read once
-        alg = 8 * e_short + 4 * (len(deg) + 1) + 4 * csr.shape[1] * F + 4 * n_short * F
+        # one launch of spmm_rows_kernel covers every stored edge of the local row block (short rows with
+        # the fused epilogue + the 128-nonzero chunks of the long rows): algorithmic bytes = SURVEY.md §8d
+        alg = spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F)
+        e_short = int(csr.nnz)
         avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
         achieved = alg / (avg_ms * 1e-3) / 1e9 if kern_ms else None
         traffic = None
@@ -171,8 +171,7 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": len(kern_ms),
-                    "edges_per_launch": e_short,
-                    "whole_op_algorithmic_bytes": spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F)}
+                    "edges_per_launch": e_short, "bytes_per_edge": alg / max(1, e_short)}
         out = {
             "metric": "GCN-layer fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3,

@@ -20,7 +20,7 @@ c_u64 = C.c_uint64
 SIGNATURES = {
     'geogcn_version': (c_i32, []),
     'geogcn_last_error': (C.c_char_p, []),
-    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
+    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
     'geogcn_spmm_plan_destroy': (None, [c_ptr]),
     'geogcn_spmm_plan_num_long_rows': (c_i64, [c_ptr]),
     'geogcn_spmm_plan_num_chunks': (c_i64, [c_ptr]),
@@ -36,9 +36,9 @@ SIGNATURES = {
                                 c_i64, c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
-    'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
+    'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                                        c_ptr, c_ptr]),
-    'geogcn_act_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_f32, c_ptr, c_ptr]),
+    'geogcn_act_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_f32, c_ptr, c_i64, c_ptr]),
     'geogcn_add_inplace_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr]),
     'geogcn_colsum_workspace_bytes': (c_sz, [c_i64, c_i32]),
     'geogcn_colsum_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_sz, c_ptr]),

@@ -74,10 +74,11 @@ __global__ __launch_bounds__(TPB) void highway_fwd_kernel(int64_t total4, const 
     }
 }
 
-__global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t total4, const float4* __restrict__ G,
+__global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t n, int ld4, const float4* __restrict__ G,
                                                           const float4* __restrict__ T, const float4* __restrict__ Hc,
                                                           const float4* __restrict__ H, float4* __restrict__ dS,
-                                                          float4* __restrict__ dU, float4* __restrict__ dHc) {
+                                                          int ld4_dS, float4* __restrict__ dU, float4* __restrict__ dHc) {
+    const int64_t total4 = n * ld4;
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total4; e += (int64_t)gridDim.x * TPB) {
         const float4 g = G[e], t = T[e], hc = Hc[e], h = H[e];
         float4 s, u, c;
@@ -87,7 +88,12 @@ __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t total4, const 
     c.m = g.m * (1.0f - t.m);
         GEOGCN_HW(x) GEOGCN_HW(y) GEOGCN_HW(z) GEOGCN_HW(w)
 #undef GEOGCN_HW
-        dS[e] = s;
+        int64_t es = e;
+        if (ld4_dS != ld4) {
+            const int64_t row = e / ld4;
+            es = row * ld4_dS + (e - row * ld4);
+        }
+        dS[es] = s;
         dU[e] = u;
         dHc[e] = c;
     }
@@ -97,7 +103,7 @@ template <int ACT>
 __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, const float* __restrict__ G,
                                                        const float* __restrict__ Y, int64_t ld,
                                                        const uint8_t* __restrict__ mask, float scale,
-                                                       float* __restrict__ dS) {
+                                                       float* __restrict__ dS, int64_t ld_dS) {
     const int64_t total = n * F4;
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
         const int64_t row = e / F4;
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, 
             else if constexpr (ACT == GEOGCN_ACT_SIGMOID) o[i] = gg * (yo[i] * (1.0f - yo[i]));
             else o[i] = gg;
         }
-        *reinterpret_cast<float4*>(dS + row * ld + c0) = mask_pad(make_float4(o[0], o[1], o[2], o[3]), c0, F);
+        *reinterpret_cast<float4*>(dS + row * ld_dS + c0) = mask_pad(make_float4(o[0], o[1], o[2], o[3]), c0, F);
     }
 }
 
@@ -296,32 +302,35 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
 }
 
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
-                           int64_t ld, float* dS, float* dU, float* dHcarry, void* stream) {
+                           int64_t ld, float* dS, int64_t ld_dS, float* dU, float* dHcarry, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "highway_bwd_f32: negative size");
     if (n == 0 || F == 0) return 0;
     CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU, dHcarry);
-    const int64_t total4 = n * ld / 4;
-    hipLaunchKernelGGL(highway_bwd_kernel, dim3(stream_grid(total4)), dim3(TPB), 0, (hipStream_t)stream, total4,
-                       (const float4*)G, (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS,
-                       (float4*)dU, (float4*)dHcarry);
+    GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= ld, GEOGCN_E_ALIGN, "highway_bwd_f32: ld_dS=%lld must be a multiple of 4, >= ld",
+                   (long long)ld_dS);
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(stream_grid(n * ld / 4)), dim3(TPB), 0, (hipStream_t)stream, n,
+                       (int)(ld / 4), (const float4*)G, (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS,
+                       (int)(ld_dS / 4), (float4*)dU, (float4*)dHcarry);
     GEOGCN_LAUNCH_CHECK("highway_bwd_kernel");
     return 0;
 }
 
 int geogcn_act_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
-                       const uint8_t* keep_mask, float scale, float* dS, void* stream) {
+                       const uint8_t* keep_mask, float scale, float* dS, int64_t ld_dS, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "act_bwd_f32: negative size");
     if (n == 0 || F == 0) return 0;
     CHECK_VEC("act_bwd_f32", ld, G, Y, dS);
+    GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= (int64_t)((F + 3) / 4) * 4, GEOGCN_E_ALIGN, "act_bwd_f32: bad ld_dS=%lld",
+                   (long long)ld_dS);
     const int F4 = (F + 3) / 4;
     const dim3 grid(stream_grid(n * F4));
     hipStream_t st = (hipStream_t)stream;
     if (act == GEOGCN_ACT_TANH)
-        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_TANH>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS);
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_TANH>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
     else if (act == GEOGCN_ACT_SIGMOID)
-        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_SIGMOID>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS);
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_SIGMOID>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
     else if (act == GEOGCN_ACT_NONE)
-        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_NONE>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS);
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_NONE>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
     else {
         set_error("act_bwd_f32: unknown act %d", act);
         return GEOGCN_E_ARG;

@@ -15,6 +15,8 @@
 //   * bias + tanh/sigmoid epilogue fused into the store (gcnmodel.py:41-42,132-136).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -36,8 +38,22 @@ __device__ __forceinline__ void fma4(float4& acc, float a, const float4& b) {
     acc.w = fmaf(a, b.w, acc.w);
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// NT = 1: non-temporal gather (global_load ... nt): the line is streamed through the L2 without
+// displacing the lines loaded with the default policy (measured: tools/micro/nt_retention.hip).
+template <int NT>
+__device__ __forceinline__ float4 gather4(const float4* p) {
+    if constexpr (NT) {
+        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+
 // One group walks nonzeros [s, e) and accumulates into acc[K4].
-template <int K4>
+template <int K4, int NT = 0>
 __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int nF4,
                                                  const int* __restrict__ colidx,
                                                  const float* __restrict__ val,
@@ -66,8 +82,8 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
             for (int k = 0; k < K4; ++k) {
                 const int q = lane16 + kGroup * k;
                 if (q < nF4) {
-                    v0[k] = b0[q];
-                    v1[k] = b1[q];
+                    v0[k] = gather4<NT>(b0 + q);
+                    v1[k] = gather4<NT>(b1 + q);
                 }
             }
 #pragma unroll
@@ -86,7 +102,7 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
 #pragma unroll
             for (int k = 0; k < K4; ++k) {
                 const int q = lane16 + kGroup * k;
-                if (q < nF4) fma4(acc[k], a0, b0[q]);
+                if (q < nF4) fma4(acc[k], a0, gather4<NT>(b0 + q));
             }
         }
     }
@@ -109,50 +125,50 @@ __device__ __forceinline__ float4 epilogue4(float4 r, int col0, int F, const flo
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// rows: one group per CSR row, long rows skipped.
-template <int K4, int ACT>
+// ONE launch covers every stored edge: the leading `n_chunk_blocks` blocks take the 128-nonzero chunks
+// of the long rows (raw partial sums into the workspace P), the remaining blocks take one CSR row per
+// 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
+// that it overlaps the bulk instead of running as an under-occupied launch of its own.
+template <int K4, int ACT, int NTT>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
     const float* __restrict__ val, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
-    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz) {
-    const int row = blockIdx.x * kGroupsPerBlock + (threadIdx.x / kGroup);
+    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
+    const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
+    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split) {
     const int lane16 = threadIdx.x % kGroup;
-    if (row >= n_rows) return;
-    const int s = rowptr[row];
-    const int e = rowptr[row + 1];
-    if (e - s > long_row_nnz) return;       // handled by the chunk path
     const int nF4 = (F + 3) >> 2;
     float4 acc[K4];
 #pragma unroll
     for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    group_accumulate<K4>(s, e, lane16, nF4, colidx, val, B, ldb, acc);
+    if ((int)blockIdx.x < n_chunk_blocks) {
+        const int ch = blockIdx.x * kGroupsPerBlock + (threadIdx.x / kGroup);
+        if (ch >= n_chunks) return;
+        const int cs = chunk_start[ch], ce = chunk_end[ch];
+        const int ch_h = chunk_split ? chunk_split[ch] : ce;       // [cs, ch_h) hubs, [ch_h, ce) streamed
+        group_accumulate<K4, 0>(cs, ch_h, lane16, nF4, colidx, val, B, ldb, acc);
+        group_accumulate<K4, NTT>(ch_h, ce, lane16, nF4, colidx, val, B, ldb, acc);
+        float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int q = lane16 + kGroup * k;
+            if (q < nF4) out[q] = acc[k];
+        }
+        return;
+    }
+    const int row = (blockIdx.x - n_chunk_blocks) * kGroupsPerBlock + (threadIdx.x / kGroup);
+    if (row >= n_rows) return;
+    const int s = rowptr[row];
+    const int e = rowptr[row + 1];
+    if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks
+    const int h = rowsplit ? rowsplit[row] : e;
+    group_accumulate<K4, 0>(s, h, lane16, nF4, colidx, val, B, ldb, acc);
+    group_accumulate<K4, NTT>(h, e, lane16, nF4, colidx, val, B, ldb, acc);
     float4* out = reinterpret_cast<float4*>(C + (int64_t)row * ldc);
 #pragma unroll
     for (int k = 0; k < K4; ++k) {
         const int q = lane16 + kGroup * k;
         if (q < nF4) out[q] = epilogue4<ACT>(acc[k], q * 4, F, bias);
-    }
-}
-
-// chunks of long rows: one group per chunk, raw partial sums into the workspace.
-template <int K4>
-__global__ __launch_bounds__(kBlock) void spmm_chunks_kernel(
-    int n_chunks, const int* __restrict__ chunk_start, const int* __restrict__ chunk_end,
-    const int* __restrict__ colidx, const float* __restrict__ val, const float* __restrict__ B,
-    int64_t ldb, float* __restrict__ P, int64_t ldp, int F) {
-    const int ch = blockIdx.x * kGroupsPerBlock + (threadIdx.x / kGroup);
-    const int lane16 = threadIdx.x % kGroup;
-    if (ch >= n_chunks) return;
-    const int nF4 = (F + 3) >> 2;
-    float4 acc[K4];
-#pragma unroll
-    for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    group_accumulate<K4>(chunk_start[ch], chunk_end[ch], lane16, nF4, colidx, val, B, ldb, acc);
-    float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
-#pragma unroll
-    for (int k = 0; k < K4; ++k) {
-        const int q = lane16 + kGroup * k;
-        if (q < nF4) out[q] = acc[k];
     }
 }
 
@@ -221,6 +237,8 @@ struct geogcn_spmm_plan {
     int* d_long_first = nullptr;   // [n_long + 1] first chunk of each long row
     int* d_chunk_start = nullptr;  // [n_chunks]
     int* d_chunk_end = nullptr;    // [n_chunks]
+    int* d_rowsplit = nullptr;     // [n_rows]   cache hint (nullable)
+    int* d_chunk_split = nullptr;  // [n_chunks] rowsplit clamped into each chunk
 };
 
 struct geogcn_timer {
@@ -240,19 +258,33 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
               const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
               const float* bias, int act, float* ws, hipStream_t st, int64_t nnz) {
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
-    const dim3 grid((unsigned)cdiv(n_rows, kGroupsPerBlock));
+    const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
+    const int n_chunk_blocks = (int)cdiv(n_chunks, kGroupsPerBlock);
+    const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
+    const dim3 grid((unsigned)(n_chunk_blocks + cdiv(n_rows, kGroupsPerBlock)));
     geogcn_timer* tm = g_spmm_timer;
     const bool timed = tm && (g_spmm_timer_F == 0 || g_spmm_timer_F == F) &&
                        (g_spmm_timer_nnz == 0 || g_spmm_timer_nnz == nnz) && tm->used < (int)tm->begin.size() &&
                        n_rows > 0;
     if (timed) GEOGCN_HIP(hipEventRecord(tm->begin[tm->used], st));
+    static const int nt_tail = [] {
+        const char* e = getenv("GEOGCN_SPMM_NT");      // experiment switch: 0 = plain loads for the tail too
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
 #define GEOGCN_ROWS(ACT)                                                                         \
-    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
-                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz)
+    if (nt_tail)                                                                                 \
+        GEOGCN_ROWS_(ACT, 1);                                                                    \
+    else                                                                                         \
+        GEOGCN_ROWS_(ACT, 0)
+#define GEOGCN_ROWS_(ACT, NTT)                                                                   \
+    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
+                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
+                       n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
+                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr)
     if (n_rows > 0) {
-        if (act == GEOGCN_ACT_TANH) GEOGCN_ROWS(GEOGCN_ACT_TANH);
-        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_ROWS(GEOGCN_ACT_SIGMOID);
-        else GEOGCN_ROWS(GEOGCN_ACT_NONE);
+        if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }
+        else if (act == GEOGCN_ACT_SIGMOID) { GEOGCN_ROWS(GEOGCN_ACT_SIGMOID); }
+        else { GEOGCN_ROWS(GEOGCN_ACT_NONE); }
         GEOGCN_LAUNCH_CHECK("spmm_rows_kernel");
     }
     if (timed) {
@@ -260,12 +292,8 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         tm->used++;
     }
 #undef GEOGCN_ROWS
-    if (plan && plan->n_long > 0) {
-        const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
-        const dim3 cgrid((unsigned)cdiv(plan->n_chunks, kGroupsPerBlock));
-        hipLaunchKernelGGL((spmm_chunks_kernel<K4>), cgrid, dim3(kBlock), 0, st, (int)plan->n_chunks,
-                           plan->d_chunk_start, plan->d_chunk_end, colidx, val, B, ldb, ws, ldp, F);
-        GEOGCN_LAUNCH_CHECK("spmm_chunks_kernel");
+#undef GEOGCN_ROWS_
+    if (n_chunks > 0) {
         const int Fpad = (int)std::min<int64_t>(ldc, ldp);
         const dim3 rgrid((unsigned)plan->n_long);
 #define GEOGCN_RED(ACT)                                                                          \
@@ -332,22 +360,26 @@ int geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32_
     return 0;
 }
 
-int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz,
-                            int32_t chunk_nnz, geogcn_spmm_plan** out) {
+int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const int32_t* rowsplit_host,
+                            int32_t long_row_nnz, int32_t chunk_nnz, geogcn_spmm_plan** out) {
     GEOGCN_REQUIRE(rowptr_host && out, GEOGCN_E_NULL, "spmm_plan_create: null pointer");
     GEOGCN_REQUIRE(n_rows >= 0 && long_row_nnz > 0 && chunk_nnz > 0, GEOGCN_E_SIZE,
                    "spmm_plan_create: bad sizes n_rows=%d long=%d chunk=%d", n_rows, long_row_nnz,
                    chunk_nnz);
-    std::vector<int> long_rows, long_first, cs, ce;
+    std::vector<int> long_rows, long_first, cs, ce, csplit;
     for (int r = 0; r < n_rows; ++r) {
         const int s = rowptr_host[r], e = rowptr_host[r + 1];
         GEOGCN_REQUIRE(e >= s, GEOGCN_E_SIZE, "spmm_plan_create: rowptr not monotone at row %d", r);
+        GEOGCN_REQUIRE(!rowsplit_host || (rowsplit_host[r] >= s && rowsplit_host[r] <= e), GEOGCN_E_SIZE,
+                       "spmm_plan_create: rowsplit[%d] outside its row", r);
         if (e - s > long_row_nnz) {
             long_rows.push_back(r);
             long_first.push_back((int)cs.size());
             for (int p = s; p < e; p += chunk_nnz) {
+                const int pe = std::min(e, p + chunk_nnz);
                 cs.push_back(p);
-                ce.push_back(std::min(e, p + chunk_nnz));
+                ce.push_back(pe);
+                if (rowsplit_host) csplit.push_back(std::min(pe, std::max(p, rowsplit_host[r])));
             }
         }
     }
@@ -369,6 +401,15 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t 
         if (e == hipSuccess) e = upload(long_first, &plan->d_long_first);
         if (e == hipSuccess) e = upload(cs, &plan->d_chunk_start);
         if (e == hipSuccess) e = upload(ce, &plan->d_chunk_end);
+        if (e == hipSuccess && rowsplit_host) e = upload(csplit, &plan->d_chunk_split);
+        if (e != hipSuccess) {
+            set_error("spmm_plan_create: %s", hipGetErrorString(e));
+            geogcn_spmm_plan_destroy(plan);
+            return (int)e;
+        }
+    }
+    if (rowsplit_host && n_rows > 0) {
+        hipError_t e = upload(std::vector<int>(rowsplit_host, rowsplit_host + n_rows), &plan->d_rowsplit);
         if (e != hipSuccess) {
             set_error("spmm_plan_create: %s", hipGetErrorString(e));
             geogcn_spmm_plan_destroy(plan);
@@ -385,6 +426,8 @@ void geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan) {
     if (plan->d_long_first) (void)hipFree(plan->d_long_first);
     if (plan->d_chunk_start) (void)hipFree(plan->d_chunk_start);
     if (plan->d_chunk_end) (void)hipFree(plan->d_chunk_end);
+    if (plan->d_rowsplit) (void)hipFree(plan->d_rowsplit);
+    if (plan->d_chunk_split) (void)hipFree(plan->d_chunk_split);
     delete plan;
 }
 

@@ -62,7 +62,7 @@ class Comm:
         """(gathered matrix, view of the local slot).  Single rank: one buffer, no pad rows."""
         K = backend.active()
         n = self.part.N
-        buf = K.DMat.empty(n, F, self.device)
+        buf = K.DMat.empty(n, F, self.device, ld=K.gather_ld(F))
         return buf, buf
 
     def all_gather_rows_(self, gathered):
@@ -91,7 +91,7 @@ class TorchDistComm(Comm):
         buf = self._bufs.get(key)
         if buf is None:
             # zero once: the tail rows of the last slot are never written and must read as 0
-            buf = self._bufs[key] = K.DMat(self.part.n_gathered, F, self.device)
+            buf = self._bufs[key] = K.DMat(self.part.n_gathered, F, self.device, ld=K.gather_ld(F))
         lo = self.rank * self.part.R
         return buf, buf.rows(lo, lo + self.part.n_local)
 

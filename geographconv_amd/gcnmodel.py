@@ -258,6 +258,7 @@ class GraphConv():
         self._graph_cache = {}
         self._idx_cache = {}
         self._injected_mask = None
+        self.hub_row_bytes = None         # SpMM cache hint (ops.CSR): off -- no gain at full-row granularity
         self._force_dist = False          # tests: run the partitioned code path at world_size 1
         self.best_params = None
         logging.info('highway is {}'.format(self.highway))
@@ -332,12 +333,13 @@ class GraphConv():
             A_loc = part.local_rows_csr(A_csr, part.n_gathered)
             At_loc = part.local_rows_csr(At, part.n_gathered)
             same = (A_loc != At_loc).nnz == 0
-            fwd = K.CSR(A_loc, self.device)
-            bwd = fwd if same else K.CSR(At_loc, self.device)
+            hub = self.hub_row_bytes
+            fwd = K.CSR(A_loc, self.device, hub_row_bytes=hub)
+            bwd = fwd if same else K.CSR(At_loc, self.device, hub_row_bytes=hub)
             dA = K.SparseOperand(fwd, bwd, same)
             dX = K.SparseOperand.from_scipy(part.local_rows(sps.csr_matrix(X)), self.device)
         else:
-            dA = K.SparseOperand.from_scipy(A, self.device)
+            dA = K.SparseOperand.from_scipy(A, self.device, hub_row_bytes=self.hub_row_bytes)
             dX = K.SparseOperand.from_scipy(X, self.device)
         hit = {'X_ref': X, 'A_ref': A, 'X': dX, 'A': dA, 'N': N, 'comm': comm}
         self._graph_cache = {key: hit}          # one graph resident at a time
@@ -395,7 +397,8 @@ class GraphConv():
         if self.regul_coef > 0:
             K.reg_penalty(self.store.p, self.store.regmask, self.regul_coef, self.regul_coef, out=sc[4:5])
         # backward: d(mean CE over train rows)/d logits, then the reverse sweep
-        dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr))
+        dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr),
+                                   out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)))
         L.backward(self.l_out, L.PreAct(dlogits), tape, **kw)
         if self._dist(comm):
             comm.all_reduce_sum_(self.store.g)
@@ -413,7 +416,7 @@ class GraphConv():
         def fetch():
             if self._dist(comm):
                 buf, loc = comm.gather_buffer(P.F, tag='out')
-                loc.t.copy_(P.t)
+                loc.copy_from(P)
                 comm.all_gather_rows_(buf)
                 return buf.numpy()[:comm.part.N]
             return P.numpy()

@@ -111,6 +111,10 @@ class ParamStore:
 # --------------------------------------------------------------------------------------------
 # gradient token: "this is already the gradient w.r.t. the PRE-activation"
 # --------------------------------------------------------------------------------------------
+def y_device(x):
+    return x.device if hasattr(x, 'device') else x.fwd.device
+
+
 class PreAct:
     def __init__(self, m):
         self.m = m
@@ -258,8 +262,10 @@ class DenseLayer(Layer):
         else:
             comm = kwargs.get('comm')
             if comm is None:
-                z = self._matmul(input, None)
-                zf = z
+                # Z is gathered row-wise by the SpMM: give it the line-aligned pitch
+                zf = K.DMat.empty(input.n if isinstance(input, K.DMat) else input.shape[0], self.num_units,
+                                  y_device(input), ld=K.gather_ld(self.num_units))
+                self._matmul(input, zf)
             else:
                 zf, zloc = comm.gather_buffer(self.num_units, tag='fwd')
                 self._matmul(input, zloc)
@@ -287,7 +293,9 @@ class DenseLayer(Layer):
         elif self.nonlinearity.act == 0:
             dS = grad
         else:
-            dS = K.act_bwd(grad, y, self.nonlinearity.act)
+            uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
+            out = K.DMat.empty(grad.n, grad.F, grad.device, ld=K.gather_ld(grad.F)) if uses_graph else None
+            dS = K.act_bwd(grad, y, self.nonlinearity.act, out=out)
         if self.b is not None:
             K.colsum(dS, out=self.b.grad)
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
@@ -297,7 +305,7 @@ class DenseLayer(Layer):
                 dZ = K.spmm(A.bwd, dS)
             else:
                 gf, gloc = comm.gather_buffer(self.num_units, tag='bwd')
-                gloc.t.copy_(dS.t)
+                gloc.copy_from(dS)
                 comm.all_gather_rows_(gf)
                 dZ = K.spmm(A.bwd, gf, F=self.num_units)
         else:

@@ -19,6 +19,14 @@ def pad4(F: int) -> int:
     return (int(F) + 3) // 4 * 4
 
 
+def gather_ld(F: int) -> int:
+    """Pitch for a matrix whose ROWS an SpMM gathers: whole 128-byte lines per row (300 -> 320 floats),
+    so a gathered row never shares a cache line with its neighbours -- the precondition for streaming
+    the non-hub rows with non-temporal loads without re-fetching shared boundary lines."""
+    F = int(F)
+    return (F + 31) // 32 * 32 if F >= 64 else pad4(F)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -38,11 +46,12 @@ class DMat:
     (geogcn.h convention) so a padded matrix is a valid reduction operand."""
     __slots__ = ('t', 'n', 'F')
 
-    def __init__(self, n, F, device=None, t=None):
+    def __init__(self, n, F, device=None, t=None, ld=None):
         self.n, self.F = int(n), int(F)
         if t is None:
-            t = torch.zeros((self.n, pad4(F)), dtype=torch.float32, device=device)
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (self.n, pad4(F))
+            t = torch.zeros((self.n, int(ld) if ld else pad4(F)), dtype=torch.float32, device=device)
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[0] == self.n
+        assert t.shape[1] >= pad4(F) and t.shape[1] % 4 == 0
         self.t = t
 
     @property
@@ -70,16 +79,28 @@ class DMat:
         return DMat.empty(self.n, self.F, self.t.device)
 
     @staticmethod
-    def empty(n, F, device):
+    def empty(n, F, device, ld=None):
         """Uninitialised when there are no pad columns (the producer writes every element);
-        zero-filled otherwise so the pads honour the zero convention."""
+        zero-filled otherwise so the pads honour the zero convention.  A matrix with the line-aligned
+        gather pitch (`ld=gather_ld(F)`) is only ever read through the SpMM / GEMM, which never touch
+        columns >= roundup4(F), so its extra pad columns may stay uninitialised."""
+        ld = int(ld) if ld else pad4(F)
         if pad4(F) == int(F):
-            return DMat(n, F, t=torch.empty((int(n), int(F)), dtype=torch.float32, device=device))
-        return DMat(n, F, device)
+            return DMat(n, F, t=torch.empty((int(n), ld), dtype=torch.float32, device=device))
+        return DMat(n, F, device, ld=ld)
 
     def rows(self, r0, r1):
         """View of a row range (shares storage)."""
         return DMat(r1 - r0, self.F, t=self.t[r0:r1])
+
+    def copy_from(self, other):
+        """Copy the logical columns of `other` (pitches may differ)."""
+        if other.ld == self.ld:
+            self.t.copy_(other.t)
+        else:
+            w = pad4(self.F)
+            self.t[:, :w].copy_(other.t[:, :w])
+        return self
 
 
 class Workspace:
@@ -96,10 +117,19 @@ class Workspace:
         return self.t
 
 
-class CSR:
-    """Device CSR (int32 indices, fp32 values) + the long-row split plan for the SpMM kernel."""
+# Bytes of the gathered operand that the hub hint tries to keep resident in each XCD's 4 MB L2.
+HUB_L2_BUDGET_BYTES = 3 * 2 ** 20
 
-    def __init__(self, m: sps.spmatrix, device, long_row_nnz=256, chunk_nnz=128):
+
+class CSR:
+    """Device CSR (int32 indices, fp32 values) + the long-row split plan for the SpMM kernel.
+
+    `hub_row_bytes` (bytes of one gathered row of the dense operand, e.g. 1200 for F=300) switches
+    the cache hint on: the columns referenced most often -- as many as fit HUB_L2_BUDGET_BYTES -- are
+    declared hubs, each row's nonzeros are reordered [hubs | rest] (sorted inside each part) and the
+    kernel gathers the rest with non-temporal loads so the hub rows stay in L2."""
+
+    def __init__(self, m: sps.spmatrix, device, long_row_nnz=256, chunk_nnz=128, hub_row_bytes=None):
         require_gpu()
         m = sps.csr_matrix(m)
         if not m.has_sorted_indices:
@@ -109,14 +139,34 @@ class CSR:
             raise ValueError("CSR too large for int32 indices")
         self.shape = m.shape
         self.nnz = int(m.nnz)
-        self.rowptr_host = np.ascontiguousarray(m.indptr, dtype=np.int32)
-        self.rowptr = torch.from_numpy(self.rowptr_host).to(device)
-        self.colidx = torch.from_numpy(np.ascontiguousarray(m.indices, dtype=np.int32)).to(device)
-        self.val = torch.from_numpy(np.ascontiguousarray(m.data, dtype=np.float32)).to(device)
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.ascontiguousarray(m.data, dtype=np.float32)
+        rowsplit = None
+        self.n_hubs = 0
+        if hub_row_bytes and self.nnz > 0:
+            k = int(HUB_L2_BUDGET_BYTES // max(1, hub_row_bytes))
+            refs = np.bincount(indices, minlength=m.shape[1])
+            if 0 < k < m.shape[1] and (refs > 0).sum() > k:
+                hubs = np.argpartition(-refs, k)[:k]
+                is_hub = np.zeros(m.shape[1], dtype=bool)
+                is_hub[hubs] = True
+                nz_hub = is_hub[indices]
+                row_of = np.repeat(np.arange(m.shape[0], dtype=np.int64), np.diff(indptr))
+                order = np.lexsort((indices, ~nz_hub, row_of))            # row, hubs first, then column
+                indices, data = indices[order], data[order]
+                hub_per_row = np.bincount(row_of[nz_hub], minlength=m.shape[0]).astype(np.int32)
+                rowsplit = np.ascontiguousarray(indptr[:-1] + hub_per_row, dtype=np.int32)
+                self.n_hubs = k
+        self.rowptr_host = indptr
+        self.rowptr = torch.from_numpy(indptr).to(device)
+        self.colidx = torch.from_numpy(indices).to(device)
+        self.val = torch.from_numpy(data).to(device)
         self.device = device
         self._plan = C.c_void_p(0)
         lib = _ffi.lib()
-        check(lib.geogcn_spmm_plan_create(self.shape[0], self.rowptr_host.ctypes.data_as(C.c_void_p),
+        check(lib.geogcn_spmm_plan_create(self.shape[0], indptr.ctypes.data_as(C.c_void_p),
+                                          rowsplit.ctypes.data_as(C.c_void_p) if rowsplit is not None else None,
                                           int(long_row_nnz), int(chunk_nnz), C.byref(self._plan)),
               'spmm_plan_create')
         self.n_long_rows = int(lib.geogcn_spmm_plan_num_long_rows(self._plan))
@@ -190,10 +240,10 @@ def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
 
 
 def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None):
-    dS = G.like() if dS is None else dS
+    dS = DMat.empty(G.n, G.F, G.device, ld=gather_ld(G.F)) if dS is None else dS      # dS feeds the A^T SpMM
     dU = G.like() if dU is None else dU
     dHcarry = G.like() if dHcarry is None else dHcarry
-    check(_ffi.lib().geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t),
+    check(_ffi.lib().geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld,
                                             _p(dU.t), _p(dHcarry.t), _stream()), 'highway_bwd_f32')
     return dS, dU, dHcarry
 
@@ -202,7 +252,7 @@ def act_bwd(G: DMat, Y: DMat, act, out: DMat = None, keep_mask=None, scale=1.0):
     """dS = G [* mask * scale] * act'(Y)  (act' through the layer output Y)."""
     out = G.like() if out is None else out
     check(_ffi.lib().geogcn_act_bwd_f32(G.n, G.F, _p(G.t), _p(Y.t), G.ld, int(act), _p(keep_mask), float(scale),
-                                        _p(out.t), _stream()), 'act_bwd_f32')
+                                        _p(out.t), out.ld, _stream()), 'act_bwd_f32')
     return out
 
 
@@ -330,10 +380,11 @@ class SparseOperand:
         self.shape = fwd.shape
 
     @staticmethod
-    def from_scipy(m, device, need_transpose=True, long_row_nnz=256, chunk_nnz=128, dense_head=True):
+    def from_scipy(m, device, need_transpose=True, long_row_nnz=256, chunk_nnz=128, dense_head=True,
+                   hub_row_bytes=None):
         m = sps.csr_matrix(m).astype(np.float32)
         m.sort_indices()
-        fwd = CSR(m, device, long_row_nnz, chunk_nnz)
+        fwd = CSR(m, device, long_row_nnz, chunk_nnz, hub_row_bytes=hub_row_bytes)
         if not need_transpose:
             return SparseOperand(fwd, None, False)
         sym = False
@@ -362,7 +413,7 @@ class SparseOperand:
                 mt = sps.csr_matrix(mt)
                 mt.eliminate_zeros()
                 mt.sort_indices()
-        bwd = CSR(mt, device, long_row_nnz, chunk_nnz)
+        bwd = CSR(mt, device, long_row_nnz, chunk_nnz, hub_row_bytes=hub_row_bytes if head_dense is None else None)
         return SparseOperand(fwd, bwd, False, head_idx, head_dense)
 
 

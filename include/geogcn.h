@@ -51,8 +51,13 @@ const char* geogcn_last_error(void);
  * bias may be NULL.  plan may be NULL (no row splitting: correct, slow on hub rows).          */
 typedef struct geogcn_spmm_plan geogcn_spmm_plan;
 
-int    geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz,
-                               int32_t chunk_nnz, geogcn_spmm_plan** out);
+/* rowsplit_host (nullable, n_rows entries, rowptr[r] <= rowsplit[r] <= rowptr[r+1]) is a CACHE HINT:
+ * the caller has ordered each row's nonzeros so that [rowptr[r], rowsplit[r]) reference the "hub"
+ * rows of B it wants kept in the 4 MB per-XCD L2; those are gathered with the default policy, the rest
+ * [rowsplit[r], rowptr[r+1]) with non-temporal loads so that they do not evict the hubs.  Results do
+ * not depend on it.                                                                               */
+int    geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const int32_t* rowsplit_host,
+                               int32_t long_row_nnz, int32_t chunk_nnz, geogcn_spmm_plan** out);
 void   geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan);
 int64_t geogcn_spmm_plan_num_long_rows(const geogcn_spmm_plan* plan);
 int64_t geogcn_spmm_plan_num_chunks(const geogcn_spmm_plan* plan);
@@ -103,13 +108,13 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
 /* its gradient + tanh'/sigmoid' of the two branches (what autodiff derives for :266,:136,:286):
  *   dS = G*T*(1-Hc^2)   dU = G*(Hc-H)*T*(1-T)   dHcarry = G*(1-T)                               */
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
-                           const float* H, int64_t ld, float* dS, float* dU, float* dHcarry,
-                           void* stream);
+                           const float* H, int64_t ld, float* dS, int64_t ld_dS /* dS may use the line-aligned
+                           pitch of an SpMM operand */, float* dU, float* dHcarry, void* stream);
 /* dS = G [* keep_mask * scale] * act'(Y) with act' expressed through the layer OUTPUT Y:
  * tanh: 1 - Y^2 (gcnmodel.py:42,136), sigmoid: Y(1-Y) (gcnmodel.py:286), none: 1.  The optional
  * mask folds in the dropout that follows layer 0 (gcnmodel.py:357); mask may be NULL.           */
 int geogcn_act_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
-                       const uint8_t* keep_mask, float scale, float* dS, void* stream);
+                       const uint8_t* keep_mask, float scale, float* dS, int64_t ld_dS, void* stream);
 /* Y += X over n_floats contiguous floats (gradient accumulation where a layer output feeds
  * several consumers: Theano's Elemwise{add} in the autodiff graph of gcnmodel.py:266,288)      */
 int geogcn_add_inplace_f32(int64_t n_floats, const float* X, float* Y, void* stream);

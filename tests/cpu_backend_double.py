@@ -8,7 +8,7 @@ import numpy as np
 import scipy.sparse as sps
 import torch
 
-from geographconv_amd.ops import DMat, pad4  # noqa: F401  (pure containers, device-agnostic)
+from geographconv_amd.ops import DMat, gather_ld, pad4  # noqa: F401  (pure containers, device-agnostic)
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 
@@ -30,7 +30,7 @@ def _v(m: DMat):
 
 
 class CSR:
-    def __init__(self, m, device=None, long_row_nnz=256, chunk_nnz=128):
+    def __init__(self, m, device=None, long_row_nnz=256, chunk_nnz=128, **kw):
         self.m = sps.csr_matrix(m).astype(np.float32)
         self.shape = self.m.shape
         self.nnz = self.m.nnz

@@ -7,7 +7,13 @@
 #include <stdlib.h>
 #include <vector>
 
-template <int K4>
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ float4 ld4(const float4* p) {
+    if (NT) { f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *p;
+}
+template <int K4, int NT>
 __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ T, long row_f4, unsigned n_rows,
                                                      int iters, float4* __restrict__ out, unsigned seed) {
     const int g = (blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -23,7 +29,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
         const float4* p1 = T + (long)r1 * row_f4 + l;
         float4 v0[K4], v1[K4];
 #pragma unroll
-        for (int k = 0; k < K4; ++k) { v0[k] = p0[16 * k]; v1[k] = p1[16 * k]; }
+        for (int k = 0; k < K4; ++k) { v0[k] = ld4<NT>(p0 + 16 * k); v1[k] = ld4<NT>(p1 + 16 * k); }
 #pragma unroll
         for (int k = 0; k < K4; ++k) {
             acc.x += v0[k].x + v1[k].x; acc.y += v0[k].y + v1[k].y;
@@ -33,15 +39,15 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
     if (acc.x == 12345.678f) out[g] = acc;
 }
 
-template <int K4>
+template <int K4, int NT>
 double run(const float4* T, long row_f4, unsigned n_rows, int groups, int iters, float4* out) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const int blocks = groups / 16;
-    gather_kernel<K4><<<blocks, 256>>>(T, row_f4, n_rows, iters, out, 1u);
+    gather_kernel<K4, NT><<<blocks, 256>>>(T, row_f4, n_rows, iters, out, 1u);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    gather_kernel<K4><<<blocks, 256>>>(T, row_f4, n_rows, iters, out, 7u);
+    gather_kernel<K4, NT><<<blocks, 256>>>(T, row_f4, n_rows, iters, out, 7u);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -59,11 +65,13 @@ int main() {
     printf("%10s %8s | TB/s for row bytes: 256 (K4=1)   512 (K4=2)   1280 (K4=5)\n", "table", "rows@256");
     for (size_t mb : {1, 2, 3, 4, 8, 16, 32, 64, 128, 192, 256, 384, 512, 1024, 2048, 4096}) {
         const size_t bytes = mb << 20;
-        double r[3];
-        r[0] = run<1>(T, 16, (unsigned)(bytes / 256), groups, 64, out);
-        r[1] = run<2>(T, 32, (unsigned)(bytes / 512), groups, 32, out);
-        r[2] = run<5>(T, 80, (unsigned)(bytes / 1280), groups, 16, out);
-        printf("%8zu MB %8zu | %28.2f %12.2f %12.2f\n", mb, bytes / 256, r[0], r[1], r[2]);
+        double r[5];
+        r[0] = run<1, 0>(T, 16, (unsigned)(bytes / 256), groups, 64, out);
+        r[1] = run<2, 0>(T, 32, (unsigned)(bytes / 512), groups, 32, out);
+        r[2] = run<5, 0>(T, 80, (unsigned)(bytes / 1280), groups, 16, out);
+        r[3] = run<1, 1>(T, 16, (unsigned)(bytes / 256), groups, 64, out);
+        r[4] = run<5, 1>(T, 80, (unsigned)(bytes / 1280), groups, 16, out);
+        printf("%8zu MB %8zu | %28.2f %12.2f %12.2f   nt: %6.2f %6.2f\n", mb, bytes / 256, r[0], r[1], r[2], r[3], r[4]);
     }
     return 0;
 }

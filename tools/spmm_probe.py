@@ -20,14 +20,18 @@ def main():
     ap.add_argument('--shape', default='twus')
     ap.add_argument('--long', type=int, default=256)
     ap.add_argument('--chunk', type=int, default=128)
+    ap.add_argument('--aligned', type=int, default=1, help='use the line-aligned gather pitch for B')
+    ap.add_argument('--hub', type=int, default=0, help='hub_row_bytes for the cache hint (0 = off)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     s = synth.SHAPES[args.shape]
     A = synth.powerlaw_ahat(s.N, s.E_target)
-    dA = ops.CSR(A, dev, args.long, args.chunk)
+    dA = ops.CSR(A, dev, args.long, args.chunk, hub_row_bytes=args.hub or None)
+    print('hubs', dA.n_hubs, 'long rows', dA.n_long_rows, flush=True)
     rng = np.random.RandomState(1)
     for F in args.F:
-        H = ops.DMat.from_numpy(rng.randn(s.N, F).astype(np.float32), dev)
+        H = ops.DMat.empty(s.N, F, dev, ld=ops.gather_ld(F) if args.aligned else None)
+        H.t[:, :F].copy_(torch.from_numpy(rng.randn(s.N, F).astype(np.float32)))
         out = ops.DMat(s.N, F, dev)
         for _ in range(2):
             ops.spmm(dA, H, out=out)
