@@ -52,6 +52,8 @@ SIGNATURES = {
                                           c_i64, c_ptr]),
     'geogcn_gather_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_scatter_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'geogcn_pack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    'geogcn_unpack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_ptr]),
     'geogcn_reg_penalty_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_sz, c_ptr]),

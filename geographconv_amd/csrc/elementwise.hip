@@ -246,6 +246,33 @@ __global__ __launch_bounds__(TPB) void scatter_rows_kernel(int F, const float* _
     }
 }
 
+__global__ __launch_bounds__(TPB) void pack_panels_kernel(int64_t n_rows, int64_t R, int F4, const float* __restrict__ X,
+                                                          int64_t ldx, int W, int wp4, float4* __restrict__ out) {
+    const int64_t total = (int64_t)W * R * wp4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int j4 = (int)(e % wp4);
+        const int64_t t = e / wp4;
+        const int64_t i = t % R;
+        const int q = (int)(t / R);
+        const int c4 = q * wp4 + j4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_rows && c4 < F4) v = *reinterpret_cast<const float4*>(X + i * ldx + (int64_t)c4 * 4);
+        out[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void unpack_panels_kernel(int64_t n_rows, int64_t R, int F, int F4, const float4* __restrict__ in,
+                                                            int W, int wp4, float* __restrict__ Y, int64_t ldy) {
+    const int64_t total = n_rows * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t i = e / F4;
+        const int c4 = (int)(e - i * F4);
+        const int q = c4 / wp4, j4 = c4 - q * wp4;
+        float4 v = in[((int64_t)q * R + i) * wp4 + j4];
+        *reinterpret_cast<float4*>(Y + i * ldy + (int64_t)c4 * 4) = mask_pad(v, c4 * 4, F);
+    }
+}
+
 int64_t colsum_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(n, 64))); }
 
 }  // namespace
@@ -403,6 +430,33 @@ int geogcn_scatter_rows_f32(int32_t F, const float* src, int64_t lds, const int3
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(stream_grid(n_idx * F)), dim3(TPB), 0, (hipStream_t)stream, F, src, lds,
                        idx, n_idx, out, ldo);
     GEOGCN_LAUNCH_CHECK("scatter_rows_kernel");
+    return 0;
+}
+
+int geogcn_pack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* X, int64_t ldx, int32_t W, int32_t wp,
+                           float* out, void* stream) {
+    GEOGCN_REQUIRE(n_rows >= 0 && R >= n_rows && F > 0 && W > 0 && wp > 0, GEOGCN_E_SIZE, "pack_panels_f32: bad sizes");
+    GEOGCN_REQUIRE(wp % 4 == 0 && (int64_t)W * wp >= F && ldx % 4 == 0 && ldx >= (int64_t)((F + 3) / 4) * 4, GEOGCN_E_ALIGN,
+                   "pack_panels_f32: need wp %% 4 == 0, W*wp >= F, ldx %% 4 == 0");
+    GEOGCN_REQUIRE(X && out && aligned16(X) && aligned16(out), GEOGCN_E_NULL, "pack_panels_f32: null/misaligned pointer");
+    const int64_t total = (int64_t)W * R * (wp / 4);
+    hipLaunchKernelGGL(pack_panels_kernel, dim3(stream_grid(total)), dim3(TPB), 0, (hipStream_t)stream, n_rows, R, (F + 3) / 4,
+                       X, ldx, W, wp / 4, (float4*)out);
+    GEOGCN_LAUNCH_CHECK("pack_panels_kernel");
+    return 0;
+}
+
+int geogcn_unpack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* in, int32_t W, int32_t wp, float* Y,
+                             int64_t ldy, void* stream) {
+    GEOGCN_REQUIRE(n_rows >= 0 && R >= n_rows && F > 0 && W > 0 && wp > 0, GEOGCN_E_SIZE, "unpack_panels_f32: bad sizes");
+    GEOGCN_REQUIRE(wp % 4 == 0 && (int64_t)W * wp >= F && ldy % 4 == 0 && ldy >= (int64_t)((F + 3) / 4) * 4, GEOGCN_E_ALIGN,
+                   "unpack_panels_f32: need wp %% 4 == 0, W*wp >= F, ldy %% 4 == 0");
+    if (n_rows == 0) return 0;
+    GEOGCN_REQUIRE(in && Y && aligned16(in) && aligned16(Y), GEOGCN_E_NULL, "unpack_panels_f32: null/misaligned pointer");
+    const int F4 = (F + 3) / 4;
+    hipLaunchKernelGGL(unpack_panels_kernel, dim3(stream_grid(n_rows * F4)), dim3(TPB), 0, (hipStream_t)stream, n_rows, R, F, F4,
+                       (const float4*)in, W, wp / 4, Y, ldy);
+    GEOGCN_LAUNCH_CHECK("unpack_panels_kernel");
     return 0;
 }
 

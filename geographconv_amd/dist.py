@@ -1,14 +1,27 @@
-"""1-D row partition of the full-graph GCN across the GPUs of one node.
+"""Full-graph GCN across the GPUs of one node.  The reference has no distributed
+code at all (single process, gcnmodel.py:409-430).
 
-The reference has no distributed code at all (single process, gcnmodel.py:409-430).  Here rank r
-owns the contiguous row block [r*R, min(N, (r+1)*R)) of X, A_hat, H, Y with R = ceil(N / world);
-column indices of A_hat stay global.  Per graph-convolution layer and direction there is ONE
-exchange: the locally produced rows of Z = H.W (forward) or dS (backward) are all-gathered --
-in place, each rank's GEMM/elementwise kernel having written straight into its slot of the
-gathered buffer -- and the local SpMM then reads the whole gathered matrix.  Parameter gradients
-and the four loss/accuracy sums are all-reduced once per step over a flat arena.  Collectives go
-through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in CPU tests)."""
+Rank r owns the contiguous row block [r*R, min(N, (r+1)*R)) of X, H, Y (R = ceil(N / world));
+parameters are replicated; parameter gradients and the four loss/accuracy sums are all-reduced
+once per step over a flat arena.  The only per-layer exchange is around the graph convolution
+S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two interchangeable schemes:
+
+``a2a`` (default) -- REPARTITION BY FEATURES.  Every rank keeps the whole (88 MB) A_hat.  The
+    row-partitioned Z (n_local x F) is packed into `world` feature panels of width wp = ceil4(F/world)
+    and exchanged with ONE all-to-all, so that rank q holds panel q of ALL rows (N x wp); it runs
+    the SpMM on that narrow operand (bias + activation fused, they are per column) and a second
+    all-to-all returns the result to the row partition.  Per rank and exchange 2*(w-1)/w * N/w * F
+    floats move -- 116 MB at w = 8, F = 300 -- instead of the (w-1)/w * N * F (462 MB) an all-gather
+    would deliver to every rank, and an all-to-all keeps all 7 xGMI links of a GPU busy at once.
+``allgather`` -- 1-D row split of A_hat as well: the local GEMM writes Z_r straight into rank r's
+    slot of the gathered buffer, all_gather_into_tensor runs in place, the local SpMM reads the
+    whole gathered matrix.  Simple, but communication-bound beyond 2 GPUs on a graph without locality.
+
+Collectives go through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in
+the CPU tests).  Select the scheme with GEOGCN_DIST_EXCHANGE=a2a|allgather."""
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import scipy.sparse as sps
@@ -42,6 +55,16 @@ class RowPartition:
             blk = sps.csr_matrix((blk.data, blk.indices, blk.indptr), shape=(blk.shape[0], pad_cols_to))
         return blk
 
+    def padded_square_csr(self, m: sps.spmatrix):
+        """The whole matrix grown to n_gathered x n_gathered (empty tail rows / columns): the operand
+        of the feature-partitioned SpMM, whose dense operand is laid out by gathered row index."""
+        m = sps.csr_matrix(m)
+        g = self.n_gathered
+        if m.shape == (g, g):
+            return m
+        indptr = np.concatenate([m.indptr, np.full(g - m.shape[0], m.indptr[-1], dtype=m.indptr.dtype)])
+        return sps.csr_matrix((m.data, m.indices, indptr), shape=(g, g))
+
     def split_indices(self, idx: np.ndarray, y: np.ndarray = None):
         """Global row indices -> (local indices, selected labels) for the rows this rank owns."""
         idx = np.asarray(idx)
@@ -53,20 +76,26 @@ class RowPartition:
 class Comm:
     """Single-rank communicator: every exchange is the identity."""
     rank, world = 0, 1
+    exchange = 'none'
 
     def __init__(self, N=None, device=None):
         self.part = None if N is None else RowPartition(N, 1, 0)
         self.device = device
 
-    def gather_buffer(self, F, tag=None):
-        """(gathered matrix, view of the local slot).  Single rank: one buffer, no pad rows."""
+    def graph_operand(self, A_host, hub_row_bytes=None):
         K = backend.active()
-        n = self.part.N
-        buf = K.DMat.empty(n, F, self.device, ld=K.gather_ld(F))
-        return buf, buf
+        return K.SparseOperand.from_scipy(A_host, self.device, hub_row_bytes=hub_row_bytes)
 
-    def all_gather_rows_(self, gathered):
-        return gathered
+    def matmul_target(self, F, tag=None):
+        """Where the GEMM that produces the SpMM's dense operand should write (n_local x F)."""
+        K = backend.active()
+        return K.DMat.empty(self.part.N, F, self.device, ld=K.gather_ld(F))
+
+    def graph_spmm(self, A_csr, z, bias, act, F, tag=None):
+        return backend.active().spmm(A_csr, z, bias=bias, act=act, F=F)
+
+    def all_gather_rows(self, local):
+        return local
 
     def all_reduce_sum_(self, t: torch.Tensor):
         return t
@@ -75,7 +104,7 @@ class Comm:
 class TorchDistComm(Comm):
     """One process per GPU; RCCL (or gloo) through torch.distributed."""
 
-    def __init__(self, N, device, group=None):
+    def __init__(self, N, device, group=None, exchange=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -83,24 +112,99 @@ class TorchDistComm(Comm):
         self.world = dist.get_world_size(group)
         self.part = RowPartition(N, self.world, self.rank)
         self.device = device
+        self.exchange = exchange or os.environ.get('GEOGCN_DIST_EXCHANGE', 'a2a')
+        if self.exchange not in ('a2a', 'allgather'):
+            raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a' or 'allgather', got %r" % self.exchange)
         self._bufs = {}
 
-    def gather_buffer(self, F, tag=None):
+    # -- constant operand ----------------------------------------------------------------------------
+    def graph_operand(self, A_host, hub_row_bytes=None):
+        """A_hat as this exchange scheme needs it: the whole matrix (a2a) or the local row block with
+        the column space widened to the gathered height (allgather)."""
         K = backend.active()
-        key = (int(F), tag)
+        part = self.part
+        A_csr = sps.csr_matrix(A_host).astype(np.float32)
+        At = sps.csr_matrix(A_csr.T)
+        if self.exchange == 'a2a':
+            Af, Ab = part.padded_square_csr(A_csr), part.padded_square_csr(At)
+        else:
+            Af = part.local_rows_csr(A_csr, part.n_gathered)
+            Ab = part.local_rows_csr(At, part.n_gathered)
+        Af.sort_indices()
+        Ab.sort_indices()
+        same = (Af.shape == Ab.shape and np.array_equal(Af.indptr, Ab.indptr) and np.array_equal(Af.indices, Ab.indices)
+                and np.array_equal(Af.data, Ab.data))
+        fwd = K.CSR(Af, self.device, hub_row_bytes=hub_row_bytes)
+        bwd = fwd if same else K.CSR(Ab, self.device, hub_row_bytes=hub_row_bytes)
+        return K.SparseOperand(fwd, bwd, same)
+
+    # -- buffers ---------------------------------------------------------------------------------------
+    def _gather_buffer(self, F, tag):
+        K = backend.active()
+        key = ('ag', int(F), tag)
         buf = self._bufs.get(key)
         if buf is None:
             # zero once: the tail rows of the last slot are never written and must read as 0
             buf = self._bufs[key] = K.DMat(self.part.n_gathered, F, self.device, ld=K.gather_ld(F))
-        lo = self.rank * self.part.R
-        return buf, buf.rows(lo, lo + self.part.n_local)
+        return buf
 
-    def all_gather_rows_(self, gathered):
-        """In-place all-gather: every rank contributes its R-row slot of `gathered`."""
+    def _flat(self, key, numel):
+        t = self._bufs.get(key)
+        if t is None or t.numel() != numel:
+            t = self._bufs[key] = torch.zeros(numel, dtype=torch.float32, device=self.device)
+        return t
+
+    def matmul_target(self, F, tag=None):
+        K = backend.active()
+        if self.exchange == 'allgather':
+            buf = self._gather_buffer(F, tag)
+            lo = self.rank * self.part.R
+            return buf.rows(lo, lo + self.part.n_local)         # the GEMM writes straight into my slot
+        return K.DMat.empty(self.part.n_local, F, self.device)
+
+    # -- the exchange around A . Z ----------------------------------------------------------------------
+    def panel_width(self, F):
+        K = backend.active()
+        return K.pad4((int(F) + self.world - 1) // self.world)
+
+    def graph_spmm(self, A_csr, z, bias, act, F, tag=None):
+        """act(A . Z + bias) for row-partitioned Z -> row-partitioned result (n_local x F)."""
+        K = backend.active()
+        part, W = self.part, self.world
+        if self.exchange == 'allgather':
+            buf = self._gather_buffer(F, tag)
+            R = part.R
+            self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group)
+            return K.spmm(A_csr, buf, bias=bias, act=act, F=F)
+        R, wp = part.R, self.panel_width(F)
+        n = W * R * wp
+        send = self._flat(('send', wp, tag), n)
+        recv = self._flat(('recv', wp, tag), n)
+        K.pack_panels(z, R, W, wp, send)
+        self.dist.all_to_all_single(recv, send, group=self.group)
+        zslab = K.DMat(part.n_gathered, wp, t=recv.view(part.n_gathered, wp))     # panel `rank` of ALL rows
+        bslab = None
+        if bias is not None:
+            bp = torch.zeros(W * wp, dtype=torch.float32, device=self.device)
+            bp[:F].copy_(bias[:F])
+            bslab = bp[self.rank * wp:(self.rank + 1) * wp]
+        sslab = K.DMat(part.n_gathered, wp, t=send.view(part.n_gathered, wp))      # reuse the send buffer
+        K.spmm(A_csr, zslab, out=sslab, bias=bslab, act=act, F=wp)
+        back = self._flat(('back', wp, tag), n)
+        self.dist.all_to_all_single(back, send, group=self.group)
+        out = K.DMat.empty(part.n_local, F, self.device)
+        K.unpack_panels(back, R, W, wp, out)
+        return out
+
+    def all_gather_rows(self, local):
+        """(n_local x F) -> (N x F) on every rank (used only to hand the full probability matrix back)."""
+        K = backend.active()
+        buf = self._gather_buffer(local.F, 'out')
+        lo = self.rank * self.part.R
+        buf.rows(lo, lo + self.part.n_local).copy_from(local)
         R = self.part.R
-        slot = gathered.t[self.rank * R:(self.rank + 1) * R]
-        self.dist.all_gather_into_tensor(gathered.t, slot, group=self.group)
-        return gathered
+        self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group)
+        return buf
 
     def all_reduce_sum_(self, t: torch.Tensor):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)

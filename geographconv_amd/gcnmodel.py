@@ -328,15 +328,7 @@ class GraphConv():
         comm = self._comm_for(N)
         part = comm.part
         if self._dist(comm):
-            A_csr = sps.csr_matrix(A)
-            At = sps.csr_matrix(A_csr.T)
-            A_loc = part.local_rows_csr(A_csr, part.n_gathered)
-            At_loc = part.local_rows_csr(At, part.n_gathered)
-            same = (A_loc != At_loc).nnz == 0
-            hub = self.hub_row_bytes
-            fwd = K.CSR(A_loc, self.device, hub_row_bytes=hub)
-            bwd = fwd if same else K.CSR(At_loc, self.device, hub_row_bytes=hub)
-            dA = K.SparseOperand(fwd, bwd, same)
+            dA = comm.graph_operand(A, hub_row_bytes=self.hub_row_bytes)
             dX = K.SparseOperand.from_scipy(part.local_rows(sps.csr_matrix(X)), self.device)
         else:
             dA = K.SparseOperand.from_scipy(A, self.device, hub_row_bytes=self.hub_row_bytes)
@@ -415,10 +407,7 @@ class GraphConv():
     def _lazy_output(self, P, comm):
         def fetch():
             if self._dist(comm):
-                buf, loc = comm.gather_buffer(P.F, tag='out')
-                loc.copy_from(P)
-                comm.all_gather_rows_(buf)
-                return buf.numpy()[:comm.part.N]
+                return comm.all_gather_rows(P).numpy()[:comm.part.N]
             return P.numpy()
         return LazyArray(fetch, (comm.part.N, P.F))
 

@@ -266,11 +266,11 @@ class DenseLayer(Layer):
                 zf = K.DMat.empty(input.n if isinstance(input, K.DMat) else input.shape[0], self.num_units,
                                   y_device(input), ld=K.gather_ld(self.num_units))
                 self._matmul(input, zf)
+                y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
-                zf, zloc = comm.gather_buffer(self.num_units, tag='fwd')
-                self._matmul(input, zloc)
-                comm.all_gather_rows_(zf)
-            y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
+                z = comm.matmul_target(self.num_units, tag='fwd')
+                self._matmul(input, z)
+                y = comm.graph_spmm(A.fwd, z, bias, act, self.num_units, tag='fwd')
         if self.nonlinearity is _nl.softmax:
             import torch
             amax = torch.empty(y.n, dtype=torch.int32, device=y.device)
@@ -304,10 +304,9 @@ class DenseLayer(Layer):
             if comm is None:
                 dZ = K.spmm(A.bwd, dS)
             else:
-                gf, gloc = comm.gather_buffer(self.num_units, tag='bwd')
-                gloc.copy_from(dS)
-                comm.all_gather_rows_(gf)
-                dZ = K.spmm(A.bwd, gf, F=self.num_units)
+                g = comm.matmul_target(self.num_units, tag='bwd')
+                g.copy_from(dS)
+                dZ = comm.graph_spmm(A.bwd, g, None, 0, self.num_units, tag='bwd')
         else:
             dZ = dS
         if isinstance(x, K.DMat):

@@ -343,6 +343,20 @@ def scatter_rows(src: DMat, idx: torch.Tensor, out: DMat):
     return out
 
 
+def pack_panels(X: DMat, R: int, W: int, wp: int, out: torch.Tensor):
+    """out[q][i][j] = X[i][q*wp + j]  (row-partitioned -> per-destination feature panels)."""
+    check(_ffi.lib().geogcn_pack_panels_f32(X.n, int(R), X.F, _p(X.t), X.ld, int(W), int(wp), _p(out), _stream()),
+          'pack_panels_f32')
+    return out
+
+
+def unpack_panels(inp: torch.Tensor, R: int, W: int, wp: int, out: DMat):
+    """out[i][q*wp + j] = inp[q][i][j]"""
+    check(_ffi.lib().geogcn_unpack_panels_f32(out.n, int(R), out.F, _p(inp), int(W), int(wp), _p(out.t), out.ld,
+                                              _stream()), 'unpack_panels_f32')
+    return out
+
+
 def adam_step(p, g, m, v, regmask, lr, b1, b2, eps, t, l1=0.0, l2=0.0):
     check(_ffi.lib().geogcn_adam_step_f32(p.numel(), _p(p), _p(g), _p(m), _p(v), _p(regmask), lr, b1, b2, eps,
                                           int(t), float(l1), float(l2), _stream()), 'adam_step_f32')

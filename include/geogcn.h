@@ -158,6 +158,16 @@ int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t
 int geogcn_scatter_rows_f32(int32_t F, const float* src, int64_t lds, const int32_t* idx, int64_t n_idx,
                             float* out, int64_t ldo, void* stream);
 
+/* ---- multi-GPU repartition helpers (no reference counterpart: the reference is single-device) -------
+ * Row-partitioned activations <-> feature-partitioned SpMM operands, exchanged with an all-to-all.
+ * pack:   out[q][i][j] = X[i][q*wp + j]   for q < W, i < R, j < wp   (0 where i >= n_rows or col >= F)
+ * unpack: Y[i][q*wp + j] = in[q][i][j]    for i < n_rows, col < F    (pad columns of Y up to roundup4(F) = 0)
+ * `out` / `in` are dense [W][R][wp] fp32 arrays, wp % 4 == 0.                                        */
+int geogcn_pack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* X, int64_t ldx, int32_t W,
+                           int32_t wp, float* out, void* stream);
+int geogcn_unpack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* in, int32_t W, int32_t wp,
+                             float* Y, int64_t ldy, void* stream);
+
 /* ---- K11/K12: lasagne.updates.adam (+ l1/l2 penalty gradient), gcnmodel.py:383-387,407 ------
  * flat arenas of n floats: t is the step index AFTER increment (1 for the first call).
  *   g' = g + regmask*(l1*sign(p) + 2*l2*p);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2

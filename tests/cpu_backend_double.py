@@ -171,6 +171,27 @@ def gather_rows(X, idx, out=None):
     return torch.from_numpy(_v(X)[idx.numpy()].copy())
 
 
+def pack_panels(X, R, W, wp, out):
+    o = out.numpy().reshape(W, R, wp)
+    o[...] = 0
+    x = _v(X)
+    for q in range(W):
+        c0, c1 = q * wp, min(X.F, (q + 1) * wp)
+        if c1 > c0:
+            o[q, :X.n, :c1 - c0] = x[:, c0:c1]
+    return out
+
+
+def unpack_panels(inp, R, W, wp, out):
+    i = inp.numpy().reshape(W, R, wp)
+    y = _v(out)
+    for q in range(W):
+        c0, c1 = q * wp, min(out.F, (q + 1) * wp)
+        if c1 > c0:
+            y[:, c0:c1] = i[q, :out.n, :c1 - c0]
+    return out
+
+
 def adam_step(p, g, m, v, regmask, lr, b1, b2, eps, t, l1=0.0, l2=0.0):
     P, G, M, V = p.numpy(), g.numpy(), m.numpy(), v.numpy()
     if l1 or l2:

@@ -21,9 +21,10 @@ def main():
     from geographconv_amd.dist import TorchDistComm
     from geographconv_amd.nn import layers as L
     from tests.helpers import load_case, make_clf
-    for name in ('tiny_highway', 'tiny_plain_reg', 'tiny_odd_widths'):
+    for name, exchange in [('tiny_highway', 'a2a'), ('tiny_plain_reg', 'a2a'), ('tiny_odd_widths', 'a2a'),
+                           ('tiny_highway', 'allgather'), ('tiny_odd_widths', 'allgather')]:
         z, A, X, params, cfg = load_case(name)
-        comm = TorchDistComm(cfg['N'], device)
+        comm = TorchDistComm(cfg['N'], device, exchange=exchange)
         clf = make_clf(cfg, params, device=device, comm=comm)
         clf.inject_dropout_mask(z['mask'])
         # force the distributed branches even at world_size 1

@@ -25,6 +25,14 @@ def test_row_partition_covers_rows_once():
         assert np.all(seen == 1)
 
 
+def test_padded_square_csr():
+    A = sps.random(10, 10, density=0.3, format='csr', dtype=np.float32, random_state=1)
+    p = RowPartition(10, 3, 0)                    # R = 4, gathered = 12
+    B = p.padded_square_csr(A)
+    assert B.shape == (12, 12) and B.nnz == A.nnz and (B[:10, :10] != A).nnz == 0
+    assert B[10:].nnz == 0
+
+
 def test_partition_split_indices_and_csr_padding():
     p = RowPartition(10, 2, 1)             # rows 5..9
     idx = np.array([9, 1, 5, 4, 7], dtype=np.int32)
@@ -44,7 +52,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -60,7 +68,7 @@ def _worker(rank, world, port, q):
         out = {}
         for name in ('tiny_highway', 'tiny_plain_reg'):
             z, A, X, params, cfg = load_case(name)
-            comm = TorchDistComm(cfg['N'], torch.device('cpu'))
+            comm = TorchDistComm(cfg['N'], torch.device('cpu'), exchange=exchange)
             clf = make_clf(cfg, params, device=torch.device('cpu'), comm=comm)
             clf.inject_dropout_mask(z['mask'])
             res = []
@@ -77,13 +85,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_matches_single_process_oracle():
+@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3)])
+def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     import torch.multiprocessing as mp
     from tests.helpers import load_case
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=240)
