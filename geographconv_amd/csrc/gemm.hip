@@ -418,6 +418,9 @@ int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float*
         return launch_gemm<BM_, BN_, AT, BT>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
     GEOGCN_T(128, 128)
     GEOGCN_T(128, 160)
+    if constexpr (BT) {
+        GEOGCN_T(96, 160)           // two k-contiguous images of 128+160 rows would not fit twice in 160 KB
+    }
     if constexpr (AT) {
         GEOGCN_T(160, 128)
         GEOGCN_T(160, 160)
@@ -471,7 +474,8 @@ int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
         return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
                                            ws_bytes, st);
     if (transB)
-        return dispatch_tiles<false, true>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+        return dispatch_tiles<false, true>(bn == 160 ? 96 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate,
+                                           ws, ws_bytes, st);
     return dispatch_tiles<false, false>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
 }
 
