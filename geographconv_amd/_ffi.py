@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libgeogcn.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'geogcn.h')
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+GEMM_F32, GEMM_BF16X3, GEMM_BF16 = 0, 1, 2
 
 c_i32, c_i64, c_f32, c_sz, c_ptr = C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_void_p
 c_u64 = C.c_uint64
@@ -31,9 +32,9 @@ SIGNATURES = {
     'geogcn_timer_destroy': (None, [c_ptr]),
     'geogcn_timer_attach_spmm': (c_i32, [c_ptr, c_i32, c_i64]),
     'geogcn_timer_read_ms': (c_i32, [c_ptr, c_ptr, c_i32, C.POINTER(c_i32)]),
-    'geogcn_gemm_workspace_bytes': (c_sz, [c_i32, c_i32, c_i64, c_i64, c_i64]),
+    'geogcn_gemm_workspace_bytes': (c_sz, [c_i32, c_i32, c_i64, c_i64, c_i64, c_i32]),
     'geogcn_gemm_f32': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
-                                c_i64, c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
+                                c_i64, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,

@@ -443,9 +443,11 @@ using namespace geogcn;
 
 extern "C" {
 
-size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K) {
+size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                                   int32_t precision) {
     (void)transB;
-    if (!transA || M <= 0 || N <= 0 || K <= 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!transA) return precision == GEOGCN_GEMM_F32 ? 0 : gemm_bf16_workspace_bytes(precision, N, K);
     const int bm = pick_tile(M), bn = pick_tile(N);
     if (bm == 128 && bn == 128) return splitk_ws_bytes<128, 128>(M, N, K);
     if (bm == 128 && bn == 160) return splitk_ws_bytes<128, 160>(M, N, K);
@@ -455,8 +457,10 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
 
 int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
                     int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
-                    int32_t act, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+                    int32_t act, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, GEOGCN_E_SIZE, "gemm_f32: negative size");
+    GEOGCN_REQUIRE(precision >= GEOGCN_GEMM_F32 && precision <= GEOGCN_GEMM_BF16, GEOGCN_E_ARG,
+                   "gemm_f32: unknown precision %d", precision);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(C && (K == 0 || (A && B)), GEOGCN_E_NULL, "gemm_f32: null pointer");
     GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG, "gemm_f32: unknown act %d", act);
@@ -469,6 +473,8 @@ int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
                    "gemm_f32: operands need 16-byte aligned bases and ld %% 4 == 0 (lda=%lld ldb=%lld)",
                    (long long)lda, (long long)ldb);
     hipStream_t st = (hipStream_t)stream;
+    if (!transA && precision != GEOGCN_GEMM_F32 && K > 0)
+        return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
     const int bn = pick_tile(N);
     if (transA)
         return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,

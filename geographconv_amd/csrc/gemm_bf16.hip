@@ -1,0 +1,323 @@
+// bf16-MFMA GEMM for the activations x weights contractions of the GCN hot path (gfx950):
+//   C[M x N] = act(A[M x K] . B + bias) [+ C]     A fp32 row-major (the N_nodes x hid activations),
+//   B = W (K x N, forward, reference gcnmodel.py:126,149,285) or W given as N x K (dH = dZ . W^T).
+// fp32 in HBM on both sides; the operands are converted on their way into LDS and multiplied with
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulate), 16x the rate of the fp32-input MFMA, in one of two modes:
+//   NS = 1  "bf16"    one bf16 term per operand (BASELINE config 5: bf16 H.W, fp32 accumulate);
+//   NS = 3  "bf16x3"  every fp32 value is split EXACTLY into three bf16 terms (8+8+8 mantissa bits:
+//           a = a1 + a2 + a3 to 2^-24) and the product is formed from the six largest cross terms
+//           a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 (each bf16 x bf16 product is exact in fp32; the
+//           dropped terms are O(2^-24 |a||b|)), i.e. fp32-class accuracy at 6/16 of the fp32-MFMA cost.
+//           With it the contraction stops being MFMA-bound and runs at the HBM streaming rate of A and C.
+// The weights are tiny (<= 600 x 600): a prep kernel writes their bf16 planes [NS][N][Kp] (k-contiguous,
+// zero padded to Kp = roundup32(K)) once per call, so the main kernel never transposes in LDS.
+// Same persistent, flattened-k-pipeline structure as gemm.hip (one LDS image, two blocks per CU).
+#include "common.h"
+
+#include <algorithm>
+
+namespace geogcn {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TPB = 256;
+constexpr int BKH = 32;                  // k per stage = one MFMA depth
+constexpr int ROWB = 80;                 // bytes per LDS row: 32 bf16 (64 B) + 16 B pad
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// round-to-nearest-even fp32 -> bf16 (upper 16 bits); inputs are finite on this path
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    const uint32_t u = f2u(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x -> NS bf16 terms; the residuals are exact in fp32 (Dekker-style splitting)
+template <int NS>
+__device__ __forceinline__ void split_bf16(float x, uint32_t (&t)[NS]) {
+    t[0] = bf16_rne(x);
+    if constexpr (NS > 1) {
+        const float r1 = x - u2f(t[0] << 16);
+        t[1] = bf16_rne(r1);
+        if constexpr (NS > 2) {
+            const float r2 = r1 - u2f(t[1] << 16);
+            t[2] = bf16_rne(r2);
+        }
+    }
+}
+
+// ---- weights -> bf16 planes [NS][N][Kp], k-contiguous -------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(TPB) void prep_b_planes_kernel(const float* __restrict__ W, int64_t ldw, int K, int N,
+                                                            int Kp, int b_is_nk, unsigned short* __restrict__ out) {
+    const int64_t total = (int64_t)N * Kp;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int n = (int)(e / Kp), k = (int)(e - (int64_t)n * Kp);
+        float x = 0.f;
+        if (k < K) x = b_is_nk ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n];
+        uint32_t t[NS];
+        split_bf16<NS>(x, t);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) out[(int64_t)p * total + e] = (unsigned short)t[p];
+    }
+}
+
+struct Bf16Args {
+    int64_t M, N, K;
+    const float* A; int64_t lda;
+    const unsigned short* Bp;           // planes [NS][N][Kp]
+    int Kp;
+    float* C; int64_t ldc;
+    const float* bias;
+    int accumulate;
+    int n_mt, n_nt;
+};
+
+template <int BM, int BN, int NS>
+struct BCfg {
+    static constexpr int kARows = BM, kBRows = BN;
+    static constexpr int kABytes = NS * BM * ROWB;
+    static constexpr int kBBytes = NS * BN * ROWB;
+    static constexpr int kStageBytes = kABytes + kBBytes;
+    // double buffered (one barrier per stage) when two blocks per CU still fit, else one image + two barriers
+    static constexpr bool kDouble = 4 * kStageBytes <= 160 * 1024;
+    static constexpr int kLdsBytes = (kDouble ? 2 : 1) * kStageBytes;
+    static constexpr int MR = BM / 32, NR = BN / 32;
+    static constexpr int kAIters = BM / 32;                 // float4 per thread per stage (8 f4 per row)
+    static constexpr int kBVec = NS * BN * 4;               // uint4 per stage (4 per row per plane)
+    static constexpr int kBIters = (kBVec + TPB - 1) / TPB;
+};
+
+template <int BM, int BN, int NS, int ACT>
+__global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
+    using Cfg = BCfg<BM, BN, NS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int p = blockIdx.x, G = gridDim.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = a.Kp / BKH;
+
+    f32x4 acc[Cfg::MR][Cfg::NR];
+#pragma unroll
+    for (int i = 0; i < Cfg::MR; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // XCD-aware persistent tile walk (as gemm.hip): the blocks of one XCD share the A panel through L2
+    const int x = p % kNumXCD, q = p / kNumXCD, Q = G / kNumXCD;
+    auto decode = [&](int j, int64_t& m0, int64_t& n0) -> bool {
+        const int64_t u = (int64_t)q + (int64_t)j * Q;
+        const int nt = (int)(u % a.n_nt);
+        const int mt = (int)(u / a.n_nt) * kNumXCD + x;
+        m0 = (int64_t)mt * BM;
+        n0 = (int64_t)nt * BN;
+        return mt < a.n_mt;
+    };
+
+    float4 ra[Cfg::kAIters];
+    uint4 rb[Cfg::kBIters];
+    const int a_f4 = tid & 7, a_rr = tid >> 3;
+    auto gload = [&](int64_t m0, int64_t n0, int kt) {
+        const int64_t k0 = (int64_t)kt * BKH + a_f4 * 4;
+        const int64_t klim = (a.K + 3) & ~(int64_t)3;          // pad columns of A are zero (geogcn.h)
+#pragma unroll
+        for (int i = 0; i < Cfg::kAIters; ++i) {
+            const int64_t row = m0 + a_rr + 32 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.M && k0 < klim) v = *reinterpret_cast<const float4*>(a.A + row * a.lda + k0);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::kBIters; ++i) {
+            const int e = tid + TPB * i;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (e < Cfg::kBVec) {
+                const int pl = e / (BN * 4), r = (e / 4) % BN, c = e & 3;
+                const int64_t n = n0 + r;
+                if (n < a.N)
+                    v = *reinterpret_cast<const uint4*>(a.Bp + ((int64_t)pl * a.N + n) * a.Kp + (int64_t)kt * BKH + c * 8);
+            }
+            rb[i] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned char* As = smem_raw + (Cfg::kDouble ? buf : 0) * Cfg::kStageBytes;
+        unsigned char* Bs = As + Cfg::kABytes;
+#pragma unroll
+        for (int i = 0; i < Cfg::kAIters; ++i) {
+            const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            uint32_t t[4][NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16<NS>(xs[e], t[e]);
+            const int row = a_rr + 32 * i;
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) {
+                uint2 w;
+                w.x = t[0][pl] | (t[1][pl] << 16);
+                w.y = t[2][pl] | (t[3][pl] << 16);
+                *reinterpret_cast<uint2*>(As + (pl * BM + row) * ROWB + a_f4 * 8) = w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::kBIters; ++i) {
+            const int e = tid + TPB * i;
+            if (e < Cfg::kBVec) {
+                const int pl = e / (BN * 4), r = (e / 4) % BN, c = e & 3;
+                *reinterpret_cast<uint4*>(Bs + (pl * BN + r) * ROWB + c * 16) = rb[i];
+            }
+        }
+    };
+
+    int cj = 0, ckt = 0, lj = 0, lkt = 0;
+    int64_t cm0, cn0, lm0, ln0;
+    if (!decode(0, cm0, cn0)) return;
+    lm0 = cm0; ln0 = cn0;
+    bool lvalid = true;
+    gload(lm0, ln0, 0);
+    sstore(0);
+    if (++lkt == nk) { lvalid = decode(++lj, lm0, ln0); lkt = 0; }
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+        if (lvalid) gload(lm0, ln0, lkt);
+        const unsigned char* As = smem_raw + (Cfg::kDouble ? cur : 0) * Cfg::kStageBytes;
+        const unsigned char* Bs = As + Cfg::kABytes;
+        // ---- MFMAs on the resident stage ----
+        // A fragments of the wave's 4 row tiles stay in registers; B fragments are read one column
+        // tile at a time (keeps the live set under 256 VGPRs without spills)
+        bf16x8 af[Cfg::MR][NS];
+#pragma unroll
+        for (int i = 0; i < Cfg::MR; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + wm * (BM / 2) + i * 16 + li) * ROWB + lg * 16);
+#pragma unroll
+        for (int j = 0; j < Cfg::NR; ++j) {
+            bf16x8 bf[NS];
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                bf[pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + wn * (BN / 2) + j * 16 + li) * ROWB + lg * 16);
+#pragma unroll
+            for (int i = 0; i < Cfg::MR; ++i) {
+                f32x4 c = acc[i][j];
+                if constexpr (NS == 3) {        // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[1], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        }
+        if (ckt == nk - 1) {
+            float bcol[Cfg::NR];
+#pragma unroll
+            for (int j = 0; j < Cfg::NR; ++j) {
+                const int64_t col = cn0 + wn * (BN / 2) + j * 16 + li;
+                bcol[j] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < Cfg::MR; ++i) {
+                const int64_t row0 = cm0 + wm * (BM / 2) + i * 16 + lg * 4;
+                float oldv[Cfg::NR][4];
+                if (a.accumulate) {
+#pragma unroll
+                    for (int j = 0; j < Cfg::NR; ++j) {
+                        const int64_t col = cn0 + wn * (BN / 2) + j * 16 + li;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            oldv[j][r] = (row0 + r < a.M && col < a.N) ? a.C[(row0 + r) * a.ldc + col] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < Cfg::NR; ++j) {
+                    const int64_t col = cn0 + wn * (BN / 2) + j * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = apply_act<ACT>(acc[i][j][r] + bcol[j]);
+                        if (a.accumulate) v += oldv[j][r];
+                        if (row0 + r < a.M && col < a.N) a.C[(row0 + r) * a.ldc + col] = v;
+                    }
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if constexpr (!Cfg::kDouble) __syncthreads();     // single image: everybody done reading first
+        if (lvalid) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        if (++ckt == nk) {
+            ckt = 0;
+            if (!decode(++cj, cm0, cn0)) break;
+        }
+        if (lvalid && ++lkt == nk) { lvalid = decode(++lj, lm0, ln0); lkt = 0; }
+    }
+}
+
+template <int BM, int BN, int NS>
+int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
+    using Cfg = BCfg<BM, BN, NS>;
+    const int per_cu = (2 * Cfg::kLdsBytes <= 160 * 1024) ? 2 : 1;
+    const int64_t tiles = (int64_t)a.n_mt * a.n_nt;
+    const int G = (int)std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(tiles, kNumXCD) * kNumXCD);
+#define GEOGCN_L(ACT)                                                                                          \
+    do {                                                                                                        \
+        auto kern = gemm_bf16_kernel<BM, BN, NS, ACT>;                                                          \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                           Cfg::kLdsBytes));                                                    \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), Cfg::kLdsBytes, st, a);                          \
+        GEOGCN_LAUNCH_CHECK("gemm_bf16_kernel");                                                                \
+    } while (0)
+    if (act == GEOGCN_ACT_TANH) GEOGCN_L(GEOGCN_ACT_TANH);
+    else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_L(GEOGCN_ACT_SIGMOID);
+    else GEOGCN_L(GEOGCN_ACT_NONE);
+#undef GEOGCN_L
+    return 0;
+}
+
+}  // namespace
+
+size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
+    const int ns = (precision == GEOGCN_GEMM_BF16X3) ? 3 : 1;
+    const int64_t Kp = cdiv(K, BKH) * BKH;
+    return (size_t)ns * (size_t)N * (size_t)Kp * sizeof(unsigned short);
+}
+
+// called by geogcn_gemm_f32 for transA == 0 and precision != F32
+int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+    const int ns = (precision == GEOGCN_GEMM_BF16X3) ? 3 : 1;
+    const int Kp = (int)(cdiv(K, BKH) * BKH);
+    const size_t need = gemm_bf16_workspace_bytes(precision, N, K);
+    GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "gemm_f32(bf16): workspace too small (%zu < %zu)",
+                   ws_bytes, need);
+    unsigned short* planes = (unsigned short*)ws;
+    const unsigned pgrid = (unsigned)std::min<int64_t>(cdiv((int64_t)N * Kp, TPB), 1024);
+    if (ns == 3)
+        hipLaunchKernelGGL((prep_b_planes_kernel<3>), dim3(pgrid), dim3(TPB), 0, st, B, ldb, (int)K, (int)N, Kp, transB, planes);
+    else
+        hipLaunchKernelGGL((prep_b_planes_kernel<1>), dim3(pgrid), dim3(TPB), 0, st, B, ldb, (int)K, (int)N, Kp, transB, planes);
+    GEOGCN_LAUNCH_CHECK("prep_b_planes_kernel");
+    const int bn = (cdiv(N, 160) * 160 < cdiv(N, 128) * 128) ? 160 : 128;
+    Bf16Args a{M, N, K, A, lda, planes, Kp, C, ldc, bias, accumulate, (int)cdiv(M, 128), (int)cdiv(N, bn)};
+    if (ns == 3) {
+        if (bn == 160) return launch_bf16<128, 160, 3>(a, act, st);
+        return launch_bf16<128, 128, 3>(a, act, st);
+    }
+    if (bn == 160) return launch_bf16<128, 160, 1>(a, act, st);
+    return launch_bf16<128, 128, 1>(a, act, st);
+}
+
+}  // namespace geogcn

@@ -6,6 +6,7 @@ a GPU is missing the call raises (no eager / CPU fallback)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sps
@@ -200,9 +201,14 @@ def spmm(A: CSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_N
 
 _gemm_ws = {}
 
+# How the activation x weight products are formed (include/geogcn.h GEOGCN_GEMM_*): 'f32' = exact fp32
+# MFMA, 'bf16x3' = three-term bf16 split (fp32-class accuracy, HBM-bound), 'bf16' = BASELINE config 5.
+GEMM_PRECISIONS = {'f32': _ffi.GEMM_F32, 'bf16x3': _ffi.GEMM_BF16X3, 'bf16': _ffi.GEMM_BF16}
+GEMM_PRECISION = os.environ.get('GEOGCN_GEMM_PRECISION', 'f32')
+
 
 def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=None, act=ACT_NONE,
-         accumulate=False):
+         accumulate=False, precision=None):
     """out = act(op(A) . op(B) + bias) [+ out]  -- T.dot / Gemm (reference gcnmodel.py:126,149,285)."""
     lib = _ffi.lib()
     M = A.F if transA else A.n
@@ -217,10 +223,11 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     ws = _gemm_ws.get(dev)
     if ws is None:
         ws = _gemm_ws[dev] = Workspace(dev)
-    need = lib.geogcn_gemm_workspace_bytes(int(transA), int(transB), M, N, K)
+    prec = GEMM_PRECISIONS[precision or GEMM_PRECISION]
+    need = lib.geogcn_gemm_workspace_bytes(int(transA), int(transB), M, N, K, prec)
     w = ws.get(need)
     check(lib.geogcn_gemm_f32(int(transA), int(transB), M, N, K, _p(A.t), A.ld, _p(B.t), B.ld, _p(out.t),
-                              out.ld, _p(bias), act, int(accumulate), _p(w), w.numel(), _stream()),
+                              out.ld, _p(bias), act, int(accumulate), prec, _p(w), w.numel(), _stream()),
           'gemm_f32')
     return out
 

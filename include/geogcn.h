@@ -91,12 +91,24 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  * transposed B) is not a multiple of 4, its pad columns up to the next multiple of 4 MUST be zero
  * (the convention every producer in this library keeps).
  * transA=1 reduces over the long dimension: it runs split-K into `ws` (see
- * geogcn_gemm_workspace_bytes) and combines the slabs in fixed order (deterministic).         */
-size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K);
+ * geogcn_gemm_workspace_bytes) and combines the slabs in fixed order (deterministic).
+ *
+ * `precision` selects how the products are formed (inputs, outputs and accumulation are fp32 in all):
+ *   GEOGCN_GEMM_F32    v_mfma_f32_16x16x4_f32: an exact fp32 fma chain (the reference's sgemm class);
+ *   GEOGCN_GEMM_BF16X3 each fp32 operand split exactly into three bf16 terms, six bf16 MFMA cross terms
+ *                      per product: fp32-class accuracy (dropped terms O(2^-24 |a||b|)), 2.7x fewer MFMA
+ *                      cycles -- the contraction becomes HBM-bound;
+ *   GEOGCN_GEMM_BF16   one bf16 term per operand (BASELINE config 5: "bf16 H.W on MFMA, fp32 accumulate").
+ * The bf16 modes apply to transA = 0; transA = 1 (dW, reduction over the node dimension) always runs F32. */
+#define GEOGCN_GEMM_F32    0
+#define GEOGCN_GEMM_BF16X3 1
+#define GEOGCN_GEMM_BF16   2
+size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                                   int32_t precision);
 int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
                     const float* A, int64_t lda, const float* B, int64_t ldb,
                     float* C, int64_t ldc, const float* bias, int32_t act, int32_t accumulate,
-                    void* ws, size_t ws_bytes, void* stream);
+                    int32_t precision, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */

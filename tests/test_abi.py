@@ -37,12 +37,12 @@ def test_library_loads_and_reports_version(built):
 def test_argument_errors_need_no_gpu(built):
     lib = _ffi.lib()
     # negative size is rejected before any HIP call
-    rc = lib.geogcn_gemm_f32(0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None)
+    rc = lib.geogcn_gemm_f32(0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 0, None, 0, None)
     assert rc == -2 and b'negative' in lib.geogcn_last_error()
     rc = lib.geogcn_spmm_csr_f32(None, 4, 4, 1, None, None, None, None, 4, None, 4, 4, None, 0, None, 0, None)
     assert rc == -1
-    assert lib.geogcn_gemm_workspace_bytes(0, 0, 1000, 300, 300) == 0
-    assert lib.geogcn_gemm_workspace_bytes(1, 0, 300, 300, 440000) > 0
+    assert lib.geogcn_gemm_workspace_bytes(0, 0, 1000, 300, 300, 0) == 0
+    assert lib.geogcn_gemm_workspace_bytes(1, 0, 300, 300, 440000, 0) > 0
     assert lib.geogcn_colsum_workspace_bytes(440000, 300) > 0
 
 

@@ -169,6 +169,35 @@ def test_gemm_nn_nt_match_oracle(dev, M, N, K):
     assert np.all(np.abs(dC.numpy() - (ref + C0)) <= tol + 1e-6)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 300, 300), (777, 129, 300), (2500, 256, 300), (513, 600, 300), (130, 300, 129)])
+def test_gemm_bf16_modes(dev, M, N, K):
+    """bf16x3: three-term split, fp32-class accuracy (same envelope as the exact fp32 MFMA path);
+    bf16: single term, the accuracy of BASELINE config 5 (relative 2^-8 per operand)."""
+    from geographconv_amd import ops
+    A = _rand((M, K), 1)
+    Bnn = _rand((K, N), 2)
+    bias = _rand((N,), 3)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(Bnn, dev)
+    dBt = ops.DMat.from_numpy(np.ascontiguousarray(Bnn.T), dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(N) - N))).to(dev)
+    ref = A.astype(np.float64) @ Bnn.astype(np.float64)
+    mag = np.abs(A) @ np.abs(Bnn)
+    for kw in (dict(), dict(transB=True)):
+        Bop = dBt if kw else dB
+        got = ops.gemm(dA, Bop, precision='bf16x3', **kw).numpy()
+        assert np.all(np.abs(got - ref) <= 2e-6 * mag + 1e-6), np.abs(got - ref).max()
+        got1 = ops.gemm(dA, Bop, precision='bf16', **kw).numpy()
+        assert np.all(np.abs(got1 - ref) <= 2 ** -7 * mag + 1e-6)
+        assert np.abs(got1 - ref).max() > 1e-4                      # it really is the coarse mode
+    got = ops.gemm(dA, dB, bias=db, act=ops.ACT_TANH, precision='bf16x3').numpy()
+    assert np.all(np.abs(got - np.tanh(ref + bias)) <= 2e-6 * mag + 1e-6)
+    C0 = _rand((M, N), 4)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm(dA, dB, out=dC, accumulate=True, precision='bf16x3')
+    assert np.all(np.abs(dC.numpy() - (ref + C0)) <= 2e-6 * mag + 2e-6)
+    assert np.array_equal(ops.gemm(dA, dB, precision='bf16x3').numpy(), ops.gemm(dA, dB, precision='bf16x3').numpy())
+
+
 @pytest.mark.parametrize("R,M,N", [(5000, 300, 300), (4097, 300, 129), (333, 300, 600), (20000, 64, 8)])
 def test_gemm_tn_splitk_matches_oracle_and_is_deterministic(dev, R, M, N):
     from geographconv_amd import ops
@@ -200,10 +229,10 @@ def test_gemm_rejects_bad_arguments(dev):
     from geographconv_amd import _ffi, ops
     lib = _ffi.lib()
     A = ops.DMat.from_numpy(_rand((8, 8), 1), dev)
-    rc = lib.geogcn_gemm_f32(1, 1, 8, 8, 8, ops._p(A.t), 8, ops._p(A.t), 8, ops._p(A.t), 8, None, 0, 0, None, 0,
+    rc = lib.geogcn_gemm_f32(1, 1, 8, 8, 8, ops._p(A.t), 8, ops._p(A.t), 8, ops._p(A.t), 8, None, 0, 0, 0, None, 0,
                              ops._stream())
     assert rc == -4
-    rc = lib.geogcn_gemm_f32(0, 0, 8, 8, 8, ops._p(A.t), 6, ops._p(A.t), 8, ops._p(A.t), 8, None, 0, 0, None, 0,
+    rc = lib.geogcn_gemm_f32(0, 0, 8, 8, 8, ops._p(A.t), 6, ops._p(A.t), 8, ops._p(A.t), 8, None, 0, 0, 0, None, 0,
                              ops._stream())
     assert rc in (-2, -3)
 

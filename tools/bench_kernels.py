@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--long', type=int, default=256)
     ap.add_argument('--chunk', type=int, default=128)
+    ap.add_argument('--precision', default='f32')
     ap.add_argument('--only', default='all', choices=['all', 'gemm', 'spmm', 'stream'])
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -77,12 +78,12 @@ def main():
     for Fo in ((300, 600, s.C) if do('gemm') else ()):
         W = ops.DMat.from_numpy((rng.randn(300, Fo) * 0.05).astype(np.float32), dev)
         Z = ops.DMat(N, Fo, dev)
-        med, mn = timeit(lambda: ops.gemm(H, W, out=Z), args.reps)
+        med, mn = timeit(lambda: ops.gemm(H, W, out=Z, precision=args.precision), args.reps)
         fl = 2.0 * N * 300 * Fo
         res['gemm_nn_%d' % Fo] = {'ms': med, 'TFLOPs': fl / med / 1e9}
         print('gemm NN N x300x%d: %.3f ms  %.1f TF' % (Fo, med, fl / med / 1e9), flush=True)
         dH = ops.DMat(N, 300, dev)
-        med, mn = timeit(lambda: ops.gemm(Z, W, out=dH, transB=True), args.reps)
+        med, mn = timeit(lambda: ops.gemm(Z, W, out=dH, transB=True, precision=args.precision), args.reps)
         res['gemm_nt_%d' % Fo] = {'ms': med, 'TFLOPs': fl / med / 1e9}
         print('gemm NT (dH) %d: %.3f ms  %.1f TF' % (Fo, med, fl / med / 1e9), flush=True)
         dW = ops.DMat(300, Fo, dev)
