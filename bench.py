@@ -81,6 +81,8 @@ def main():
     ap.add_argument('--shape', default='twus', choices=['twus', 'cmu'])
     ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
     ap.add_argument('--dropout', type=float, default=0.5)
+    ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
+                    help='f32 = exact fp32 MFMA (the headline configuration)')
     ap.add_argument('--cpu-sample', default='step', choices=['step', 'layer', 'none'])
     args = ap.parse_args()
 
@@ -114,7 +116,8 @@ def main():
         from geographconv_amd.dist import TorchDistComm
         comm = TorchDistComm(N, device)
 
-    clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm)
+    clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm,
+                    gemm_precision=args.gemm_precision)
     clf.build_model(A, seed=77)
     y_tr, y_dev = Y[tr], Y[dev]
 
@@ -175,11 +178,13 @@ def main():
         out = {
             "metric": "GCN-layer fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.gemm_precision != "bf16" else "bf16", "data": "synthetic",
             "config": {"workload": "TwitterUS-shape synthetic power-law CSR (BASELINE configs[2]): N=%d, nnz(A_hat)=%d, "
                                    "X %dx%d nnz=%d, C=%d; %s highway GCN, dropout %.2f, Adam; full-graph f_train step"
                                    % (N, nnz, N, X.shape[1], X.nnz, C, 'x'.join(map(str, args.hid)), args.dropout),
                        "edges_per_step": n_conv * nnz, "parallelism": "rows%d" % world if world > 1 else "single",
+                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
+                                "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
                        "train_loss_last": float(last[0])},
             "roofline": roofline,
         }

@@ -179,15 +179,17 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int jn = 0; jn < Cfg::NR; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[Cfg::kAIters], rb[Cfg::kBIters];
-    auto gload = [&](const TileCoord& t, int kt) {
+    // two register sets: while stage s is multiplied, stage s+1 waits in one set to be written to LDS and
+    // the global loads of stage s+2 land in the other (two stages of HBM latency tolerance)
+    float4 ra0[Cfg::kAIters], rb0[Cfg::kBIters], ra1[Cfg::kAIters], rb1[Cfg::kBIters];
+    auto gload = [&](float4 (&ra)[Cfg::kAIters], float4 (&rb)[Cfg::kBIters], const TileCoord& t, int kt) {
         const int64_t k0 = t.kbeg + (int64_t)kt * BK;
         if constexpr (AT) gload_kstrided<BM>(ra, a.A, a.lda, t.m0, a.M, k0, t.kend);
         else gload_kcontig<BM>(ra, a.A, a.lda, t.m0, a.M, k0, t.kend);
         if constexpr (BT) gload_kcontig<BN>(rb, a.B, a.ldb, t.n0, a.N, k0, t.kend);
         else gload_kstrided<BN>(rb, a.B, a.ldb, t.n0, a.N, k0, t.kend);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const float4 (&ra)[Cfg::kAIters], const float4 (&rb)[Cfg::kBIters]) {
         float* As = smem + buf * Cfg::kStageFloats;
         float* Bs = As + Cfg::kAFloats;
         if constexpr (AT) sstore_kstrided<BM>(As, ra);
@@ -201,14 +203,22 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
     if (!ct.valid) return;
     int lj = 0, lkt = 0;                     // load cursor
     TileCoord lt = ct;
-    gload(lt, 0);
-    sstore(0);
-    if (++lkt == lt.nk) { lt = decode_tile(a, BM, BN, p, G, ++lj); lkt = 0; }
+    auto advance_load = [&]() {
+        if (++lkt == lt.nk) { lt = decode_tile(a, BM, BN, p, G, ++lj); lkt = 0; }
+    };
+    gload(ra0, rb0, lt, 0);
+    sstore(0, ra0, rb0);
+    advance_load();
+    bool pending = lt.valid;                 // stage s+1 sits in a register set, not yet in LDS
+    if (pending) { gload(ra1, rb1, lt, lkt); advance_load(); }
     __syncthreads();
     int cur = 0;
-    while (true) {
-        const bool have_next = lt.valid;
-        if (have_next) gload(lt, lkt);
+    bool running = true;
+    // one pipeline step; (la, lb) = set to load stage s+2 into, (sa, sb) = set holding stage s+1
+    auto step = [&](float4 (&la)[Cfg::kAIters], float4 (&lb)[Cfg::kBIters], const float4 (&sa)[Cfg::kAIters],
+                    const float4 (&sb)[Cfg::kBIters]) {
+        const bool have_load = lt.valid;
+        if (have_load) gload(la, lb, lt, lkt);
         const float* As = smem + cur * Cfg::kStageFloats;
         const float* Bs = As + Cfg::kAFloats;
         const int64_t k_stage = ct.kbeg + (int64_t)ckt * BK;
@@ -292,15 +302,21 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
                 }
             }
         }
-        if (have_next) sstore(cur ^ 1);
+        if (pending) sstore(cur ^ 1, sa, sb);
         __syncthreads();
         cur ^= 1;
         if (++ckt == ct.nk) {
             ct = decode_tile(a, BM, BN, p, G, ++cj);
             ckt = 0;
-            if (!ct.valid) break;
+            if (!ct.valid) running = false;
         }
-        if (have_next && ++lkt == lt.nk) { lt = decode_tile(a, BM, BN, p, G, ++lj); lkt = 0; }
+        pending = have_load;
+        if (have_load) advance_load();
+    };
+    while (running) {
+        step(ra0, rb0, ra1, rb1);            // set 1 holds s+1, set 0 is free for s+2
+        if (!running) break;
+        step(ra1, rb1, ra0, rb0);
     }
 }
 

@@ -152,7 +152,8 @@ def main(data, args, **kwargs):
         comm = TorchDistComm(X.shape[0], device)
     rank0 = comm is None or comm.rank == 0
     clf = GraphConv(input_size=input_size, output_size=output_size, hid_size_list=hidden_size, regul_coef=regul,
-                    drop_out=dropout, batchnorm=args.batchnorm, highway=model_args.highway, device=device, comm=comm)
+                    drop_out=dropout, batchnorm=args.batchnorm, highway=model_args.highway, device=device, comm=comm,
+                    gemm_precision=getattr(args, 'gemm_precision', None))
     clf.build_model(A, use_text=args.notxt, use_labels=args.lp, seed=model_args.seed)
 
     results = []
@@ -223,6 +224,8 @@ def parse_args(argv):
     parser.add_argument('-lblfraction', nargs='+', type=float, help="fraction of labelled data used for training e.g. 0.01 0.1", default=[1.0])
     # additions
     parser.add_argument('--synthetic', choices=['cmu', 'twus'], default=None, help='use the pinned synthetic graph instead of dump.pkl')
+    parser.add_argument('--gemm-precision', choices=['f32', 'bf16x3', 'bf16'], default=None,
+                        help="how H.W products are formed: f32 = exact fp32 MFMA (default), bf16x3 = 3-term bf16 split, bf16 = BASELINE config 5")
     parser.add_argument('--epochs', type=int, default=10000, help='max epochs (reference hard-codes 10000, gcnmain.py:221)')
     return parser.parse_args(argv)
 

@@ -71,7 +71,7 @@ class SparseConvolutionDenseLayer2(DenseLayer):
     def _uses_graph(self, kwargs):
         return kwargs.get('A') is not None
 
-    def _matmul(self, input, out):
+    def _matmul(self, input, out, precision=None):
         return backend.active().spmm(input.fwd, self.W.data, out=out)
 
 
@@ -105,7 +105,7 @@ class SparseConvolutionDenseLayer(_BoundA):
         if not _is_sparse_operand(input):
             raise ValueError("Input for this layer must be sparse")
 
-    def _matmul(self, input, out):
+    def _matmul(self, input, out, precision=None):
         return backend.active().spmm(input.fwd, self.W.data, out=out)
 
 
@@ -240,7 +240,7 @@ class GraphConv():
     '''
 
     def __init__(self, input_size, output_size, hid_size_list, regul_coef, drop_out, dtype='float32',
-                 batchnorm=False, highway=True, device=None, comm=None):
+                 batchnorm=False, highway=True, device=None, comm=None, gemm_precision=None):
         self.input_size = int(input_size)
         self.output_size = int(output_size)
         self.hid_size_list = list(hid_size_list)
@@ -255,6 +255,8 @@ class GraphConv():
         self.highway = highway
         self.device = device
         self.comm = comm
+        # how H.W products are formed: None/'f32' exact fp32 MFMA (default), 'bf16x3', 'bf16' (BASELINE config 5)
+        self.gemm_precision = gemm_precision
         self._graph_cache = {}
         self._idx_cache = {}
         self._injected_mask = None
@@ -380,7 +382,8 @@ class GraphConv():
                 m = m[comm.part.r0:comm.part.r1]
             mask = torch.from_numpy(np.ascontiguousarray(m)).to(self.device)
         tape = {}
-        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if self._dist(comm) else None)
+        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if self._dist(comm) else None,
+                  gemm_precision=self.gemm_precision)
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
         sc = self._scal
@@ -417,7 +420,8 @@ class GraphConv():
         import torch
         g = self._device_graph(X, A)
         comm = g['comm']
-        kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None)
+        kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None,
+                  gemm_precision=self.gemm_precision)
         tape = {}
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
@@ -435,7 +439,8 @@ class GraphConv():
         def f_gate(X, A):
             g = self._device_graph(X, A)
             comm = g['comm']
-            kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None)
+            kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None,
+                      gemm_precision=self.gemm_precision)
             T = L.get_output(layer, {self.l_in: g['X']}, **kw)
             return T.numpy()
         return f_gate

@@ -237,8 +237,8 @@ class DenseLayer(Layer):
         if not isinstance(input, K.DMat):
             raise ValueError("Input for this layer must be dense")
 
-    def _matmul(self, input, out):
-        return backend.active().gemm(input, self.W.data, out=out)
+    def _matmul(self, input, out, precision=None):
+        return backend.active().gemm(input, self.W.data, out=out, precision=precision)
 
     def _fused_act(self):
         if self.nonlinearity.act is None and self.nonlinearity is not _nl.softmax:
@@ -253,10 +253,11 @@ class DenseLayer(Layer):
         bias = None if self.b is None else self.b.data
         act = self._fused_act()
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
+        prec = kwargs.get('gemm_precision')     # None = backend default ('f32': exact fp32 MFMA)
         saved = {'x': input}
         if A is None:
             if isinstance(input, K.DMat):
-                y = K.gemm(input, self.W.data, bias=bias, act=act)        # bias + act fused in the epilogue
+                y = K.gemm(input, self.W.data, bias=bias, act=act, precision=prec)   # bias + act fused
             else:
                 y = K.spmm(input.fwd, self.W.data, bias=bias, act=act)    # sparse input: X.W0
         else:
@@ -265,11 +266,11 @@ class DenseLayer(Layer):
                 # Z is gathered row-wise by the SpMM: give it the line-aligned pitch
                 zf = K.DMat.empty(input.n if isinstance(input, K.DMat) else input.shape[0], self.num_units,
                                   y_device(input), ld=K.gather_ld(self.num_units))
-                self._matmul(input, zf)
+                self._matmul(input, zf, prec)
                 y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
                 z = comm.matmul_target(self.num_units, tag='fwd')
-                self._matmul(input, z)
+                self._matmul(input, z, prec)
                 y = comm.graph_spmm(A.fwd, z, bias, act, self.num_units, tag='fwd')
         if self.nonlinearity is _nl.softmax:
             import torch
@@ -313,9 +314,10 @@ class DenseLayer(Layer):
             K.gemm(x, dZ, out=self.W.grad, transA=True)                    # dW = H^T . dZ
             if not need_input_grad:
                 return [None]
+            prec = kwargs.get('gemm_precision')
             if into[0] is not None:
-                return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True)]
-            return [K.gemm(dZ, self.W.data, transB=True)]                  # dH = dZ . W^T
+                return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True, precision=prec)]
+            return [K.gemm(dZ, self.W.data, transB=True, precision=prec)]  # dH = dZ . W^T
         K.spmm_t(x, dZ, out=self.W.grad)                                   # dW0 = X^T . dS0
         return [None]
 

@@ -62,7 +62,7 @@ def spmm_t(x, G, out=None):
     return spmm(x.bwd, G, out=out)
 
 
-def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False):
+def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None):
     a = _v(A).T if transA else _v(A)
     b = _v(B).T if transB else _v(B)
     r = a @ b
