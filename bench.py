@@ -133,7 +133,11 @@ def main():
         step()
     # roofline leg: library-side hipEvent pairs around the F=hid SpMM row kernel, on the launch stream
     timer = ops.SpmmTimer(capacity=max(16, 8 * args.steps))
-    timer.attach(only_F=args.hid[-1], only_nnz=clf._device_graph(X, A)['A'].fwd.nnz)
+    # the dense operand of the timed SpMM: F = hid at one GPU; one feature panel per rank under the a2a scheme
+    F_spmm = args.hid[-1]
+    if comm is not None and comm.exchange == 'a2a':
+        F_spmm = comm.panel_width(args.hid[-1])
+    timer.attach(only_F=F_spmm, only_nnz=clf._device_graph(X, A)['A'].fwd.nnz)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -156,21 +160,22 @@ def main():
         csr = g['A'].fwd
         rp = csr.rowptr_host
         deg = np.diff(rp)
-        F = args.hid[-1]
+        F = F_spmm
         # one launch of spmm_rows_kernel covers every stored edge of the local row block (short rows with
         # the fused epilogue + the 128-nonzero chunks of the long rows): algorithmic bytes = SURVEY.md §8d
         alg = spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F)
         e_short = int(csr.nnz)
-        avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
+        avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = alg / (avg_ms * 1e-3) / 1e9 if kern_ms else None
-        traffic = None
+        traffic = None            # PMC passes are collected at 1 GPU, F = hid (profiles/pmc_spmm_latest.json)
         pmc_file = os.path.join(ROOT, 'profiles', 'pmc_spmm_latest.json')
-        if os.path.exists(pmc_file):
+        if os.path.exists(pmc_file) and world == 1 and F == 300:
             try:
                 traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> (A_hat.Z, F=%d)" % ((F + 63) // 64, F),
+        roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> (A_hat.Z, F=%d%s)" % (
+                        (F + 63) // 64, F, "" if world == 1 else ", rank 0's feature panel of all rows"),
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": len(kern_ms),
