@@ -102,9 +102,13 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     comm = None
-    if world > 1:
+    force_dist = os.environ.get('GEOGCN_BENCH_FORCE_DIST') == '1'      # exercise the partitioned path at world 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
 
     t0 = time.time()
@@ -112,13 +116,14 @@ def main():
     N, nnz = A.shape[0], int(A.nnz)
     if rank == 0:
         log('[bench] %s graph generated in %.1fs: N=%d nnz(A)=%d nnz(X)=%d' % (args.shape, time.time() - t0, N, nnz, X.nnz))
-    if world > 1:
+    if world > 1 or force_dist:
         from geographconv_amd.dist import TorchDistComm
         comm = TorchDistComm(N, device)
 
     clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm,
                     gemm_precision=args.gemm_precision)
     clf.build_model(A, seed=77)
+    clf._force_dist = force_dist
     y_tr, y_dev = Y[tr], Y[dev]
 
     def step():
@@ -198,8 +203,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample)
         else:
             out["cpu_baseline"] = None
+        # RCCL prints a version banner through C stdio; flush it so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -6,7 +6,7 @@ parameters are replicated; parameter gradients and the four loss/accuracy sums a
 once per step over a flat arena.  The only per-layer exchange is around the graph convolution
 S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two interchangeable schemes:
 
-``a2a`` (default) -- REPARTITION BY FEATURES.  Every rank keeps the whole (88 MB) A_hat.  The
+``a2a`` (default from 3 ranks) -- REPARTITION BY FEATURES.  Every rank keeps the whole (88 MB) A_hat.  The
     row-partitioned Z (n_local x F) is packed into `world` feature panels of width wp = ceil4(F/world)
     and exchanged with ONE all-to-all, so that rank q holds panel q of ALL rows (N x wp); it runs
     the SpMM on that narrow operand (bias + activation fused, they are per column) and a second
@@ -18,7 +18,7 @@ S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two interchangeable
     whole gathered matrix.  Simple, but communication-bound beyond 2 GPUs on a graph without locality.
 
 Collectives go through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in
-the CPU tests).  Select the scheme with GEOGCN_DIST_EXCHANGE=a2a|allgather."""
+the CPU tests).  GEOGCN_DIST_EXCHANGE=a2a|allgather overrides the default (all-gather at 2 ranks, a2a from 3)."""
 from __future__ import annotations
 
 import os
@@ -112,7 +112,11 @@ class TorchDistComm(Comm):
         self.world = dist.get_world_size(group)
         self.part = RowPartition(N, self.world, self.rank)
         self.device = device
-        self.exchange = exchange or os.environ.get('GEOGCN_DIST_EXCHANGE', 'a2a')
+        self.exchange = exchange or os.environ.get('GEOGCN_DIST_EXCHANGE', 'auto')
+        if self.exchange == 'auto':
+            # at 2 ranks both schemes move the same bytes and the all-gather needs no repacking; from 3 ranks on
+            # the all-to-all moves (w-1)/w * 2/w of what the all-gather delivers to every rank
+            self.exchange = 'a2a' if self.world >= 3 else 'allgather'
         if self.exchange not in ('a2a', 'allgather'):
             raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a' or 'allgather', got %r" % self.exchange)
         self._bufs = {}
