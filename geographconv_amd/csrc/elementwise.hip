@@ -99,6 +99,51 @@ __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t n, int ld4, co
     }
 }
 
+// Same arithmetic, plus the column sums of dS and dU (the two bias gradients) in the same pass: block b owns
+// a contiguous chunk of rows, thread (ri, q) walks float4 column q of every rpi-th row; the per-thread sums are
+// combined over ri in fixed order and written as one partial row per block (summed by colsum_final_kernel).
+__global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int ld4, const float4* __restrict__ G,
+                                                                 const float4* __restrict__ T, const float4* __restrict__ Hc,
+                                                                 const float4* __restrict__ H, float4* __restrict__ dS,
+                                                                 int ld4_dS, float4* __restrict__ dU, float4* __restrict__ dHc,
+                                                                 int64_t rows_per_block, float4* __restrict__ P) {
+    __shared__ float4 red[2][TPB];
+    const int W = ld4, rpi = TPB / W;
+    const int q = threadIdx.x % W, ri = threadIdx.x / W;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    float4 aS = make_float4(0.f, 0.f, 0.f, 0.f), aU = aS;
+    if (ri < rpi) {
+        for (int64_t row = r0 + ri; row < r1; row += rpi) {
+            const int64_t e = row * ld4 + q;
+            const float4 g = G[e], t = T[e], hc = Hc[e], h = H[e];
+            float4 s, u, c;
+#define GEOGCN_HW(m)                                   \
+    s.m = (g.m * t.m) * (1.0f - hc.m * hc.m);          \
+    u.m = ((g.m * (hc.m - h.m)) * t.m) * (1.0f - t.m); \
+    c.m = g.m * (1.0f - t.m);                          \
+    aS.m += s.m;                                       \
+    aU.m += u.m;
+            GEOGCN_HW(x) GEOGCN_HW(y) GEOGCN_HW(z) GEOGCN_HW(w)
+#undef GEOGCN_HW
+            dS[row * ld4_dS + q] = s;
+            dU[e] = u;
+            dHc[e] = c;
+        }
+    }
+    red[0][threadIdx.x] = aS;
+    red[1][threadIdx.x] = aU;
+    __syncthreads();
+    if (ri == 0) {
+        for (int k = 1; k < rpi; ++k) {
+            const float4 a = red[0][k * W + q], b = red[1][k * W + q];
+            aS.x += a.x; aS.y += a.y; aS.z += a.z; aS.w += a.w;
+            aU.x += b.x; aU.y += b.y; aU.z += b.z; aU.w += b.w;
+        }
+        P[(int64_t)blockIdx.x * 2 * W + q] = aS;
+        P[(int64_t)blockIdx.x * 2 * W + W + q] = aU;
+    }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, const float* __restrict__ G,
                                                        const float* __restrict__ Y, int64_t ld,
@@ -197,13 +242,13 @@ __global__ __launch_bounds__(TPB) void colsum_partial_kernel(int64_t n, int F, c
 // 16 columns x 16 part-groups per block: group g adds parts g, g+16, ... in order, then the 16 group
 // sums are added in group order (fixed tree => deterministic)
 __global__ __launch_bounds__(TPB) void colsum_final_kernel(int nparts, int F, const float* __restrict__ P,
-                                                           float* __restrict__ out) {
+                                                           int64_t stride, float* __restrict__ out) {
     __shared__ float s[16][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + c;
     float a = 0.f;
     if (col < F)
-        for (int p = g; p < nparts; p += 16) a += P[(int64_t)p * F + col];
+        for (int p = g; p < nparts; p += 16) a += P[(int64_t)p * stride + col];
     s[g][c] = a;
     __syncthreads();
     if (g == 0 && col < F) {
@@ -328,17 +373,50 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
     return 0;
 }
 
+static int64_t hw_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(2048, cdiv(n, 32))); }
+
+size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F) {
+    if (n <= 0 || F <= 0) return 0;
+    return (size_t)hw_parts(n) * 2 * (size_t)((F + 3) / 4) * 4 * sizeof(float);
+}
+
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
-                           int64_t ld, float* dS, int64_t ld_dS, float* dU, float* dHcarry, void* stream) {
+                           int64_t ld, float* dS, int64_t ld_dS, float* dU, float* dHcarry, float* dbS, float* dbU,
+                           void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "highway_bwd_f32: negative size");
     if (n == 0 || F == 0) return 0;
     CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU, dHcarry);
     GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= ld, GEOGCN_E_ALIGN, "highway_bwd_f32: ld_dS=%lld must be a multiple of 4, >= ld",
                    (long long)ld_dS);
-    hipLaunchKernelGGL(highway_bwd_kernel, dim3(stream_grid(n * ld / 4)), dim3(TPB), 0, (hipStream_t)stream, n,
-                       (int)(ld / 4), (const float4*)G, (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS,
-                       (int)(ld_dS / 4), (float4*)dU, (float4*)dHcarry);
+    GEOGCN_REQUIRE((dbS == nullptr) == (dbU == nullptr), GEOGCN_E_ARG, "highway_bwd_f32: pass both bias gradients or neither");
+    hipStream_t st = (hipStream_t)stream;
+    const int ld4 = (int)(ld / 4);
+    if (dbS && ld4 <= TPB && ld == (int64_t)((F + 3) / 4) * 4) {
+        const int64_t parts = hw_parts(n);
+        const int64_t rpb = cdiv(n, parts);
+        const int nparts = (int)cdiv(n, rpb);
+        GEOGCN_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)nparts * 2 * ld * sizeof(float), GEOGCN_E_ARG,
+                       "highway_bwd_f32: workspace too small");
+        hipLaunchKernelGGL(highway_bwd_colsum_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, ld4, (const float4*)G,
+                           (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS, (int)(ld_dS / 4), (float4*)dU,
+                           (float4*)dHcarry, rpb, (float4*)ws);
+        GEOGCN_LAUNCH_CHECK("highway_bwd_colsum_kernel");
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, (const float*)ws,
+                           (int64_t)2 * ld, dbS);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F,
+                           (const float*)ws + ld, (int64_t)2 * ld, dbU);
+        GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
+        return 0;
+    }
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(stream_grid(n * ld / 4)), dim3(TPB), 0, st, n, ld4, (const float4*)G,
+                       (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS, (int)(ld_dS / 4), (float4*)dU,
+                       (float4*)dHcarry);
     GEOGCN_LAUNCH_CHECK("highway_bwd_kernel");
+    if (dbS) {          // very wide layers: separate deterministic column sums
+        int rc = geogcn_colsum_f32(n, F, dS, ld_dS, dbS, ws, ws_bytes, stream);
+        if (rc) return rc;
+        return geogcn_colsum_f32(n, F, dU, ld, dbU, ws, ws_bytes, stream);
+    }
     return 0;
 }
 
@@ -389,7 +467,7 @@ int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* 
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, F, X, ldx, rpb, (float*)ws);
     GEOGCN_LAUNCH_CHECK("colsum_partial_kernel");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F,
-                       (const float*)ws, out);
+                       (const float*)ws, (int64_t)F, out);
     GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
 }

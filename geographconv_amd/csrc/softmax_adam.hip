@@ -53,6 +53,47 @@ __global__ __launch_bounds__(TPB) void softmax_rows_kernel(int64_t n, int C, con
     if (amax && lane == 0) amax[row] = mi;
 }
 
+// C <= 64 * KREG: the row lives in registers -- one read of the logits, one exp per element, one write.
+template <int KREG>
+__global__ __launch_bounds__(TPB) void softmax_rows_reg_kernel(int64_t n, int C, const float* __restrict__ L, int64_t ldl,
+                                                               float* __restrict__ P, int64_t ldp, int ldp_pad,
+                                                               int* __restrict__ amax) {
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    if (row >= n) return;
+    const float* x = L + row * ldl;
+    float v[KREG];
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+        const int c = lane + kWave * k;
+        v[k] = (c < C) ? x[c] : -INFINITY;
+        if (v[k] > m) { m = v[k]; mi = c; }        // ascending c within a lane: strict > keeps the first index
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, kWave);
+        const int oi = __shfl_xor(mi, o, kWave);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+        const int c = lane + kWave * k;
+        v[k] = (c < C) ? expf(v[k] - m) : 0.f;
+        s += v[k];
+    }
+    s = wave_sum(s);
+    float* p = P + row * ldp;
+#pragma unroll
+    for (int k = 0; k < KREG; ++k) {
+        const int c = lane + kWave * k;
+        if (c < ldp_pad) p[c] = (c < C) ? v[k] / s : 0.f;
+    }
+    if (amax && lane == 0) amax[row] = mi;
+}
+
 // per-index loss / hit, block partial sums in a fixed tree
 __global__ __launch_bounds__(TPB) void ce_partial_kernel(int C, const float* __restrict__ P, int64_t ldp,
                                                          const int* __restrict__ amax,
@@ -180,8 +221,14 @@ int geogcn_softmax_rows_f32(int64_t n, int32_t C, const float* logits, int64_t l
     GEOGCN_REQUIRE(logits && probs, GEOGCN_E_NULL, "softmax_rows_f32: null pointer");
     GEOGCN_REQUIRE(ldl >= C && ldp >= C, GEOGCN_E_SIZE, "softmax_rows_f32: ld < C");
     const int ldp_pad = (int)std::min<int64_t>(ldp, (int64_t)((C + 3) / 4) * 4);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(n, kWavesPerBlock)), dim3(TPB), 0, (hipStream_t)stream,
-                       n, C, logits, ldl, probs, ldp, ldp_pad, argmax_out);
+    const dim3 grid((unsigned)cdiv(n, kWavesPerBlock));
+    hipStream_t st = (hipStream_t)stream;
+    if (ldp_pad <= 64 * 4)
+        hipLaunchKernelGGL((softmax_rows_reg_kernel<4>), grid, dim3(TPB), 0, st, n, C, logits, ldl, probs, ldp, ldp_pad, argmax_out);
+    else if (ldp_pad <= 64 * 16)
+        hipLaunchKernelGGL((softmax_rows_reg_kernel<16>), grid, dim3(TPB), 0, st, n, C, logits, ldl, probs, ldp, ldp_pad, argmax_out);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel, grid, dim3(TPB), 0, st, n, C, logits, ldl, probs, ldp, ldp_pad, argmax_out);
     GEOGCN_LAUNCH_CHECK("softmax_rows_kernel");
     return 0;
 }

@@ -178,11 +178,14 @@ class MultiplicativeGatingLayer(L.MergeLayer):
             raise NotImplementedError("gating backward is implemented for the highway pattern "
                                       "(sigmoid gate, tanh branch) the reference builds (gcnmodel.py:268-288)")
         # one pass: gradients w.r.t. both PRE-activations and the carry
-        dS, dU, dH = K.highway_bwd(grad, t, h1, h2)
+        # ... and the two bias gradients (column sums of dS / dU) while the data is in registers
+        fuse_b = gate_l.b is not None and h1_l.b is not None
+        dS, dU, dH = K.highway_bwd(grad, t, h1, h2, dbS=h1_l.b.grad if fuse_b else None,
+                                   dbU=gate_l.b.grad if fuse_b else None)
         if into[2] is not None:
             K.add_inplace(dH, into[2])
             dH = into[2]
-        return [L.PreAct(dU), L.PreAct(dS), dH]
+        return [L.PreAct(dU, bias_done=fuse_b), L.PreAct(dS, bias_done=fuse_b), dH]
 
 
 def highway_dense(incoming, gconv=False, Wh=_init.GlorotUniform(), bh=_init.Constant(0.0),

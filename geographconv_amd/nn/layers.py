@@ -116,8 +116,9 @@ def y_device(x):
 
 
 class PreAct:
-    def __init__(self, m):
+    def __init__(self, m, bias_done=False):
         self.m = m
+        self.bias_done = bias_done        # the producer already wrote this layer's bias gradient
 
 
 # --------------------------------------------------------------------------------------------
@@ -297,7 +298,7 @@ class DenseLayer(Layer):
             uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
             out = K.DMat.empty(grad.n, grad.F, grad.device, ld=K.gather_ld(grad.F)) if uses_graph else None
             dS = K.act_bwd(grad, y, self.nonlinearity.act, out=out)
-        if self.b is not None:
+        if self.b is not None and not (isinstance(grad, PreAct) and grad.bias_done):
             K.colsum(dS, out=self.b.grad)
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
         if A is not None:

@@ -246,12 +246,17 @@ def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
     return out
 
 
-def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None):
+def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None,
+                dbS: torch.Tensor = None, dbU: torch.Tensor = None):
+    """-> (dS, dU, dHcarry); with dbS / dbU given, also the two bias gradients (column sums) in the same pass."""
+    lib = _ffi.lib()
     dS = DMat.empty(G.n, G.F, G.device, ld=gather_ld(G.F)) if dS is None else dS      # dS feeds the A^T SpMM
     dU = G.like() if dU is None else dU
     dHcarry = G.like() if dHcarry is None else dHcarry
-    check(_ffi.lib().geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld,
-                                            _p(dU.t), _p(dHcarry.t), _stream()), 'highway_bwd_f32')
+    w = _ws_for(G.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(G.n, G.F),
+                                  lib.geogcn_colsum_workspace_bytes(G.n, G.F)) if dbS is not None else 0)
+    check(lib.geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
+                                     _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
     return dS, dU, dHcarry
 
 

@@ -121,7 +121,12 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
  *   dS = G*T*(1-Hc^2)   dU = G*(Hc-H)*T*(1-T)   dHcarry = G*(1-T)                               */
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
                            const float* H, int64_t ld, float* dS, int64_t ld_dS /* dS may use the line-aligned
-                           pitch of an SpMM operand */, float* dU, float* dHcarry, void* stream);
+                           pitch of an SpMM operand */, float* dU, float* dHcarry,
+                           float* dbS /* nullable: column sums of dS = grad of the conv bias */,
+                           float* dbU /* nullable: column sums of dU = grad of the gate bias */,
+                           void* ws, size_t ws_bytes, void* stream);
+/* workspace of the fused column sums (deterministic two-pass); 0 when they are not requested */
+size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F);
 /* dS = G [* keep_mask * scale] * act'(Y) with act' expressed through the layer OUTPUT Y:
  * tanh: 1 - Y^2 (gcnmodel.py:42,136), sigmoid: Y(1-Y) (gcnmodel.py:286), none: 1.  The optional
  * mask folds in the dropout that follows layer 0 (gcnmodel.py:357); mask may be NULL.           */

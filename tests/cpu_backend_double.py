@@ -91,13 +91,16 @@ def highway_fwd(T, Hc, H, out=None):
     return out
 
 
-def highway_bwd(G, T, Hc, H, dS=None, dU=None, dHcarry=None):
+def highway_bwd(G, T, Hc, H, dS=None, dU=None, dHcarry=None, dbS=None, dbU=None):
     mk = lambda: DMat(G.n, G.F, G.device)
     dS, dU, dHcarry = dS or mk(), dU or mk(), dHcarry or mk()
     g, t, hc, h = _v(G), _v(T), _v(Hc), _v(H)
     _v(dS)[...] = g * t * (1 - hc * hc)
     _v(dU)[...] = g * (hc - h) * t * (1 - t)
     _v(dHcarry)[...] = g * (1 - t)
+    if dbS is not None:
+        dbS.numpy()[:G.F] = _v(dS).sum(axis=0)
+        dbU.numpy()[:G.F] = _v(dU).sum(axis=0)
     return dS, dU, dHcarry
 
 

@@ -253,6 +253,19 @@ def test_highway_and_tanh_kernels(dev, n, F):
     assert np.allclose(dU.numpy(), G * (Hc - H) * T * (1 - T), rtol=1e-5, atol=1e-7)
     assert np.allclose(dHc.numpy(), G * (1 - T), rtol=1e-6, atol=1e-7)
     assert torch.all(dS.t[:, F:ops.pad4(F)] == 0)
+    # fused bias gradients: same dS / dU, plus deterministic column sums
+    bS = torch.zeros(ops.pad4(F), device=dev)
+    bU = torch.zeros(ops.pad4(F), device=dev)
+    dS2, dU2, dHc2 = ops.highway_bwd(d(G), d(T), d(Hc), d(H), dbS=bS, dbU=bU)
+    assert np.array_equal(dS2.numpy(), dS.numpy()) and np.array_equal(dU2.numpy(), dU.numpy())
+    assert np.array_equal(dHc2.numpy(), dHc.numpy())
+    refS = dS.numpy().astype(np.float64).sum(axis=0)
+    refU = dU.numpy().astype(np.float64).sum(axis=0)
+    assert np.all(np.abs(bS.cpu().numpy()[:F] - refS) <= 1e-6 * np.abs(dS.numpy()).sum(axis=0) + 1e-6)
+    assert np.all(np.abs(bU.cpu().numpy()[:F] - refU) <= 1e-6 * np.abs(dU.numpy()).sum(axis=0) + 1e-6)
+    bS2 = torch.zeros_like(bS)
+    ops.highway_bwd(d(G), d(T), d(Hc), d(H), dbS=bS2, dbU=torch.zeros_like(bU))
+    assert torch.equal(bS, bS2)
     # tanh backward, with and without the dropout mask folded in
     got = ops.tanh_bwd(d(G), d(Hc)).numpy()
     assert np.allclose(got, G * (1 - Hc * Hc), rtol=1e-5, atol=1e-7)
@@ -299,7 +312,7 @@ def test_philox_mask_statistics_and_reproducibility(dev):
     assert abs(np.corrcoef(m1[:, 0], m1[:, 1])[0, 1]) < 0.06
 
 
-@pytest.mark.parametrize("n,Cc", [(3000, 129), (1000, 256), (50, 930), (7, 2)])
+@pytest.mark.parametrize("n,Cc", [(3000, 129), (1000, 256), (50, 930), (7, 2), (40, 1500)])
 def test_softmax_ce_head(dev, n, Cc):
     from geographconv_amd import ops
     L = _rand((n, Cc), 1, scale=3.0)
