@@ -76,24 +76,28 @@ struct Bf16Args {
     int n_mt, n_nt;
 };
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int NT>
 struct BCfg {
+    static constexpr int kWavesM = NT / 128;                 // waves along M (2 or 4); always 2 along N
     static constexpr int kARows = BM, kBRows = BN;
     static constexpr int kABytes = NS * BM * ROWB;
     static constexpr int kBBytes = NS * BN * ROWB;
     static constexpr int kStageBytes = kABytes + kBBytes;
     // double buffered (one barrier per stage) when two blocks per CU still fit, else one image + two barriers
-    static constexpr bool kDouble = 4 * kStageBytes <= 160 * 1024;
+    // (the 8-wave x3 variant is limited to one block per CU by registers: it double-buffers whenever 2 images fit)
+    static constexpr bool kDouble = (NT == 512) ? (2 * kStageBytes <= 160 * 1024) : (4 * kStageBytes <= 160 * 1024);
     static constexpr int kLdsBytes = (kDouble ? 2 : 1) * kStageBytes;
-    static constexpr int MR = BM / 32, NR = BN / 32;
-    static constexpr int kAIters = BM / 32;                 // float4 per thread per stage (8 f4 per row)
+    static constexpr int MR = BM / (16 * kWavesM), NR = BN / 32;
+    static constexpr int kAIters = BM / (NT / 8);           // float4 per thread per stage (8 f4 per row)
     static constexpr int kBVec = NS * BN * 4;               // uint4 per stage (4 per row per plane)
-    static constexpr int kBIters = (kBVec + TPB - 1) / TPB;
+    static constexpr int kBIters = (kBVec + NT - 1) / NT;
 };
 
-template <int BM, int BN, int NS, int ACT>
-__global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
-    using Cfg = BCfg<BM, BN, NS>;
+template <int BM, int BN, int NS, int ACT, int NT>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
+    using Cfg = BCfg<BM, BN, NS, NT>;
+    constexpr int kRowsPerPass = NT / 8;
+    constexpr int kWaveRows = BM / Cfg::kWavesM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int p = blockIdx.x, G = gridDim.x;
     const int tid = threadIdx.x;
@@ -119,22 +123,27 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
         return mt < a.n_mt;
     };
 
-    float4 ra[Cfg::kAIters];
+    // A (HBM stream) is prefetched TWO stages ahead in two register sets, B (L2-resident weight planes) one
+    // stage ahead: with two blocks per CU that keeps four 16 KB A tiles in flight per CU -- the single-stage
+    // version of this kernel was latency-bound (5 us per stage).
+    float4 ra0[Cfg::kAIters], ra1[Cfg::kAIters];
     uint4 rb[Cfg::kBIters];
     const int a_f4 = tid & 7, a_rr = tid >> 3;
-    auto gload = [&](int64_t m0, int64_t n0, int kt) {
+    auto gloadA = [&](float4 (&ra)[Cfg::kAIters], int64_t m0, int kt) {
         const int64_t k0 = (int64_t)kt * BKH + a_f4 * 4;
         const int64_t klim = (a.K + 3) & ~(int64_t)3;          // pad columns of A are zero (geogcn.h)
 #pragma unroll
         for (int i = 0; i < Cfg::kAIters; ++i) {
-            const int64_t row = m0 + a_rr + 32 * i;
+            const int64_t row = m0 + a_rr + kRowsPerPass * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < a.M && k0 < klim) v = *reinterpret_cast<const float4*>(a.A + row * a.lda + k0);
             ra[i] = v;
         }
+    };
+    auto gloadB = [&](int64_t n0, int kt) {
 #pragma unroll
         for (int i = 0; i < Cfg::kBIters; ++i) {
-            const int e = tid + TPB * i;
+            const int e = tid + NT * i;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (e < Cfg::kBVec) {
                 const int pl = e / (BN * 4), r = (e / 4) % BN, c = e & 3;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
             rb[i] = v;
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const float4 (&ra)[Cfg::kAIters]) {
         unsigned char* As = smem_raw + (Cfg::kDouble ? buf : 0) * Cfg::kStageBytes;
         unsigned char* Bs = As + Cfg::kABytes;
 #pragma unroll
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
             uint32_t t[4][NS];
 #pragma unroll
             for (int e = 0; e < 4; ++e) split_bf16<NS>(xs[e], t[e]);
-            const int row = a_rr + 32 * i;
+            const int row = a_rr + kRowsPerPass * i;
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl) {
                 uint2 w;
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kBIters; ++i) {
-            const int e = tid + TPB * i;
+            const int e = tid + NT * i;
             if (e < Cfg::kBVec) {
                 const int pl = e / (BN * 4), r = (e / 4) % BN, c = e & 3;
                 *reinterpret_cast<uint4*>(Bs + (pl * BN + r) * ROWB + c * 16) = rb[i];
@@ -174,28 +183,33 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
     };
 
     int cj = 0, ckt = 0, lj = 0, lkt = 0;
-    int64_t cm0, cn0, lm0, ln0;
+    int64_t cm0, cn0, lm0, ln0, pm0 = 0, pn0 = 0;
+    int pkt = 0;
     if (!decode(0, cm0, cn0)) return;
     lm0 = cm0; ln0 = cn0;
-    bool lvalid = true;
-    gload(lm0, ln0, 0);
-    sstore(0);
-    if (++lkt == nk) { lvalid = decode(++lj, lm0, ln0); lkt = 0; }
+    bool lvalid = true, pvalid = false;
+    auto advance_load = [&]() {
+        if (++lkt == nk) { lvalid = decode(++lj, lm0, ln0); lkt = 0; }
+    };
+    gloadA(ra0, lm0, 0);
+    gloadB(ln0, 0);
+    sstore(0, ra0);
+    advance_load();
+    pvalid = lvalid; pm0 = lm0; pn0 = ln0; pkt = lkt;      // stage 1: its A goes to set 1 now, its B next iteration
+    if (pvalid) { gloadA(ra1, pm0, pkt); advance_load(); }
     __syncthreads();
     int cur = 0;
-    while (true) {
-        if (lvalid) gload(lm0, ln0, lkt);
+    bool running = true;
+    // (xa) = free A set, receives stage s+2;  (ya) = A set holding stage s+1
+    auto step = [&](float4 (&xa)[Cfg::kAIters], const float4 (&ya)[Cfg::kAIters]) {
+        const bool have_load = lvalid;
+        if (have_load) gloadA(xa, lm0, lkt);
+        if (pvalid) gloadB(pn0, pkt);
         const unsigned char* As = smem_raw + (Cfg::kDouble ? cur : 0) * Cfg::kStageBytes;
         const unsigned char* Bs = As + Cfg::kABytes;
         // ---- MFMAs on the resident stage ----
-        // A fragments of the wave's 4 row tiles stay in registers; B fragments are read one column
-        // tile at a time (keeps the live set under 256 VGPRs without spills)
-        bf16x8 af[Cfg::MR][NS];
-#pragma unroll
-        for (int i = 0; i < Cfg::MR; ++i)
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl)
-                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + wm * (BM / 2) + i * 16 + li) * ROWB + lg * 16);
+        // fragments are re-read from LDS per (column tile, row tile) pair: 24 live fragment registers instead
+        // of 60+ -- the register file is needed for the two-stage prefetch, LDS bandwidth is not the limit
 #pragma unroll
         for (int j = 0; j < Cfg::NR; ++j) {
             bf16x8 bf[NS];
@@ -204,15 +218,19 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
                 bf[pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + wn * (BN / 2) + j * 16 + li) * ROWB + lg * 16);
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
+                bf16x8 af[NS];
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    af[pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + wm * kWaveRows + i * 16 + li) * ROWB + lg * 16);
                 f32x4 c = acc[i][j];
                 if constexpr (NS == 3) {        // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
         }
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
             }
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
-                const int64_t row0 = cm0 + wm * (BM / 2) + i * 16 + lg * 4;
+                const int64_t row0 = cm0 + wm * kWaveRows + i * 16 + lg * 4;
                 float oldv[Cfg::NR][4];
                 if (a.accumulate) {
 #pragma unroll
@@ -250,33 +268,39 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_kernel(const Bf16Args a) {
             }
         }
         if constexpr (!Cfg::kDouble) __syncthreads();     // single image: everybody done reading first
-        if (lvalid) sstore(cur ^ 1);
+        if (pvalid) sstore(cur ^ 1, ya);
         __syncthreads();
         cur ^= 1;
         if (++ckt == nk) {
             ckt = 0;
-            if (!decode(++cj, cm0, cn0)) break;
+            if (!decode(++cj, cm0, cn0)) running = false;
         }
-        if (lvalid && ++lkt == nk) { lvalid = decode(++lj, lm0, ln0); lkt = 0; }
+        pvalid = have_load; pm0 = lm0; pn0 = ln0; pkt = lkt;
+        if (have_load) advance_load();
+    };
+    while (running) {
+        step(ra0, ra1);
+        if (!running) break;
+        step(ra1, ra0);
     }
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int NT>
 int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
-    using Cfg = BCfg<BM, BN, NS>;
+    using Cfg = BCfg<BM, BN, NS, NT>;
     const int per_cu = (2 * Cfg::kLdsBytes <= 160 * 1024) ? 2 : 1;
     const int64_t tiles = (int64_t)a.n_mt * a.n_nt;
     const int G = (int)std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(tiles, kNumXCD) * kNumXCD);
 #define GEOGCN_L(ACT)                                                                                          \
     do {                                                                                                        \
-        auto kern = gemm_bf16_kernel<BM, BN, NS, ACT>;                                                          \
+        auto kern = gemm_bf16_kernel<BM, BN, NS, ACT, NT>;                                                          \
         static bool attr_done = false;                                                                          \
         if (!attr_done) {                                                                                       \
             GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                            Cfg::kLdsBytes));                                                    \
             attr_done = true;                                                                                   \
         }                                                                                                       \
-        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), Cfg::kLdsBytes, st, a);                          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NT), Cfg::kLdsBytes, st, a);                          \
         GEOGCN_LAUNCH_CHECK("gemm_bf16_kernel");                                                                \
     } while (0)
     if (act == GEOGCN_ACT_TANH) GEOGCN_L(GEOGCN_ACT_TANH);
@@ -312,12 +336,12 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
     GEOGCN_LAUNCH_CHECK("prep_b_planes_kernel");
     const int bn = (cdiv(N, 160) * 160 < cdiv(N, 128) * 128) ? 160 : 128;
     Bf16Args a{M, N, K, A, lda, planes, Kp, C, ldc, bias, accumulate, (int)cdiv(M, 128), (int)cdiv(N, bn)};
-    if (ns == 3) {
-        if (bn == 160) return launch_bf16<128, 160, 3>(a, act, st);
-        return launch_bf16<128, 128, 3>(a, act, st);
+    if (ns == 3) {      // 8 waves per block: half the accumulators / staging registers per lane
+        if (bn == 160) return launch_bf16<128, 160, 3, 512>(a, act, st);
+        return launch_bf16<128, 128, 3, 512>(a, act, st);
     }
-    if (bn == 160) return launch_bf16<128, 160, 1>(a, act, st);
-    return launch_bf16<128, 128, 1>(a, act, st);
+    if (bn == 160) return launch_bf16<128, 160, 1, 256>(a, act, st);
+    return launch_bf16<128, 128, 1, 256>(a, act, st);
 }
 
 }  // namespace geogcn
