@@ -1,0 +1,88 @@
+"""Per-rank COMPUTE time of the partitioned f_train step, measured on one GPU: rank `--rank` of a simulated
+`--world`-rank job runs its real share of the work while the collectives are replaced by local copies of the
+same size (so packing, the narrow SpMM, the local GEMMs, ... are timed; the wire time is not).  Used to split
+a multi-GPU step into compute and communication when only 1-GPU boxes are available.
+   python tools/sim_rank.py --world 8 [--rank 0] [--exchange a2a|allgather] [--steps 5]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from geographconv_amd import synth  # noqa: E402
+from geographconv_amd.dist import RowPartition, TorchDistComm  # noqa: E402
+from geographconv_amd.gcnmodel import GraphConv  # noqa: E402
+
+
+class FakeDist:
+    class ReduceOp:
+        SUM = 0
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.bytes_a2a = self.bytes_ag = self.n_a2a = self.n_ag = 0
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def all_to_all_single(self, out, inp, group=None):
+        out.copy_(inp)                                   # same bytes through HBM instead of xGMI
+        self.bytes_a2a += inp.numel() * 4 * (self.world - 1) // self.world
+        self.n_a2a += 1
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        self.bytes_ag += out.numel() * 4 * (self.world - 1) // self.world
+        self.n_ag += 1
+
+    def all_reduce(self, t, op=None, group=None):
+        pass
+
+
+class SimComm(TorchDistComm):
+    def __init__(self, N, device, rank, world, exchange):
+        self.dist = FakeDist(rank, world)
+        self.group = None
+        self.rank, self.world = rank, world
+        self.part = RowPartition(N, world, rank)
+        self.device = device
+        self.exchange = exchange
+        self._bufs = {}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--world', type=int, default=8)
+    ap.add_argument('--rank', type=int, default=0)
+    ap.add_argument('--exchange', default='a2a')
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--shape', default='twus')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    A, X, Y, (tr, dv, te), C = synth.make_graph(args.shape)
+    comm = SimComm(A.shape[0], dev, args.rank, args.world, args.exchange)
+    clf = GraphConv(X.shape[1], C, [300, 300, 300], 0.0, 0.5, highway=True, device=dev, comm=comm)
+    clf.build_model(A, seed=77)
+    for _ in range(2):
+        clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
+    torch.cuda.synchronize()
+    d = comm.dist
+    d.bytes_a2a = d.bytes_ag = d.n_a2a = d.n_ag = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print('world=%d rank=%d exchange=%s: %.2f ms compute per step; per step: %d all-to-all (%.0f MB on the wire), '
+          '%d all-gather (%.0f MB)' % (args.world, args.rank, args.exchange, ms, d.n_a2a // args.steps,
+                                       d.bytes_a2a / args.steps / 1e6, d.n_ag // args.steps, d.bytes_ag / args.steps / 1e6))
+
+
+if __name__ == '__main__':
+    main()
