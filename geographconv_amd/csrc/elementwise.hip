@@ -373,7 +373,7 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
     return 0;
 }
 
-static int64_t hw_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(2048, cdiv(n, 32))); }
+static int64_t hw_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(768, cdiv(n, 64))); }
 
 size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F) {
     if (n <= 0 || F <= 0) return 0;
