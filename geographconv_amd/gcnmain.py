@@ -188,8 +188,47 @@ def main(data, args, **kwargs):
             t = geo_eval(Y_test, y_pred, U_test, classLatMedian, classLonMedian, userLocation)
             results.append({'fraction': percentile, 'dev': (mean, median, acc), 'test': t[:3]})
     if args.feature_report:
-        raise NotImplementedError("-feature_report (gcnmain.py:234-261) is a SURVEY.md §8f 'next' row")
+        # gcnmain.py:234-246: probe the trained model with one-hot "documents" (X = I over the vocabulary) on an
+        # identity graph and list, per class, the words it is most confident about
+        vocab_file = os.path.join(args.dir, 'vocab.pkl')
+        if os.path.exists(vocab_file):
+            vocab = load_obj(vocab_file)
+        elif getattr(model_args, 'synthetic', None):
+            vocab = {'w%d' % i: i for i in range(X.shape[1])}
+        else:
+            logging.error('vocab file {} not found'.format(vocab_file))
+            return clf, results
+        logging.info('{} vocab loaded from file'.format(len(vocab)))
+        from collections import Counter
+        train_vocab = set(term for term, count in Counter(X[train_indices].nonzero()[1]).items() if count >= 10)
+        dev_vocab = set(np.nonzero(np.asarray(X[dev_indices].sum(axis=0)).ravel())[0])
+        X_onehot = sps.identity(len(vocab), dtype=dtype, format='csr')
+        A_onehot = X_onehot
+        if rank0 and comm is None:
+            feature_report(clf, vocab, X_onehot, A_onehot, classLatMedian, classLonMedian, train_vocab, dev_vocab,
+                           topk=200, dtypeint=dtypeint)
+        else:
+            logging.warning('-feature_report runs on a single GPU only')
     return clf, results
+
+
+def feature_report(model, vocab, X, A, classLatMedian, classLonMedian, train_vocab=set(), dev_vocab=set(), topk=20,
+                   dtypeint='int32', filename='important_features.txt'):
+    """Top-k most indicative vocabulary entries per class (reference gcnmain.py:249-261, python-3 idioms)."""
+    import codecs
+    eval_indices = np.asarray(range(X.shape[0])).astype(dtypeint)
+    preds, probs = model.predict(X, A, eval_indices)
+    id2v = {v: k for k, v in vocab.items()}
+    logging.info('{} train vocab are being excluded!'.format(len(train_vocab)))
+    feature_importance = np.argsort(-probs, axis=0)
+    with codecs.open(filename, 'w', encoding='utf-8') as fout:
+        for lbl in range(probs.shape[1]):
+            important_vocab = ' '.join([id2v[idx] for idx in feature_importance[:, lbl].reshape(-1).tolist()
+                                        if idx not in train_vocab][0:topk])
+            lat, lon = classLatMedian[str(lbl)], classLonMedian[str(lbl)]
+            fout.write(u'location: {},{} \nimportant features: {} \n\n'.format(lat, lon, important_vocab))
+    logging.info('important features are written to {}'.format(filename))
+    return feature_importance
 
 
 def parse_args(argv):

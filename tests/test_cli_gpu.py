@@ -27,3 +27,14 @@ def test_gcnmain_runs_reference_flag_set(tmp_path, monkeypatch):
     p1, _ = clf.predict(X, data[0], idx)
     p2, _ = clf2.predict(X, data[0], idx)
     assert np.array_equal(p1, p2)
+
+
+def test_feature_report_probes_model_with_onehot_inputs(tmp_path, monkeypatch):
+    """-feature_report (reference gcnmain.py:234-261): predict on X = I (vocabulary) with A = I -- a second
+    (X, A) pair of a different node count through the same trained model."""
+    from geographconv_amd import gcnmain
+    monkeypatch.chdir(tmp_path)
+    argv = '-hid 64 64 -reg 0.0 -dropout 0.0 -highway -silent --synthetic cmu --epochs 3 -maxdown 1 -feature_report'.split()
+    clf, results = gcnmain.run(argv)
+    txt = open('important_features.txt', encoding='utf-8').read()
+    assert txt.count('location:') == 129 and 'important features: w' in txt
