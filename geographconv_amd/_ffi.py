@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgeogcn.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'geogcn.h')
 
-ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_TANH, ACT_SIGMOID, ACT_SELU, ACT_RELU = 0, 1, 2, 3, 4
 GEMM_F32, GEMM_BF16X3, GEMM_BF16 = 0, 1, 2
 
 c_i32, c_i64, c_f32, c_sz, c_ptr = C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_void_p

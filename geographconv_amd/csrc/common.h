@@ -52,6 +52,10 @@ __device__ __forceinline__ float apply_act(float x) {
         return tanhf(x);
     } else if constexpr (ACT == GEOGCN_ACT_SIGMOID) {
         return 1.0f / (1.0f + expf(-x));
+    } else if constexpr (ACT == GEOGCN_ACT_SELU) {          // scale * elu(x, alpha) (Klambauer et al. 2017)
+        return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * (expf(x) - 1.0f));
+    } else if constexpr (ACT == GEOGCN_ACT_RELU) {
+        return x > 0.f ? x : 0.f;
     } else {
         return x;
     }

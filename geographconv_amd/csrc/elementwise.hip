@@ -165,6 +165,9 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, 
             if (mask) gg = (c0 + i < F) ? gg * ((float)mask[row * F + c0 + i] * scale) : 0.f;
             if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = gg * (1.0f - yo[i] * yo[i]);
             else if constexpr (ACT == GEOGCN_ACT_SIGMOID) o[i] = gg * (yo[i] * (1.0f - yo[i]));
+            else if constexpr (ACT == GEOGCN_ACT_SELU)      // y > 0: scale; else scale*alpha*exp(x) = y + scale*alpha
+                o[i] = gg * (yo[i] > 0.f ? 1.0507009873554805f : yo[i] + 1.0507009873554805f * 1.6732632423543772f);
+            else if constexpr (ACT == GEOGCN_ACT_RELU) o[i] = yo[i] > 0.f ? gg : 0.f;
             else o[i] = gg;
         }
         *reinterpret_cast<float4*>(dS + row * ld_dS + c0) = mask_pad(make_float4(o[0], o[1], o[2], o[3]), c0, F);
@@ -352,6 +355,10 @@ int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const
         hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_SIGMOID>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
     else if (act == GEOGCN_ACT_NONE)
         hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_NONE>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
+    else if (act == GEOGCN_ACT_SELU)
+        hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_SELU>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
+    else if (act == GEOGCN_ACT_RELU)
+        hipLaunchKernelGGL((bias_act_kernel<GEOGCN_ACT_RELU>), grid, dim3(TPB), 0, st, n, F, F4, X, ldx, bias, Y, ldy);
     else {
         set_error("bias_act_f32: unknown act %d", act);
         return GEOGCN_E_ARG;
@@ -436,6 +443,10 @@ int geogcn_act_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int
         hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_SIGMOID>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
     else if (act == GEOGCN_ACT_NONE)
         hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_NONE>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
+    else if (act == GEOGCN_ACT_SELU)
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_SELU>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
+    else if (act == GEOGCN_ACT_RELU)
+        hipLaunchKernelGGL((act_bwd_kernel<GEOGCN_ACT_RELU>), grid, dim3(TPB), 0, st, n, F, F4, G, Y, ld, keep_mask, scale, dS, ld_dS);
     else {
         set_error("act_bwd_f32: unknown act %d", act);
         return GEOGCN_E_ARG;

@@ -203,8 +203,7 @@ def highway_dense(incoming, gconv=False, Wh=_init.GlorotUniform(), bh=_init.Cons
 
 
 def residual_dense(incoming, nonlinearity=NL.selu):
-    """Residual block of the reference (gcnmodel.py:290-294) -- never used by GraphConv; its SELU has no
-    gfx950 epilogue yet, so evaluating it raises NotImplementedError (SURVEY.md §8f "next")."""
+    """Residual block of the reference (gcnmodel.py:290-294) -- never used by GraphConv: selu(conv(x) + x)."""
     num_inputs = int(np.prod(incoming.output_shape[1:]))
     convX = ConvolutionDenseLayer2(incoming, num_units=num_inputs, nonlinearity=None)
     convX_plus_X = L.ElemwiseSumLayer([convX, incoming], coeffs=1, cropping=None)

@@ -243,8 +243,10 @@ class DenseLayer(Layer):
 
     def _fused_act(self):
         if self.nonlinearity.act is None and self.nonlinearity is not _nl.softmax:
-            raise NotImplementedError("nonlinearity %s has no gfx950 epilogue yet" % self.nonlinearity.name)
-        return 0 if self.nonlinearity is _nl.softmax else self.nonlinearity.act
+            raise NotImplementedError("nonlinearity %s has no gfx950 kernel yet" % self.nonlinearity.name)
+        if self.nonlinearity is _nl.softmax or not self.nonlinearity.fusable:
+            return 0                      # applied by its own kernel after the product
+        return self.nonlinearity.act
 
     def forward(self, input, tape, **kwargs):
         K = backend.active()
@@ -273,6 +275,8 @@ class DenseLayer(Layer):
                 z = comm.matmul_target(self.num_units, tag='fwd')
                 self._matmul(input, z, prec)
                 y = comm.graph_spmm(A.fwd, z, bias, act, self.num_units, tag='fwd')
+        if self.nonlinearity.act is not None and not self.nonlinearity.fusable:
+            y = K.bias_act(y, None, self.nonlinearity.act)       # relu / selu: bias was added in the epilogue
         if self.nonlinearity is _nl.softmax:
             import torch
             amax = torch.empty(y.n, dtype=torch.int32, device=y.device)

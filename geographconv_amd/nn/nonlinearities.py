@@ -7,8 +7,9 @@ from __future__ import annotations
 
 
 class Nonlinearity:
-    def __init__(self, name, act):
-        self.name, self.act = name, act
+    def __init__(self, name, act, fusable=True):
+        # act: GEOGCN_ACT_* code (None: needs its own kernel); fusable: available as a GEMM / SpMM epilogue
+        self.name, self.act, self.fusable = name, act, fusable
 
     def __repr__(self):
         return "<nonlinearity %s>" % self.name
@@ -19,8 +20,8 @@ identity = linear
 tanh = Nonlinearity('tanh', 1)
 sigmoid = Nonlinearity('sigmoid', 2)
 softmax = Nonlinearity('softmax', None)        # row softmax: geogcn_softmax_rows_f32
-rectify = Nonlinearity('rectify', None)        # commented out in the reference (gcnmodel.py:345)
-selu = Nonlinearity('selu', None)              # only in the unused residual_dense (gcnmodel.py:290)
+rectify = Nonlinearity('rectify', 4, fusable=False)   # commented out in the reference (gcnmodel.py:345)
+selu = Nonlinearity('selu', 3, fusable=False)         # only in the unused residual_dense (gcnmodel.py:290)
 
 
 def resolve(nl):

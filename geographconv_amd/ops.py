@@ -13,7 +13,7 @@ import scipy.sparse as sps
 import torch
 
 from . import _ffi
-from ._ffi import ACT_NONE, ACT_SIGMOID, ACT_TANH, check  # noqa: F401
+from ._ffi import ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_TANH, check  # noqa: F401
 
 
 def pad4(F: int) -> int:

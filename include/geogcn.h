@@ -39,6 +39,9 @@ extern "C" {
 #define GEOGCN_ACT_NONE    0   /* linear (softmax layers keep logits; softmax is its own entry) */
 #define GEOGCN_ACT_TANH    1   /* lasagne.nonlinearities.tanh     gcnmodel.py:347 */
 #define GEOGCN_ACT_SIGMOID 2   /* T.nnet.sigmoid                  gcnmodel.py:286 */
+/* elementwise entry points only (geogcn_bias_act_f32 / geogcn_act_bwd_f32), not fused epilogues: */
+#define GEOGCN_ACT_SELU    3   /* lasagne.nonlinearities.selu     gcnmodel.py:290 (residual_dense) */
+#define GEOGCN_ACT_RELU    4   /* lasagne.nonlinearities.rectify  gcnmodel.py:345 (commented out)  */
 
 int         geogcn_version(void);
 const char* geogcn_last_error(void);

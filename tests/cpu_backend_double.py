@@ -22,6 +22,10 @@ def _act(x, act):
         return np.tanh(x)
     if act == ACT_SIGMOID:
         return (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+    if act == 3:
+        return (1.0507009873554805 * np.where(x > 0, x, 1.6732632423543772 * (np.exp(x) - 1))).astype(np.float32)
+    if act == 4:
+        return np.maximum(x, 0)
     return x
 
 

@@ -187,11 +187,26 @@ def test_layer_zoo_variants_match_oracle(cmu):
     # sparse-input layers reject dense input like the reference (gcnmodel.py:34-36,82-84,236-238)
     with pytest.raises(ValueError):
         L.get_output(l, {l_in: H}, A=A)
-    # residual_dense builds, but its SELU has no kernel yet
+    # residual_dense (gcnmodel.py:290-294): selu(A.(H.W) + b + H), forward and backward
+    np.random.seed(3)
     r = M.residual_dense(d_in)
     L.ParamStore(L.get_all_params(r), dev)
-    with pytest.raises(NotImplementedError):
-        L.get_output(r, {d_in: H}, A=A)
+    Wr, br = L.get_all_param_values(r)
+    tape = {}
+    yr = L.get_output(r, {d_in: H}, tape=tape, A=A)
+    pre = O.spmm(c['A'], ref @ Wr) + br + ref
+    sel = 1.0507009873554805 * np.where(pre > 0, pre, 1.6732632423543772 * (np.exp(pre) - 1))
+    assert np.abs(yr.numpy() - sel).max() < 5e-5
+    Gr = rng.randn(*sel.shape).astype(np.float32)
+    L.backward(r, ops.DMat.from_numpy(Gr, dev), tape, A=A)
+    dpre = Gr * np.where(pre > 0, 1.0507009873554805, sel + 1.0507009873554805 * 1.6732632423543772)
+    dWr = ref.T @ O.spmm_t(c['A'], dpre)
+    got = L.get_all_params(r)[0]._store.read_grad(L.get_all_params(r)[0])
+    assert np.abs(got - dWr).max() <= 2e-4 * np.abs(dWr).max()
+    # rectify as a layer nonlinearity (the reference's commented-out alternative, gcnmodel.py:345)
+    l5 = M.ConvolutionDenseLayer2(d_in, num_units=32, W=W2, b=None, nonlinearity=NL.rectify)
+    L.ParamStore(L.get_all_params(l5), dev)
+    assert np.abs(L.get_output(l5, {d_in: H}, A=A).numpy() - np.maximum(O.spmm(c['A'], ref @ W2), 0)).max() < 2e-5
 
 
 def test_config5_bf16_six_layer_600_hidden():
