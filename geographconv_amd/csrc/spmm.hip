@@ -459,7 +459,7 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
     hipStream_t st = (hipStream_t)stream;
     const int F4 = (F + 3) / 4;
     const bool vec_ok = (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
-                        ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 10;
+                        ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 16;      // F <= 1024
     if (!vec_ok) {
         const dim3 grid((unsigned)cdiv(n_rows, kBlock / kWave));
 #define GEOGCN_SC(ACT)                                                                              \
@@ -494,6 +494,12 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
         GEOGCN_CASE(8)
         GEOGCN_CASE(9)
         GEOGCN_CASE(10)
+        GEOGCN_CASE(11)     // hid 700..1024: the WORLD configuration of the reference uses 900 (README.md:180)
+        GEOGCN_CASE(12)
+        GEOGCN_CASE(13)
+        GEOGCN_CASE(14)
+        GEOGCN_CASE(15)
+        GEOGCN_CASE(16)
 #undef GEOGCN_CASE
         default:
             break;

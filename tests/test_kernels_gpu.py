@@ -46,7 +46,7 @@ def _skewed_csr(n_rows, n_cols, seed, hub_nnz=3000, empty_every=7):
     return m
 
 
-@pytest.mark.parametrize("F", [1, 5, 64, 129, 256, 300, 600])
+@pytest.mark.parametrize("F", [1, 5, 64, 129, 256, 300, 600, 900])
 @pytest.mark.parametrize("act,use_bias", [(0, False), (1, True)])
 def test_spmm_matches_oracle(dev, F, act, use_bias):
     from geographconv_amd import ops
