@@ -342,6 +342,25 @@ class GraphConv():
         self._idx_cache = {}
         return hit
 
+    def _train_columns_operand(self, g, A, train_indices):
+        """CSR of A^T restricted to the columns in `train_indices` (cached per graph and index set)."""
+        idx = np.asarray(train_indices)
+        key = (idx.ctypes.data, len(idx), int(idx.sum()))
+        hit = g.get('A_tr')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        At = sps.csr_matrix(sps.csr_matrix(A).T).astype(np.float32)
+        keep = np.zeros(At.shape[1], dtype=bool)
+        keep[idx] = True
+        sel = keep[At.indices]
+        row_of = np.repeat(np.arange(At.shape[0], dtype=np.int64), np.diff(At.indptr))
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(row_of[sel], minlength=At.shape[0]))])
+        M = sps.csr_matrix((At.data[sel], At.indices[sel], indptr.astype(np.int32)), shape=At.shape)
+        op = g['comm'].graph_operand(M, hub_row_bytes=None) if self._dist(g['comm']) else None
+        csr = op.fwd if op is not None else backend.active().CSR(M, self.device)
+        g['A_tr'] = (key, csr)
+        return csr
+
     def _device_indices(self, comm, idx, y=None):
         """Index / label vectors on the device (local share when distributed) + the global count."""
         import torch
@@ -396,7 +415,9 @@ class GraphConv():
         # backward: d(mean CE over train rows)/d logits, then the reverse sweep
         dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr),
                                    out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)))
-        L.backward(self.l_out, L.PreAct(dlogits), tape, **kw)
+        # dlogits is zero outside the training rows: A^T . dlogits only needs the training COLUMNS of A^T
+        kw_b = dict(kw, A_bwd_rows_hint=(self.l_out, self._train_columns_operand(g, A, train_indices)))
+        L.backward(self.l_out, L.PreAct(dlogits), tape, **kw_b)
         if self._dist(comm):
             comm.all_reduce_sum_(self.store.g)
             comm.all_reduce_sum_(sc[0:4])

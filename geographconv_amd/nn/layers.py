@@ -307,12 +307,18 @@ class DenseLayer(Layer):
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
         if A is not None:
             comm = kwargs.get('comm')
+            A_bwd = A.bwd
+            # structural zeros: when the incoming gradient is known to be zero outside a set of rows (the CE
+            # gradient lives on the training rows only), the caller may pass A^T with the other COLUMNS removed
+            hint = kwargs.get('A_bwd_rows_hint')
+            if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
+                A_bwd = hint[1]
             if comm is None:
-                dZ = K.spmm(A.bwd, dS)
+                dZ = K.spmm(A_bwd, dS)
             else:
                 g = comm.matmul_target(self.num_units, tag='bwd')
                 g.copy_from(dS)
-                dZ = comm.graph_spmm(A.bwd, g, None, 0, self.num_units, tag='bwd')
+                dZ = comm.graph_spmm(A_bwd, g, None, 0, self.num_units, tag='bwd')
         else:
             dZ = dS
         if isinstance(x, K.DMat):
