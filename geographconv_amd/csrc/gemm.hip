@@ -37,17 +37,33 @@ struct KStrided {                   // BK rows x Ccols floats, pitch Ccols + 4
     static constexpr int kIters = (BK * kF4PerRow) / TPB;   // Ccols multiple of 32 => exact
 };
 
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64_t idx, int64_t lim4, bool row_ok) {
-    // One predicated 16-byte load, no scalar tail: `lim4` is the limit of the contiguous dimension
-    // rounded UP to a multiple of 4 (<= ld), so a float4 is either wholly inside or wholly outside.
-    // Elements in [lim, lim4) are pad columns, which are zero by the geogcn.h convention.
-    // (A branchy tail here made hipcc put s_waitcnt vmcnt(0) in front of every load of the tile.)
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row_ok && idx < lim4) r = *reinterpret_cast<const float4*>(p + idx);
-    return r;
+// ---- global -> registers ----------------------------------------------------------------------
+// Buffer loads (raw, stride 0): the descriptor is rebased on the tile / stage origin, so that
+//   * rows past the end of the operand (M tail, K tail of a k-strided operand, end of a split-K chunk) lie
+//     beyond num_records and read as 0 in hardware -- no exec-masked branches, straight-line code, and the
+//     compiler can count its vmcnt waits exactly;
+//   * the per-lane offset is a loop-invariant 32-bit VGPR (no 64-bit address arithmetic per load);
+//   * operands larger than 4 GB work: only the distance from the tile origin must fit 31 bits.
+// The contiguous dimension is guarded by swapping the offset for one that is out of range: its limit is
+// rounded UP to a multiple of 4 (<= ld), so a float4 is wholly inside or wholly outside; elements in
+// [lim, lim4) are pad columns, which are zero by the geogcn.h convention.
+constexpr uint32_t kOobOffset = 0x80000000u;     // > any num_records we ever set (clamped to 2^31 - 1)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, int64_t bytes) {
+    // base and bytes depend on blockIdx and loop counters only; readfirstlane states that uniformity for the
+    // compiler (a descriptor it cannot prove uniform is loaded through a per-lane "waterfall" loop)
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    // (readfirstlane returns int: go through uint32_t, or the low word is sign-extended into the high one)
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+__device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// ---- global -> registers ----------------------------------------------------------------------
 // k-contiguous operand: memory [R_total][K] row-major (ld), tile rows r0.., k range k0..k0+31
 template <int R>
 __device__ __forceinline__ void gload_kcontig(float4 (&reg)[KContig<R>::kIters], const float* __restrict__ P,
@@ -55,10 +71,13 @@ __device__ __forceinline__ void gload_kcontig(float4 (&reg)[KContig<R>::kIters],
     const int tid = threadIdx.x;
     const int f4 = tid & 7;
     const int rr = tid >> 3;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + r0 * ld + k0, ((Rtot - r0) * ld - k0) * 4);
+    const bool k_ok = k0 + f4 * 4 < ((Kend + 3) & ~(int64_t)3);
+    const uint32_t ld4 = (uint32_t)ld * 4u;
 #pragma unroll
     for (int i = 0; i < KContig<R>::kIters; ++i) {
-        const int64_t row = r0 + rr + 32 * i;
-        reg[i] = load4_guard(P + row * ld, k0 + f4 * 4, (Kend + 3) & ~(int64_t)3, row < Rtot);
+        const uint32_t off = (uint32_t)(rr + 32 * i) * ld4 + (uint32_t)f4 * 16u;
+        reg[i] = buffer_load4(rs, k_ok ? off : kOobOffset);
     }
 }
 template <int R>
@@ -76,13 +95,16 @@ __device__ __forceinline__ void gload_kstrided(float4 (&reg)[KStrided<Ccols>::kI
                                                int64_t ld, int64_t c0, int64_t Ctot, int64_t k0, int64_t Kend) {
     const int tid = threadIdx.x;
     constexpr int F4R = KStrided<Ccols>::kF4PerRow;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + k0 * ld + c0, ((Kend - k0) * ld - c0) * 4);
+    const int64_t c_lim = ((Ctot + 3) & ~(int64_t)3) - c0;       // valid columns of this tile (multiple of 4)
+    const uint32_t ld4 = (uint32_t)ld * 4u;
 #pragma unroll
     for (int i = 0; i < KStrided<Ccols>::kIters; ++i) {
         const int e = tid + TPB * i;
         const int kr = e / F4R;
         const int c4 = e % F4R;
-        const int64_t k = k0 + kr;
-        reg[i] = load4_guard(P + k * ld, c0 + c4 * 4, (Ctot + 3) & ~(int64_t)3, k < Kend);
+        const uint32_t off = (uint32_t)kr * ld4 + (uint32_t)c4 * 16u;
+        reg[i] = buffer_load4(rs, c4 * 4 < c_lim ? off : kOobOffset);
     }
 }
 template <int Ccols>
@@ -121,16 +143,16 @@ struct GemmArgs {
     int n_mt, n_nt, n_split, xcd_order;
 };
 
+// Tile coordinates are wave-uniform (functions of blockIdx and loop counters); readfirstlane keeps them in
+// SGPRs so that everything derived from them (buffer descriptors, loop control) is scalar code.
 struct TileCoord {
-    int64_t m0, n0, kbeg, kend;
-    int nk, z;
-    bool valid;
+    int mt, nt, z, nk;      // nk == 0: past the end of this block's list
 };
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Persistent blocks: block p walks its tile list p, p+G, ... (XCD-aware: the blocks of one XCD walk the
 // N tiles / K slices of the same M tiles concurrently, so the A panel is shared through that XCD's L2).
-__device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int BM, int BN, int p, int G, int j) {
-    TileCoord t;
+__device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int p, int G, int j) {
     int mt, nt, z;
     if (a.xcd_order) {
         const int x = p % kNumXCD, q = p / kNumXCD, Q = G / kNumXCD;
@@ -147,23 +169,28 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int BM, int 
         z = (int)(rest / a.n_mt);
         if (z >= a.n_split) mt = a.n_mt;           // past the end
     }
-    t.valid = mt < a.n_mt;
-    t.m0 = (int64_t)mt * BM;
-    t.n0 = (int64_t)nt * BN;
-    t.z = z;
-    t.kbeg = (int64_t)z * a.kchunk;
-    t.kend = min(a.K, t.kbeg + a.kchunk);
-    t.nk = t.valid ? (int)((t.kend - t.kbeg + BK - 1) / BK) : 0;
-    if (t.nk <= 0) t.valid = false;
+    TileCoord t;
+    t.mt = uni(mt);
+    t.nt = uni(nt);
+    t.z = uni(z);
+    const int64_t kbeg = (int64_t)t.z * a.kchunk;
+    const int64_t kend = min(a.K, kbeg + a.kchunk);
+    int nk = (t.mt < a.n_mt) ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+    t.nk = uni(nk < 0 ? 0 : nk);
     return t;
 }
 
 // MODE 0: C = act(acc + bias) [+ C if accumulate];  MODE 1: split-K slab z (raw partial sums)
-// The k-loop is FLATTENED across the block's tiles: the global loads of stage s+1 are always in
-// flight during the MFMAs of stage s, also across a tile boundary, so the short K = 300 contractions
-// of the GCN (10 stages per tile) pay no per-tile prologue.
-template <int BM, int BN, bool AT, bool BT, int ACT, int MODE>
+// The k-loop is FLATTENED across the block's tiles: the global loads of stage s+2 are always in flight
+// during the MFMAs of stage s, also across a tile boundary, so the short K = 300 contractions of the GCN
+// (10 stages per tile) pay no per-tile prologue.  The loop body is branch-free apart from wave-uniform
+// control (K tail, epilogue, tile advance): loads past the end of the list use an empty buffer descriptor
+// (they return zeros) and their LDS image is written but never multiplied, so the compiler can count its
+// vmcnt waits exactly instead of draining the memory pipeline at control-flow joins.
+template <int BM, int BN, bool AT, bool BT, int ACT, int MODE, int PROBE = 0>
 __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
+    // PROBE (tools/micro/gemm_variants.hip only; 0 in the library): 1 = no global loads, 2 = no C stores,
+    // 4 = no K-tail early-out, 8 = no LDS stores
     using Cfg = GemmCfg<BM, BN, AT, BT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int p = blockIdx.x, G = gridDim.x;
@@ -183,11 +210,16 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
     // the global loads of stage s+2 land in the other (two stages of HBM latency tolerance)
     float4 ra0[Cfg::kAIters], rb0[Cfg::kBIters], ra1[Cfg::kAIters], rb1[Cfg::kBIters];
     auto gload = [&](float4 (&ra)[Cfg::kAIters], float4 (&rb)[Cfg::kBIters], const TileCoord& t, int kt) {
-        const int64_t k0 = t.kbeg + (int64_t)kt * BK;
-        if constexpr (AT) gload_kstrided<BM>(ra, a.A, a.lda, t.m0, a.M, k0, t.kend);
-        else gload_kcontig<BM>(ra, a.A, a.lda, t.m0, a.M, k0, t.kend);
-        if constexpr (BT) gload_kcontig<BN>(rb, a.B, a.ldb, t.n0, a.N, k0, t.kend);
-        else gload_kstrided<BN>(rb, a.B, a.ldb, t.n0, a.N, k0, t.kend);
+        const int64_t kbeg = (int64_t)t.z * a.kchunk;
+        // past the end of the list (nk == 0): kend = k0 makes every descriptor empty
+        const int64_t k0 = kbeg + (int64_t)kt * BK;
+        const int64_t kend = t.nk > 0 ? min(a.K, kbeg + a.kchunk) : k0;
+        const int64_t m0 = (int64_t)t.mt * BM, n0 = (int64_t)t.nt * BN;
+        const int64_t Mlim = t.nk > 0 ? a.M : 0, Nlim = t.nk > 0 ? a.N : 0;
+        if constexpr (AT) gload_kstrided<BM>(ra, a.A, a.lda, m0, Mlim, k0, kend);
+        else gload_kcontig<BM>(ra, a.A, a.lda, m0, Mlim, k0, kend);
+        if constexpr (BT) gload_kcontig<BN>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
+        else gload_kstrided<BN>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
     };
     auto sstore = [&](int buf, const float4 (&ra)[Cfg::kAIters], const float4 (&rb)[Cfg::kBIters]) {
         float* As = smem + buf * Cfg::kStageFloats;
@@ -199,32 +231,34 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
     };
 
     int cj = 0, ckt = 0;                     // compute cursor (tile index in my list, stage)
-    TileCoord ct = decode_tile(a, BM, BN, p, G, 0);
-    if (!ct.valid) return;
+    TileCoord ct = decode_tile(a, p, G, 0);
+    if (ct.nk == 0) return;
     int lj = 0, lkt = 0;                     // load cursor
     TileCoord lt = ct;
     auto advance_load = [&]() {
-        if (++lkt == lt.nk) { lt = decode_tile(a, BM, BN, p, G, ++lj); lkt = 0; }
+        if (lt.nk == 0) return;
+        if (++lkt == lt.nk) { lt = decode_tile(a, p, G, ++lj); lkt = 0; }
     };
     gload(ra0, rb0, lt, 0);
     sstore(0, ra0, rb0);
     advance_load();
-    bool pending = lt.valid;                 // stage s+1 sits in a register set, not yet in LDS
-    if (pending) { gload(ra1, rb1, lt, lkt); advance_load(); }
+    gload(ra1, rb1, lt, lkt);                // stage 1 (zeros if there is none)
+    advance_load();
     __syncthreads();
     int cur = 0;
-    bool running = true;
     // one pipeline step; (la, lb) = set to load stage s+2 into, (sa, sb) = set holding stage s+1
     auto step = [&](float4 (&la)[Cfg::kAIters], float4 (&lb)[Cfg::kBIters], const float4 (&sa)[Cfg::kAIters],
                     const float4 (&sb)[Cfg::kBIters]) {
-        const bool have_load = lt.valid;
-        if (have_load) gload(la, lb, lt, lkt);
+        if (!(PROBE & 1)) gload(la, lb, lt, lkt);
+        advance_load();
         const float* As = smem + cur * Cfg::kStageFloats;
         const float* Bs = As + Cfg::kAFloats;
-        const int64_t k_stage = ct.kbeg + (int64_t)ckt * BK;
+        const int64_t ckbeg = (int64_t)ct.z * a.kchunk;
+        const int64_t ckend = min(a.K, ckbeg + a.kchunk);
+        const int64_t k_stage = ckbeg + (int64_t)ckt * BK;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-            if (kk > 0 && k_stage + kk >= ct.kend) break;      // K tail: nothing but zero padding left
+            if (!(PROBE & 4) && kk > 0 && k_stage + kk >= ckend) break;      // K tail: nothing but zero padding left
             float af[Cfg::MR][4], bf[Cfg::NR][4];
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
@@ -254,69 +288,83 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
                 for (int i = 0; i < Cfg::MR; ++i)
 #pragma unroll
                     for (int jn = 0; jn < Cfg::NR; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[jn][t], acc[i][jn], 0, 0, 0);
+                        // operands swapped (the 16x16 product is computed transposed): a lane then owns 4
+                        // CONSECUTIVE COLUMNS of one row of C, and the epilogue stores float4s
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[jn][t], af[i][t], acc[i][jn], 0, 0, 0);
         }
+        // stage s+1: registers -> the other LDS buffer.  BEFORE the epilogue's stores in program order, so
+        // that the wait for these registers never has to drain the C stores behind them.
+        if (!(PROBE & 8)) sstore(cur ^ 1, sa, sb);
         if (ckt == ct.nk - 1) {
-            // epilogue of this tile: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+            // epilogue of this tile.  With the swapped operands the accumulator of lane (li, lg) holds
+            // C[row = li][col = 4*lg + r], r = 0..3, of each 16x16 sub-tile: one float4 per sub-tile.
+            // Columns in [N, roundup4(N)) are pad columns and are written as zeros (geogcn.h convention).
             float* Cout = a.C;
             if constexpr (MODE == 1) Cout = a.C + (int64_t)ct.z * a.M * a.ldc;
-            // all loads of the epilogue (bias, old C when accumulating) are issued as independent
-            // batches before their first use -- no load/wait/store chains
-            float bcol[Cfg::NR];
+            const int64_t m0 = (int64_t)ct.mt * BM, n0 = (int64_t)ct.nt * BN;
+            float bcol[Cfg::NR][4];
 #pragma unroll
             for (int jn = 0; jn < Cfg::NR; ++jn) {
-                const int64_t col = ct.n0 + wn * (BN / 2) + jn * 16 + li;
-                bcol[jn] = 0.f;
-                if constexpr (MODE == 0) {
-                    if (a.bias && col < a.N) bcol[jn] = a.bias[col];
+                const int64_t col0 = n0 + wn * (BN / 2) + jn * 16 + lg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bcol[jn][r] = 0.f;
+                    if constexpr (MODE == 0) {
+                        if (a.bias && col0 + r < a.N) bcol[jn][r] = a.bias[col0 + r];
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
-                const int64_t row0 = ct.m0 + wm * (BM / 2) + i * 16 + lg * 4;
-                float oldv[Cfg::NR][4];
+                const int64_t row = m0 + wm * (BM / 2) + i * 16 + li;
+                float* crow = Cout + row * a.ldc;
+                const bool row_ok = row < a.M;
+                // all loads of the epilogue (bias above, old C when accumulating) are issued as independent
+                // batches before their first use -- no load/wait/store chains
+                float4 oldv[Cfg::NR];
                 if constexpr (MODE == 0) {
                     if (a.accumulate) {
 #pragma unroll
                         for (int jn = 0; jn < Cfg::NR; ++jn) {
-                            const int64_t col = ct.n0 + wn * (BN / 2) + jn * 16 + li;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                oldv[jn][r] = (row0 + r < a.M && col < a.N) ? Cout[(row0 + r) * a.ldc + col] : 0.f;
+                            const int64_t col0 = n0 + wn * (BN / 2) + jn * 16 + lg * 4;
+                            oldv[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (row_ok && col0 < a.N) oldv[jn] = *reinterpret_cast<const float4*>(crow + col0);
                         }
                     }
                 }
 #pragma unroll
                 for (int jn = 0; jn < Cfg::NR; ++jn) {
-                    const int64_t col = ct.n0 + wn * (BN / 2) + jn * 16 + li;
+                    const int64_t col0 = n0 + wn * (BN / 2) + jn * 16 + lg * 4;
+                    float x[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x = acc[i][jn][r];
-                        if constexpr (MODE == 0) {
-                            x = apply_act<ACT>(x + bcol[jn]);
-                            if (a.accumulate) x += oldv[jn][r];
-                        }
-                        if (row0 + r < a.M && col < a.N) Cout[(row0 + r) * a.ldc + col] = x;
+                        x[r] = acc[i][jn][r];
+                        if constexpr (MODE == 0) x[r] = apply_act<ACT>(x[r] + bcol[jn][r]);
                     }
+                    if constexpr (MODE == 0) {
+                        if (a.accumulate) { x[0] += oldv[jn].x; x[1] += oldv[jn].y; x[2] += oldv[jn].z; x[3] += oldv[jn].w; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r >= a.N) x[r] = 0.f;
+                    if ((PROBE & 2) ? (x[0] == 123.456f) : (row_ok && col0 < a.N))
+                        *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
                     acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
-        if (pending) sstore(cur ^ 1, sa, sb);
         __syncthreads();
         cur ^= 1;
         if (++ckt == ct.nk) {
-            ct = decode_tile(a, BM, BN, p, G, ++cj);
+            ct = decode_tile(a, p, G, ++cj);
             ckt = 0;
-            if (!ct.valid) running = false;
         }
-        pending = have_load;
-        if (have_load) advance_load();
     };
-    while (running) {
+    while (true) {
         step(ra0, rb0, ra1, rb1);            // set 1 holds s+1, set 0 is free for s+2
-        if (!running) break;
+        if (ct.nk == 0) break;
         step(ra1, rb1, ra0, rb0);
+        if (ct.nk == 0) break;
     }
 }
 
@@ -394,7 +442,7 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
         return 0;
     }
     // split-K slabs into the workspace, then the ordered combine
-    const int64_t ldw = N;
+    const int64_t ldw = (N + 3) & ~(int64_t)3;      // slabs are stored as float4s
     const size_t need = (size_t)sp.nsplit * (size_t)M * (size_t)ldw * sizeof(float);
     GEOGCN_REQUIRE(ws && ws_bytes >= need, GEOGCN_E_ARG, "gemm_f32: split-K workspace too small (%zu < %zu)",
                    ws_bytes, need);
@@ -449,7 +497,7 @@ int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float*
 template <int BM, int BN>
 size_t splitk_ws_bytes(int64_t M, int64_t N, int64_t K) {
     const SplitPlan sp = plan_grid<BM, BN, true, false>(M, N, K);
-    return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)N * sizeof(float);
+    return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)((N + 3) & ~(int64_t)3) * sizeof(float);
 }
 
 }  // namespace
@@ -485,9 +533,10 @@ int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
     GEOGCN_REQUIRE(lda >= a_cols && ldb >= b_cols && ldc >= N, GEOGCN_E_SIZE,
                    "gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda,
                    (long long)ldb, (long long)ldc);
-    GEOGCN_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B), GEOGCN_E_ALIGN,
-                   "gemm_f32: operands need 16-byte aligned bases and ld %% 4 == 0 (lda=%lld ldb=%lld)",
-                   (long long)lda, (long long)ldb);
+    GEOGCN_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C),
+                   GEOGCN_E_ALIGN,
+                   "gemm_f32: A, B, C need 16-byte aligned bases and ld %% 4 == 0 (lda=%lld ldb=%lld ldc=%lld)",
+                   (long long)lda, (long long)ldb, (long long)ldc);
     hipStream_t st = (hipStream_t)stream;
     if (!transA && precision != GEOGCN_GEMM_F32 && K > 0)
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);

@@ -92,7 +92,9 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  * accumulate=1 adds into C (C += ...), used for dH += dZ.Wh^T + dU.Wt^T.
  * Operands are read in whole float4s: when a contiguous dimension (K for a non-transposed A or a
  * transposed B) is not a multiple of 4, its pad columns up to the next multiple of 4 MUST be zero
- * (the convention every producer in this library keeps).
+ * (the convention every producer in this library keeps).  C is written in whole float4s as well:
+ * A, B and C need 16-byte aligned bases and leading dimensions that are multiples of 4 (GEOGCN_E_ALIGN
+ * otherwise); C's pad columns [N, roundup4(N)) are written as zeros.
  * transA=1 reduces over the long dimension: it runs split-K into `ws` (see
  * geogcn_gemm_workspace_bytes) and combines the slabs in fixed order (deterministic).
  *
