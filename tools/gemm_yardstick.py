@@ -40,6 +40,11 @@ def timed(fn, reps=20):
 
 
 flops = 2.0 * N * F * F
+# clock ramp: the first ~20 ms after an idle period run ~10 % slow (measured: the first timed case of a
+# process is always the slowest, whatever it is) -- burn 200 launches before timing anything
+for _ in range(200):
+    ops.gemm(H, W, out=Z)
+torch.cuda.synchronize()
 out_v = torch.empty_like(Zt)
 out_w = torch.empty(F, F, device=dev)
 cases = [
@@ -51,3 +56,21 @@ print("N=%d F=%d  (%.1f GFLOP per product)" % (N, F, flops / 1e9))
 for name, ours, vendor in cases:
     t1, t2 = timed(ours), timed(vendor)
     print("%-18s libgeogcn %.3f ms (%.1f TF)   torch.mm %.3f ms (%.1f TF)" % (name, t1, flops / t1 / 1e9, t2, flops / t2 / 1e9))
+
+# layout experiments: line-aligned pitch (320) for the streamed operands; NN through the NT kernel on a
+# pre-transposed W
+H320 = ops.DMat.empty(N, F, dev, ld=ops.gather_ld(F)); H320.copy_from(H)
+Z320 = ops.DMat.empty(N, F, dev, ld=ops.gather_ld(F)); Z320.copy_from(Z)
+WT = ops.DMat.from_numpy(np.ascontiguousarray(W.numpy().T), dev)
+for name, fn in [
+    ('NN ld 320 -> 320', lambda: ops.gemm(H320, W, out=Z320)),
+    ('NN ld 300 -> 320', lambda: ops.gemm(H, W, out=Z320)),
+    ('NN ld 320 -> 300', lambda: ops.gemm(H320, W, out=Z)),
+    ('NN as NT(H, W^T) 300 -> 300', lambda: ops.gemm(H, WT, out=Z, transB=True)),
+    ('NN as NT(H, W^T) 320 -> 320', lambda: ops.gemm(H320, WT, out=Z320, transB=True)),
+    ('NT ld 320 -> 320', lambda: ops.gemm(Z320, W, out=H320, transB=True)),
+    ('TN ld 320', lambda: ops.gemm(H320, Z320, out=dW, transA=True)),
+]:
+    t = timed(fn)
+    print("%-30s %.3f ms (%.1f TF)" % (name, t, flops / t / 1e9))
+
