@@ -237,6 +237,26 @@ def test_gemm_rejects_bad_arguments(dev):
     assert rc in (-2, -3)
 
 
+def test_sigmoid_epilogue_accuracy(dev):
+    """The gate nonlinearity (T.nnet.sigmoid, gcnmodel.py:286) is evaluated with v_exp_f32 / v_rcp_f32 on
+    a range-reduced argument: <= 3 ulp of the fp64 result over the whole float range, exact limits."""
+    from geographconv_amd import ops
+    x = np.concatenate([np.linspace(-40, 40, 200001), _rand((100000,), 5) * 6, [0.0, -0.0, 87.0, -87.0, 88.8, -88.8,
+                        103.0, -103.9, 150.0, -150.0, 1e4, -1e4, 3e38, -3e38, np.inf, -np.inf]]).astype(np.float32)
+    n = x.size // 4 * 4
+    x = x[-n:].reshape(-1, 4)
+    got = ops.bias_act(ops.DMat.from_numpy(x, dev), None, ops.ACT_SIGMOID).numpy().astype(np.float64)
+    with np.errstate(over='ignore'):
+        ref = 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+    fin = ref > 1e-37                     # below: fp32 denormals, flushed (the reference's exp underflows too)
+    assert np.all(np.abs(got - ref)[fin] <= 3 * ulp[fin])
+    assert np.all(got[~fin] <= 2e-37) and np.all(got >= 0) and np.all(got <= 1)
+    assert got[x == np.inf].min() == 1.0 and got[x == -np.inf].max() == 0.0
+    nan = ops.bias_act(ops.DMat.from_numpy(np.full((1, 4), np.nan, np.float32), dev), None, ops.ACT_SIGMOID).numpy()
+    assert np.all(np.isnan(nan))
+
+
 @pytest.mark.parametrize("n,F", [(1000, 300), (257, 129), (3, 5)])
 def test_highway_and_tanh_kernels(dev, n, F):
     from geographconv_amd import ops
