@@ -59,6 +59,27 @@ __global__ __launch_bounds__(TPB) void bias_act_kernel(int64_t n, int F, int F4,
     }
 }
 
+// fp32 -> bfloat16, round to nearest even (NaN stays NaN); whole pitch of Y written, pads as zeros
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // quiet NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ __launch_bounds__(TPB) void cast_bf16_kernel(int64_t n, int F, int Y4, const float* __restrict__ X, int64_t ldx,
+                                                        uint16_t* __restrict__ Y, int64_t ldy) {
+    const int64_t total = n * Y4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t row = e / Y4;
+        const int c0 = (int)(e - row * Y4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 < F) v = *reinterpret_cast<const float4*>(X + row * ldx + c0);      // X pads are zero by convention
+        uint2 o;
+        o.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
+        o.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+        *reinterpret_cast<uint2*>(Y + row * ldy + c0) = o;
+    }
+}
+
 // Hout = T*Hc + (1-T)*H   (gcnmodel.py:266, same association as the reference expression)
 __global__ __launch_bounds__(TPB) void highway_fwd_kernel(int64_t total4, const float4* __restrict__ T,
                                                           const float4* __restrict__ Hc,
@@ -364,6 +385,21 @@ int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const
         return GEOGCN_E_ARG;
     }
     GEOGCN_LAUNCH_CHECK("bias_act_kernel");
+    return 0;
+}
+
+int geogcn_cast_bf16_f32(int64_t n, int32_t F, const float* X, int64_t ldx, uint16_t* Y, int64_t ldy, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "cast_bf16_f32: negative size");
+    if (n == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(X && Y, GEOGCN_E_NULL, "cast_bf16_f32: null pointer");
+    const int64_t F4 = (F + 3) / 4 * 4;
+    GEOGCN_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= F4 && ldy >= F4 && aligned16(X) && aligned16(Y), GEOGCN_E_ALIGN,
+                   "cast_bf16_f32: needs 16-byte aligned bases and ld %% 4 == 0, >= roundup4(F) (ldx=%lld ldy=%lld)",
+                   (long long)ldx, (long long)ldy);
+    const int Y4 = (int)(ldy / 4);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(stream_grid(n * Y4)), dim3(TPB), 0, (hipStream_t)stream, n, F, Y4, X, ldx, Y,
+                       ldy);
+    GEOGCN_LAUNCH_CHECK("cast_bf16_kernel");
     return 0;
 }
 

@@ -43,21 +43,51 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // NT = 1: non-temporal gather (global_load ... nt): the line is streamed through the L2 without
 // displacing the lines loaded with the default policy (measured: tools/micro/nt_retention.hip).
 template <int NT>
-__device__ __forceinline__ float4 gather4(const float4* p) {
-    if constexpr (NT) {
-        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
-        return make_float4(v.x, v.y, v.z, v.w);
-    } else {
-        return *p;
-    }
+__device__ __forceinline__ float4 gather4(const void* row, int q) {
+    const f32x4v* p = reinterpret_cast<const f32x4v*>(row) + q;
+    f32x4v v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// BF = 1: the gathered operand is stored as bfloat16.  A lane still loads 16 bytes per pass -- now 8
+// features, unpacked into TWO float4 accumulators -- because this kernel's ceiling counts 64-lane load
+// instructions in flight, not bytes: a first version with 8-byte loads (4 features per lane and pass) moved
+// half the bytes per instruction and ran no faster than fp32 (1.93 vs 1.98 ms at F = 300).
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ u32x4v gather8_bf16(const void* row, int q8) {
+    const u32x4v* p = reinterpret_cast<const u32x4v*>(row) + q8;
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+// a * (8 bf16 features) accumulated into two float4s; the raw 16 bytes stay packed until here, so that the
+// loads in flight cost 4 VGPRs each, not 8
+__device__ __forceinline__ void fma8_bf16(float4& lo, float4& hi, float a, const u32x4v v) {
+    fma4(lo, a, make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                            __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)));
+    fma4(hi, a, make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                            __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)));
+}
+// float4 index (within the output row) of accumulator k of lane `lane`: fp32 -> pass k covers float4s
+// lane + G*k; bf16 -> accumulators 2j, 2j+1 are the two halves of the 8 features of pass j
+template <int G, int BF>
+__device__ __forceinline__ int f4_index(int lane, int k) {
+    if constexpr (BF) return 2 * (lane + G * (k >> 1)) + (k & 1);
+    else return lane + G * k;
+}
+template <int BF>
+__device__ __forceinline__ const void* row_ptr(const void* B, int64_t ldb, int c) {
+    if constexpr (BF) return reinterpret_cast<const uint16_t*>(B) + (int64_t)c * ldb;
+    else return reinterpret_cast<const float*>(B) + (int64_t)c * ldb;
 }
 
 // One group walks nonzeros [s, e) and accumulates into acc[K4].
-template <int K4, int NT = 0, int G = kGroup>
+template <int K4, int NT, int G, int BF>
 __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int nF4,
                                                  const int* __restrict__ colidx,
                                                  const float* __restrict__ val,
-                                                 const float* __restrict__ B, int64_t ldb,
+                                                 const void* __restrict__ B, int64_t ldb,
                                                  float4 (&acc)[K4]) {
     for (int base = s; base < e; base += G) {
         const int j = base + lane16;
@@ -69,40 +99,68 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
         }
         const int cnt = min(G, e - base);
         int t = 0;
-        // two nonzeros per trip: 2*K4 independent 16-byte loads in flight per lane
+        // two nonzeros per trip: 2*K4 independent loads in flight per lane
         for (; t + 1 < cnt; t += 2) {
             const int c0 = __shfl(c, t, G);
             const int c1 = __shfl(c, t + 1, G);
             const float a0 = __shfl(a, t, G);
             const float a1 = __shfl(a, t + 1, G);
-            const float4* b0 = reinterpret_cast<const float4*>(B + (int64_t)c0 * ldb);
-            const float4* b1 = reinterpret_cast<const float4*>(B + (int64_t)c1 * ldb);
-            float4 v0[K4], v1[K4];
+            const void* b0 = row_ptr<BF>(B, ldb, c0);
+            const void* b1 = row_ptr<BF>(B, ldb, c1);
+            if constexpr (BF) {
+                u32x4v r0[K4 / 2], r1[K4 / 2];
 #pragma unroll
-            for (int k = 0; k < K4; ++k) {
-                const int q = lane16 + G * k;
-                if (q < nF4) {
-                    v0[k] = gather4<NT>(b0 + q);
-                    v1[k] = gather4<NT>(b1 + q);
+                for (int j = 0; j < K4 / 2; ++j) {
+                    const int q8 = lane16 + G * j;
+                    if (2 * q8 < nF4) {
+                        r0[j] = gather8_bf16<NT>(b0, q8);
+                        r1[j] = gather8_bf16<NT>(b1, q8);
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < K4; ++k) {
-                const int q = lane16 + G * k;
-                if (q < nF4) {
-                    fma4(acc[k], a0, v0[k]);
-                    fma4(acc[k], a1, v1[k]);
+                for (int j = 0; j < K4 / 2; ++j) {
+                    // (the upper half of the last piece may lie in the zero pad columns of the operand)
+                    if (2 * (lane16 + G * j) < nF4) {
+                        fma8_bf16(acc[2 * j], acc[2 * j + 1], a0, r0[j]);
+                        fma8_bf16(acc[2 * j], acc[2 * j + 1], a1, r1[j]);
+                    }
+                }
+            } else {
+                float4 v0[K4], v1[K4];
+#pragma unroll
+                for (int k = 0; k < K4; ++k) {
+                    const int q = lane16 + G * k;
+                    if (q < nF4) {
+                        v0[k] = gather4<NT>(b0, q);
+                        v1[k] = gather4<NT>(b1, q);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K4; ++k) {
+                    const int q = lane16 + G * k;
+                    if (q < nF4) {
+                        fma4(acc[k], a0, v0[k]);
+                        fma4(acc[k], a1, v1[k]);
+                    }
                 }
             }
         }
         if (t < cnt) {
             const int c0 = __shfl(c, t, G);
             const float a0 = __shfl(a, t, G);
-            const float4* b0 = reinterpret_cast<const float4*>(B + (int64_t)c0 * ldb);
+            const void* b0 = row_ptr<BF>(B, ldb, c0);
+            if constexpr (BF) {
 #pragma unroll
-            for (int k = 0; k < K4; ++k) {
-                const int q = lane16 + G * k;
-                if (q < nF4) fma4(acc[k], a0, gather4<NT>(b0 + q));
+                for (int k = 0; k < K4; k += 2) {
+                    const int q8 = lane16 + G * (k >> 1);
+                    if (2 * q8 < nF4) fma8_bf16(acc[k], acc[k + 1], a0, gather8_bf16<NT>(b0, q8));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K4; ++k) {
+                    const int q = lane16 + G * k;
+                    if (q < nF4) fma4(acc[k], a0, gather4<NT>(b0, q));
+                }
             }
         }
     }
@@ -129,10 +187,10 @@ __device__ __forceinline__ float4 epilogue4(float4 r, int col0, int F, const flo
 // of the long rows (raw partial sums into the workspace P), the remaining blocks take one CSR row per
 // 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
 // that it overlaps the bulk instead of running as an under-occupied launch of its own.
-template <int K4, int ACT, int NTT, int G>
+template <int K4, int ACT, int NTT, int G, int BF>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
-    const float* __restrict__ val, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
     const int* __restrict__ rowsplit, const int* __restrict__ chunk_split) {
@@ -146,12 +204,12 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
         if (ch >= n_chunks) return;
         const int cs = chunk_start[ch], ce = chunk_end[ch];
         const int ch_h = chunk_split ? chunk_split[ch] : ce;       // [cs, ch_h) hubs, [ch_h, ce) streamed
-        group_accumulate<K4, 0, G>(cs, ch_h, lane16, nF4, colidx, val, B, ldb, acc);
-        group_accumulate<K4, NTT, G>(ch_h, ce, lane16, nF4, colidx, val, B, ldb, acc);
+        group_accumulate<K4, 0, G, BF>(cs, ch_h, lane16, nF4, colidx, val, B, ldb, acc);
+        group_accumulate<K4, NTT, G, BF>(ch_h, ce, lane16, nF4, colidx, val, B, ldb, acc);
         float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
 #pragma unroll
         for (int k = 0; k < K4; ++k) {
-            const int q = lane16 + G * k;
+            const int q = f4_index<G, BF>(lane16, k);
             if (q < nF4) out[q] = acc[k];
         }
         return;
@@ -162,12 +220,12 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     const int e = rowptr[row + 1];
     if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks
     const int h = rowsplit ? rowsplit[row] : e;
-    group_accumulate<K4, 0, G>(s, h, lane16, nF4, colidx, val, B, ldb, acc);
-    group_accumulate<K4, NTT, G>(h, e, lane16, nF4, colidx, val, B, ldb, acc);
+    group_accumulate<K4, 0, G, BF>(s, h, lane16, nF4, colidx, val, B, ldb, acc);
+    group_accumulate<K4, NTT, G, BF>(h, e, lane16, nF4, colidx, val, B, ldb, acc);
     float4* out = reinterpret_cast<float4*>(C + (int64_t)row * ldc);
 #pragma unroll
     for (int k = 0; k < K4; ++k) {
-        const int q = lane16 + G * k;
+        const int q = f4_index<G, BF>(lane16, k);
         if (q < nF4) out[q] = epilogue4<ACT>(acc[k], q * 4, F, bias);
     }
 }
@@ -219,9 +277,9 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
     }
 }
 
-template <int K4, int G>
+template <int K4, int G, int BF>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
-              const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
+              const float* val, const void* B, int64_t ldb, float* C, int64_t ldc, int F,
               const float* bias, int act, float* ws, hipStream_t st, int64_t nnz);
 
 }  // namespace
@@ -253,9 +311,9 @@ geogcn_timer* g_spmm_timer = nullptr;
 int g_spmm_timer_F = 0;
 int64_t g_spmm_timer_nnz = 0;
 
-template <int K4, int G>
+template <int K4, int G, int BF>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
-              const float* val, const float* B, int64_t ldb, float* C, int64_t ldc, int F,
+              const float* val, const void* B, int64_t ldb, float* C, int64_t ldc, int F,
               const float* bias, int act, float* ws, hipStream_t st, int64_t nnz) {
     constexpr int kGroupsPerBlock = kBlock / G;
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
@@ -273,12 +331,14 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         return (e && e[0] == '0') ? 0 : 1;
     }();
 #define GEOGCN_ROWS(ACT)                                                                         \
-    if (nt_tail)                                                                                 \
+    if constexpr (BF) {          /* no cache-hint variant for the bf16 operand */               \
+        GEOGCN_ROWS_(ACT, 0);                                                                    \
+    } else if (nt_tail)                                                                          \
         GEOGCN_ROWS_(ACT, 1);                                                                    \
     else                                                                                         \
         GEOGCN_ROWS_(ACT, 0)
 #define GEOGCN_ROWS_(ACT, NTT)                                                                   \
-    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
+    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
                        plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr)
@@ -308,6 +368,119 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     }
     return 0;
 }
+
+}  // namespace
+}  // namespace geogcn
+
+namespace geogcn {
+namespace {
+
+template <int BF>
+int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                  const int32_t* rowptr, const int32_t* colidx, const float* val, const void* B, int64_t ldb,
+                  float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* ws, size_t ws_bytes,
+                  void* stream) {
+    GEOGCN_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && F >= 0, GEOGCN_E_SIZE,
+                   "%s: negative size", fn);
+    if (n_rows == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(rowptr && C && (nnz == 0 || (colidx && val && B)), GEOGCN_E_NULL,
+                   "%s: null pointer", fn);
+    GEOGCN_REQUIRE(ldb >= F && ldc >= F, GEOGCN_E_SIZE, "%s: ld < F (ldb=%lld ldc=%lld F=%d)", fn,
+                   (long long)ldb, (long long)ldc, F);
+    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG,
+                   "%s: unknown act %d", fn, act);
+    GEOGCN_REQUIRE(!plan || plan->n_rows == n_rows, GEOGCN_E_ARG,
+                   "%s: plan built for %d rows, called with %d", fn, plan ? plan->n_rows : 0,
+                   n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    const int F4 = (F + 3) / 4;
+    if constexpr (BF) {
+        // bf16 rows are read in 16-byte pieces of 8 features: 16-byte row starts, pitch covering whole pieces
+        const int F8 = (F + 7) / 8;
+        GEOGCN_REQUIRE(ldb % 8 == 0 && ldb >= (int64_t)F8 * 8 && ldc % 4 == 0 && ldc >= (int64_t)F4 * 4 && aligned16(B) &&
+                           aligned16(C) && F <= 1024,
+                       GEOGCN_E_ALIGN,
+                       "%s: needs 16-byte aligned B and C, ldb %% 8 == 0 and >= roundup8(F), ldc %% 4 == 0, F <= 1024 "
+                       "(ldb=%lld ldc=%lld F=%d)", fn, (long long)ldb, (long long)ldc, F);
+        const size_t need = geogcn_spmm_workspace_bytes(plan, F);
+        GEOGCN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16(ws)), GEOGCN_E_ARG,
+                       "%s: workspace too small or misaligned (%zu < %zu)", fn, ws_bytes, need);
+        float* wsf = (float*)ws;
+        // 8 lanes per row while that keeps <= 5 passes (F <= 320: every lane of a wave fetches 16 useful bytes,
+        // 8 rows in flight per wave); 16 lanes per row beyond
+#define GEOGCN_BF(K16, G_)                                                                                       \
+    return launch_k4<2 * K16, G_, 1>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz)
+        const int k8 = (F8 + 7) / 8, k16 = (F8 + 15) / 16;
+        if (k8 <= 5) {
+            switch (k8) {
+                case 1: GEOGCN_BF(1, 8);
+                case 2: GEOGCN_BF(2, 8);
+                case 3: GEOGCN_BF(3, 8);
+                case 4: GEOGCN_BF(4, 8);
+                default: GEOGCN_BF(5, 8);
+            }
+        }
+        switch (k16) {
+            case 3: GEOGCN_BF(3, 16);
+            case 4: GEOGCN_BF(4, 16);
+            case 5: GEOGCN_BF(5, 16);
+            case 6: GEOGCN_BF(6, 16);
+            case 7: GEOGCN_BF(7, 16);
+            default: GEOGCN_BF(8, 16);
+        }
+#undef GEOGCN_BF
+    } else {
+    const bool vec_ok = (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
+                        ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 16;      // F <= 1024
+    if (!vec_ok) {
+        const dim3 grid((unsigned)cdiv(n_rows, kBlock / kWave));
+#define GEOGCN_SC(ACT)                                                                              \
+    hipLaunchKernelGGL((spmm_scalar_kernel<ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr, colidx, \
+                       val, (const float*)B, ldb, C, ldc, F, bias)
+        if (act == GEOGCN_ACT_TANH) GEOGCN_SC(GEOGCN_ACT_TANH);
+        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_SC(GEOGCN_ACT_SIGMOID);
+        else GEOGCN_SC(GEOGCN_ACT_NONE);
+#undef GEOGCN_SC
+        GEOGCN_LAUNCH_CHECK("spmm_scalar_kernel");
+        return 0;
+    }
+    const size_t need = geogcn_spmm_workspace_bytes(plan, F);
+    GEOGCN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16(ws)), GEOGCN_E_ARG,
+                   "%s: workspace too small or misaligned (%zu < %zu)", fn, ws_bytes, need);
+    float* wsf = (float*)ws;
+    // narrow operands (F <= 32, e.g. the per-rank feature panels of C = 256 over 8 GPUs): 8 lanes per row,
+    // twice as many rows in flight per wave (measured 0.306 -> 0.267 ms at F = 16); otherwise 16 lanes per row
+    if (F4 <= 8) return launch_k4<1, 8, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
+    const int K4 = (F4 + kGroup - 1) / kGroup;
+    switch (K4) {
+#define GEOGCN_CASE(K)                                                                             \
+    case K:                                                                                        \
+        return launch_k4<K, kGroup, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
+        GEOGCN_CASE(1)
+        GEOGCN_CASE(2)
+        GEOGCN_CASE(3)
+        GEOGCN_CASE(4)
+        GEOGCN_CASE(5)
+        GEOGCN_CASE(6)
+        GEOGCN_CASE(7)
+        GEOGCN_CASE(8)
+        GEOGCN_CASE(9)
+        GEOGCN_CASE(10)
+        GEOGCN_CASE(11)     // hid 700..1024: the WORLD configuration of the reference uses 900 (README.md:180)
+        GEOGCN_CASE(12)
+        GEOGCN_CASE(13)
+        GEOGCN_CASE(14)
+        GEOGCN_CASE(15)
+        GEOGCN_CASE(16)
+#undef GEOGCN_CASE
+        default:
+            break;
+    }
+    set_error("%s: F=%d not supported", fn, F);
+    return GEOGCN_E_ARG;
+    }   // fp32 operand
+}
+
 
 }  // namespace
 }  // namespace geogcn
@@ -444,68 +617,16 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
                         const int32_t* rowptr, const int32_t* colidx, const float* val,
                         const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
                         const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream) {
-    GEOGCN_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && F >= 0, GEOGCN_E_SIZE,
-                   "spmm_csr_f32: negative size");
-    if (n_rows == 0 || F == 0) return 0;
-    GEOGCN_REQUIRE(rowptr && C && (nnz == 0 || (colidx && val && B)), GEOGCN_E_NULL,
-                   "spmm_csr_f32: null pointer");
-    GEOGCN_REQUIRE(ldb >= F && ldc >= F, GEOGCN_E_SIZE, "spmm_csr_f32: ld < F (ldb=%lld ldc=%lld F=%d)",
-                   (long long)ldb, (long long)ldc, F);
-    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG,
-                   "spmm_csr_f32: unknown act %d", act);
-    GEOGCN_REQUIRE(!plan || plan->n_rows == n_rows, GEOGCN_E_ARG,
-                   "spmm_csr_f32: plan built for %d rows, called with %d", plan ? plan->n_rows : 0,
-                   n_rows);
-    hipStream_t st = (hipStream_t)stream;
-    const int F4 = (F + 3) / 4;
-    const bool vec_ok = (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
-                        ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 16;      // F <= 1024
-    if (!vec_ok) {
-        const dim3 grid((unsigned)cdiv(n_rows, kBlock / kWave));
-#define GEOGCN_SC(ACT)                                                                              \
-    hipLaunchKernelGGL((spmm_scalar_kernel<ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr, colidx, \
-                       val, B, ldb, C, ldc, F, bias)
-        if (act == GEOGCN_ACT_TANH) GEOGCN_SC(GEOGCN_ACT_TANH);
-        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_SC(GEOGCN_ACT_SIGMOID);
-        else GEOGCN_SC(GEOGCN_ACT_NONE);
-#undef GEOGCN_SC
-        GEOGCN_LAUNCH_CHECK("spmm_scalar_kernel");
-        return 0;
-    }
-    const size_t need = geogcn_spmm_workspace_bytes(plan, F);
-    GEOGCN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16(ws)), GEOGCN_E_ARG,
-                   "spmm_csr_f32: workspace too small or misaligned (%zu < %zu)", ws_bytes, need);
-    float* wsf = (float*)ws;
-    // narrow operands (F <= 32, e.g. the per-rank feature panels of C = 256 over 8 GPUs): 8 lanes per row,
-    // twice as many rows in flight per wave (measured 0.306 -> 0.267 ms at F = 16); otherwise 16 lanes per row
-    if (F4 <= 8) return launch_k4<1, 8>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
-    const int K4 = (F4 + kGroup - 1) / kGroup;
-    switch (K4) {
-#define GEOGCN_CASE(K)                                                                             \
-    case K:                                                                                        \
-        return launch_k4<K, kGroup>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
-        GEOGCN_CASE(1)
-        GEOGCN_CASE(2)
-        GEOGCN_CASE(3)
-        GEOGCN_CASE(4)
-        GEOGCN_CASE(5)
-        GEOGCN_CASE(6)
-        GEOGCN_CASE(7)
-        GEOGCN_CASE(8)
-        GEOGCN_CASE(9)
-        GEOGCN_CASE(10)
-        GEOGCN_CASE(11)     // hid 700..1024: the WORLD configuration of the reference uses 900 (README.md:180)
-        GEOGCN_CASE(12)
-        GEOGCN_CASE(13)
-        GEOGCN_CASE(14)
-        GEOGCN_CASE(15)
-        GEOGCN_CASE(16)
-#undef GEOGCN_CASE
-        default:
-            break;
-    }
-    set_error("spmm_csr_f32: F=%d not supported", F);
-    return GEOGCN_E_ARG;
+    return spmm_csr_impl<0>("spmm_csr_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, C, ldc, F, bias,
+                            act, ws, ws_bytes, stream);
+}
+
+int geogcn_spmm_csr_bf16b(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                          const int32_t* rowptr, const int32_t* colidx, const float* val,
+                          const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                          const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream) {
+    return spmm_csr_impl<1>("spmm_csr_bf16b", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, C, ldc, F,
+                            bias, act, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

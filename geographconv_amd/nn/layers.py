@@ -270,6 +270,8 @@ class DenseLayer(Layer):
                 zf = K.DMat.empty(input.n if isinstance(input, K.DMat) else input.shape[0], self.num_units,
                                   y_device(input), ld=K.gather_ld(self.num_units))
                 self._matmul(input, zf, prec)
+                if K.bf16_gather(prec):
+                    zf = K.cast_bf16(zf)      # bf16 configuration: half the bytes per gathered row
                 y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
                 z = comm.matmul_target(self.num_units, tag='fwd')
@@ -314,7 +316,7 @@ class DenseLayer(Layer):
             if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
                 A_bwd = hint[1]
             if comm is None:
-                dZ = K.spmm(A_bwd, dS)
+                dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
             else:
                 g = comm.matmul_target(self.num_units, tag='bwd')
                 g.copy_from(dS)

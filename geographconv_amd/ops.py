@@ -104,6 +104,49 @@ class DMat:
         return self
 
 
+class HMat:
+    """Row-major bfloat16 device matrix (the gathered operand of the SpMM in the bf16 configuration,
+    include/geogcn.h geogcn_spmm_csr_bf16b).  Pitch = gather_ld(F): 128-byte multiples, pads zero."""
+    __slots__ = ('t', 'n', 'F')
+
+    def __init__(self, n, F, device=None, t=None, ld=None):
+        self.n, self.F = int(n), int(F)
+        if t is None:
+            t = torch.empty((self.n, int(ld) if ld else bf16_ld(F)), dtype=torch.bfloat16, device=device)
+        assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 2 and t.shape[0] == self.n
+        assert t.shape[1] >= pad4(F) and t.shape[1] % 4 == 0
+        self.t = t
+
+    @property
+    def ld(self):
+        return self.t.shape[1]
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def numpy(self):
+        return self.t[:, :self.F].float().cpu().numpy()
+
+
+def bf16_ld(F):
+    """Pitch (elements) of a bf16 gather operand: rows start on 128-byte lines."""
+    return (int(F) + 63) // 64 * 64
+
+
+def bf16_gather(precision=None):
+    """True in the bf16 configuration ('bf16': BASELINE config 5): the SpMM then gathers a bf16 copy of its
+    dense operand.  'f32' and 'bf16x3' keep the fp32 operand (their results are fp32-class)."""
+    return (precision or GEMM_PRECISION) == 'bf16'
+
+
+def cast_bf16(X: DMat, out: HMat = None):
+    """fp32 -> bf16 (round to nearest even), whole pitch written."""
+    out = HMat(X.n, X.F, X.device) if out is None else out
+    check(_ffi.lib().geogcn_cast_bf16_f32(X.n, X.F, _p(X.t), X.ld, _p(out.t), out.ld, _stream()), 'cast_bf16_f32')
+    return out
+
+
 class Workspace:
     """Grow-only scratch buffer (split-K slabs, long-row partials, reduction partials)."""
 
@@ -183,8 +226,9 @@ class CSR:
             pass
 
 
-def spmm(A: CSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None):
-    """out = act(A . B + bias)  -- S.structured_dot (reference gcnmodel.py:39,130,153)."""
+def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None):
+    """out = act(A . B + bias)  -- S.structured_dot (reference gcnmodel.py:39,130,153).  B is a DMat, or an
+    HMat (bf16 gathered operand, fp32 accumulation) in the bf16 configuration."""
     lib = _ffi.lib()
     F = B.F if F is None else F
     if B.n != A.shape[1]:
@@ -193,9 +237,10 @@ def spmm(A: CSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_N
         out = DMat.empty(A.shape[0], F, B.device)
     need = lib.geogcn_spmm_workspace_bytes(A._plan, F)
     ws = A._ws.get(need)
-    check(lib.geogcn_spmm_csr_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx),
-                                  _p(A.val), _p(B.t), B.ld, _p(out.t), out.ld, F, _p(bias), act,
-                                  _p(ws), ws.numel(), _stream()), 'spmm_csr_f32')
+    fn, name = ((lib.geogcn_spmm_csr_bf16b, 'spmm_csr_bf16b') if isinstance(B, HMat)
+                else (lib.geogcn_spmm_csr_f32, 'spmm_csr_f32'))
+    check(fn(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), _p(B.t), B.ld,
+             _p(out.t), out.ld, F, _p(bias), act, _p(ws), ws.numel(), _stream()), name)
     return out
 
 

@@ -71,8 +71,22 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
                         const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
                         const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
 
+/* Reduced-precision variant for the bf16 configuration (BASELINE config 5, `-gemm-precision bf16`; no
+ * reference counterpart -- the reference is fp32 throughout): the GATHERED operand B is stored as
+ * bfloat16 (raw uint16 bit patterns, row pitch ldb ELEMENTS), everything else -- CSR values, products,
+ * the sequential fp32 accumulation, bias, activation, C -- is as in geogcn_spmm_csr_f32.  The kernel is
+ * bound by the gather traffic from beyond the L2, so halving the row nearly halves its run time.  Requires
+ * 16-byte aligned B and C, ldb % 8 == 0 and >= roundup8(F) (pad columns zero), ldc % 4 == 0, F <= 1024
+ * (GEOGCN_E_ALIGN otherwise; there is no scalar fallback).  geogcn_cast_bf16_f32 produces B: round-to-nearest-even, whole pitch written
+ * (pad columns [F, ldy) as zeros).                                                               */
+int geogcn_spmm_csr_bf16b(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                          const int32_t* rowptr, const int32_t* colidx, const float* val,
+                          const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
+                          const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
+int geogcn_cast_bf16_f32(int64_t n, int32_t F, const float* X, int64_t ldx, uint16_t* Y, int64_t ldy, void* stream);
+
 /* profiling aid (bench.py's roofline leg): a pool of hipEvent pairs owned by the library.  While a
- * timer is attached, every geogcn_spmm_csr_f32 call whose F equals `only_F` and whose nnz equals
+ * timer is attached, every geogcn_spmm_csr_f32 / _bf16b call whose F equals `only_F` and whose nnz equals
  * `only_nnz` (0 = any) records one
  * (begin, end) pair immediately around its main row kernel (spmm_rows_kernel) on the call's stream,
  * until the pool is full.  geogcn_timer_read_ms synchronises the recorded events and returns the

@@ -74,6 +74,43 @@ def test_spmm_matches_oracle(dev, F, act, use_bias):
     assert empty.any()
 
 
+@pytest.mark.parametrize("F", [5, 64, 129, 300, 600])
+def test_spmm_bf16_gathered_operand(dev, F):
+    """bf16 configuration (BASELINE config 5): the gathered operand is rounded to bfloat16 (RNE, bit-identical
+    to torch's cast), products and the sequential accumulation stay fp32 -- so the result equals the fp32 SpMM
+    applied to the rounded operand."""
+    from geographconv_amd import ops
+    A = _skewed_csr(700, 900, seed=F)
+    B = _rand((900, F), 1)
+    B[0, 0] = np.float32(1.00390625)          # exactly between two bf16 values: ties to even
+    B[1, 0] = np.float32(1.01171875)
+    bias = _rand((F,), 2)
+    dA = ops.CSR(A, dev)
+    dB = ops.DMat.from_numpy(B, dev)
+    hB = ops.cast_bf16(dB)
+    assert hB.ld % 64 == 0 and hB.t.dtype == torch.bfloat16
+    want = torch.from_numpy(B).to(torch.bfloat16)
+    assert torch.equal(hB.t[:, :F].cpu(), want)
+    assert torch.all(hB.t[:, F:].float() == 0)
+    Br = want.float().numpy()
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(F) - F))).to(dev)
+    out = ops.spmm(dA, hB, bias=db, act=1)
+    ref = np.tanh(O.spmm(A, Br) + bias)
+    mag = np.asarray(abs(A) @ np.abs(Br)) + np.abs(bias)
+    assert np.all(np.abs(out.numpy() - ref) <= 2e-6 * mag + 1e-6)
+    assert torch.all(out.t[:, F:] == 0)
+    # and it is the SAME arithmetic as the fp32 kernel on the rounded operand: bitwise equal
+    same = ops.spmm(dA, ops.DMat.from_numpy(Br, dev), bias=db, act=1)
+    assert torch.equal(same.t, out.t)
+    # a pitch that is not a multiple of 4 elements is refused (no scalar fallback for the bf16 operand)
+    from geographconv_amd import _ffi
+    ws = dA._ws.get(_ffi.lib().geogcn_spmm_workspace_bytes(dA._plan, F))
+    rc = _ffi.lib().geogcn_spmm_csr_bf16b(dA._plan, 700, 900, A.nnz, ops._p(dA.rowptr), ops._p(dA.colidx), ops._p(dA.val),
+                                         ops._p(hB.t), hB.ld - 2, ops._p(out.t), out.ld, min(F, hB.ld - 2), None, 0,
+                                         ops._p(ws), ws.numel(), ops._stream())
+    assert rc == -3
+
+
 def test_spmm_short_rows_bitwise_reproducible_and_sequential(dev):
     """Rows below the split threshold accumulate in stored order with fmaf: two runs are bitwise
     equal and equal to a sequential fp32 fma chain (checked via float64 emulation bound)."""

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=128)
     ap.add_argument('--aligned', type=int, default=1, help='use the line-aligned gather pitch for B')
     ap.add_argument('--hub', type=int, default=0, help='hub_row_bytes for the cache hint (0 = off)')
+    ap.add_argument('--bf16', type=int, default=0, help='gather a bf16 copy of B (geogcn_spmm_csr_bf16b)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     s = synth.SHAPES[args.shape]
@@ -33,6 +34,8 @@ def main():
         H = ops.DMat.empty(s.N, F, dev, ld=ops.gather_ld(F) if args.aligned else None)
         H.t[:, :F].copy_(torch.from_numpy(rng.randn(s.N, F).astype(np.float32)))
         out = ops.DMat(s.N, F, dev)
+        if args.bf16:
+            H = ops.cast_bf16(H)
         for _ in range(2):
             ops.spmm(dA, H, out=out)
         torch.cuda.synchronize()
