@@ -75,7 +75,7 @@ __device__ __forceinline__ float apply_act(float x) {
 // gemm_bf16.hip
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K);
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate,
-                       void* ws, size_t ws_bytes, hipStream_t st);
+                       const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace geogcn

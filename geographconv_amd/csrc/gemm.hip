@@ -519,27 +519,35 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
     return splitk_ws_bytes<160, 160>(M, N, K);
 }
 
-int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
-                    int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
-                    int32_t act, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
-    GEOGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, GEOGCN_E_SIZE, "gemm_f32: negative size");
+static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
+                      int64_t lda, const float* B, int64_t ldb, void* Cv, int64_t ldc, int c_bf16, const float* bias,
+                      int32_t act, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, GEOGCN_E_SIZE, "%s: negative size", fn);
     GEOGCN_REQUIRE(precision >= GEOGCN_GEMM_F32 && precision <= GEOGCN_GEMM_BF16, GEOGCN_E_ARG,
-                   "gemm_f32: unknown precision %d", precision);
+                   "%s: unknown precision %d", fn, precision);
     if (M == 0 || N == 0) return 0;
-    GEOGCN_REQUIRE(C && (K == 0 || (A && B)), GEOGCN_E_NULL, "gemm_f32: null pointer");
-    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG, "gemm_f32: unknown act %d", act);
-    GEOGCN_REQUIRE(!(transA && transB), GEOGCN_E_ARG, "gemm_f32: transA && transB not supported");
+    GEOGCN_REQUIRE(Cv && (K == 0 || (A && B)), GEOGCN_E_NULL, "%s: null pointer", fn);
+    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG, "%s: unknown act %d", fn, act);
+    GEOGCN_REQUIRE(!(transA && transB), GEOGCN_E_ARG, "%s: transA && transB not supported", fn);
     const int64_t a_cols = transA ? M : K, b_cols = transB ? K : N;
     GEOGCN_REQUIRE(lda >= a_cols && ldb >= b_cols && ldc >= N, GEOGCN_E_SIZE,
-                   "gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda,
+                   "%s: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", fn, (long long)lda,
                    (long long)ldb, (long long)ldc);
-    GEOGCN_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C),
+    GEOGCN_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(Cv),
                    GEOGCN_E_ALIGN,
-                   "gemm_f32: A, B, C need 16-byte aligned bases and ld %% 4 == 0 (lda=%lld ldb=%lld ldc=%lld)",
+                   "%s: A, B, C need 16-byte aligned bases and ld %% 4 == 0 (lda=%lld ldb=%lld ldc=%lld)", fn,
                    (long long)lda, (long long)ldb, (long long)ldc);
     hipStream_t st = (hipStream_t)stream;
+    if (c_bf16) {
+        GEOGCN_REQUIRE(!transA && precision == GEOGCN_GEMM_BF16 && !accumulate && K > 0, GEOGCN_E_ARG,
+                       "%s: a bf16 C needs transA = 0, precision = GEOGCN_GEMM_BF16, accumulate = 0", fn);
+        GEOGCN_REQUIRE(ldc % 8 == 0 && ldc >= ((N + 7) & ~(int64_t)7), GEOGCN_E_ALIGN,
+                       "%s: a bf16 C needs ldc %% 8 == 0 and >= roundup8(N) (ldc=%lld)", fn, (long long)ldc);
+    }
     if (!transA && precision != GEOGCN_GEMM_F32 && K > 0)
-        return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+        return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
+                                  ws_bytes, st);
+    float* C = (float*)Cv;
     const int bn = pick_tile(N);
     if (transA)
         return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
@@ -548,6 +556,20 @@ int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
         return dispatch_tiles<false, true>(bn == 160 ? 96 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate,
                                            ws, ws_bytes, st);
     return dispatch_tiles<false, false>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+}
+
+int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
+                    int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                    int32_t act, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
+    return gemm_entry("gemm_f32", transA, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, bias, act, accumulate, precision, ws,
+                      ws_bytes, stream);
+}
+
+int geogcn_gemm_f32_bf16c(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                          int64_t ldb, uint16_t* C, int64_t ldc, const float* bias, int32_t act, void* ws,
+                          size_t ws_bytes, void* stream) {
+    return gemm_entry("gemm_f32_bf16c", 0, transB, M, N, K, A, lda, B, ldb, C, ldc, 1, bias, act, 0, GEOGCN_GEMM_BF16, ws,
+                      ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -70,10 +70,12 @@ struct Bf16Args {
     const float* A; int64_t lda;
     const unsigned short* Bp;           // planes [NS][N][Kp]
     int Kp;
-    float* C; int64_t ldc;
+    void* C; int64_t ldc;               // fp32, or bf16 bit patterns when c_bf16
     const float* bias;
     int accumulate;
     int n_mt, n_nt;
+    int c_bf16;
+    int64_t n_store;                    // columns written per row (pads beyond N as zeros)
 };
 
 template <int BM, int BN, int NS, int NT>
@@ -223,45 +225,62 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
                 for (int pl = 0; pl < NS; ++pl)
                     af[pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + wm * kWaveRows + i * 16 + li) * ROWB + lg * 16);
                 f32x4 c = acc[i][j];
+                // operands swapped (B fragment first): the 16x16 product comes out transposed, so a lane owns 4
+                // CONSECUTIVE COLUMNS of one row of C and the epilogue stores 16 (fp32) / 8 (bf16) bytes at once
                 if constexpr (NS == 3) {        // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2], af[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[0], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
         }
         if (ckt == nk - 1) {
-            float bcol[Cfg::NR];
+            // lane (li, lg) holds C[row = li][col = 4*lg + r], r = 0..3, of each 16x16 sub-tile.  Columns in
+            // [N, n_store) are pad columns and are written as zeros (n_store = roundup4(N), or roundup8(N) when C
+            // is stored as bf16 for the SpMM, which reads 8 features at a time).
+            float bcol[Cfg::NR][4];
 #pragma unroll
             for (int j = 0; j < Cfg::NR; ++j) {
-                const int64_t col = cn0 + wn * (BN / 2) + j * 16 + li;
-                bcol[j] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+                const int64_t col0 = cn0 + wn * (BN / 2) + j * 16 + lg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && col0 + r < a.N) ? a.bias[col0 + r] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
-                const int64_t row0 = cm0 + wm * kWaveRows + i * 16 + lg * 4;
-                float oldv[Cfg::NR][4];
-                if (a.accumulate) {
+                const int64_t row = cm0 + wm * kWaveRows + i * 16 + li;
+                const bool row_ok = row < a.M;
+                float4 oldv[Cfg::NR];
+                if (a.accumulate) {          // (fp32 C only)
 #pragma unroll
                     for (int j = 0; j < Cfg::NR; ++j) {
-                        const int64_t col = cn0 + wn * (BN / 2) + j * 16 + li;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            oldv[j][r] = (row0 + r < a.M && col < a.N) ? a.C[(row0 + r) * a.ldc + col] : 0.f;
+                        const int64_t col0 = cn0 + wn * (BN / 2) + j * 16 + lg * 4;
+                        oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row_ok && col0 < a.N) oldv[j] = *reinterpret_cast<const float4*>((const float*)a.C + row * a.ldc + col0);
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < Cfg::NR; ++j) {
-                    const int64_t col = cn0 + wn * (BN / 2) + j * 16 + li;
+                    const int64_t col0 = cn0 + wn * (BN / 2) + j * 16 + lg * 4;
+                    float x[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = apply_act<ACT>(acc[i][j][r] + bcol[j]);
-                        if (a.accumulate) v += oldv[j][r];
-                        if (row0 + r < a.M && col < a.N) a.C[(row0 + r) * a.ldc + col] = v;
+                    for (int r = 0; r < 4; ++r) x[r] = apply_act<ACT>(acc[i][j][r] + bcol[j][r]);
+                    if (a.accumulate) { x[0] += oldv[j].x; x[1] += oldv[j].y; x[2] += oldv[j].z; x[3] += oldv[j].w; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r >= a.N) x[r] = 0.f;
+                    if (row_ok && col0 < a.n_store) {
+                        if (a.c_bf16) {
+                            uint2 w;
+                            w.x = bf16_rne(x[0]) | (bf16_rne(x[1]) << 16);
+                            w.y = bf16_rne(x[2]) | (bf16_rne(x[3]) << 16);
+                            *reinterpret_cast<uint2*>((unsigned short*)a.C + row * a.ldc + col0) = w;
+                        } else {
+                            *reinterpret_cast<float4*>((float*)a.C + row * a.ldc + col0) = make_float4(x[0], x[1], x[2], x[3]);
+                        }
                     }
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -320,8 +339,8 @@ size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
 
 // called by geogcn_gemm_f32 for transA == 0 and precision != F32
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate,
-                       void* ws, size_t ws_bytes, hipStream_t st) {
+                       const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     const int ns = (precision == GEOGCN_GEMM_BF16X3) ? 3 : 1;
     const int Kp = (int)(cdiv(K, BKH) * BKH);
     const size_t need = gemm_bf16_workspace_bytes(precision, N, K);
@@ -335,7 +354,8 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
         hipLaunchKernelGGL((prep_b_planes_kernel<1>), dim3(pgrid), dim3(TPB), 0, st, B, ldb, (int)K, (int)N, Kp, transB, planes);
     GEOGCN_LAUNCH_CHECK("prep_b_planes_kernel");
     const int bn = (cdiv(N, 160) * 160 < cdiv(N, 128) * 128) ? 160 : 128;
-    Bf16Args a{M, N, K, A, lda, planes, Kp, C, ldc, bias, accumulate, (int)cdiv(M, 128), (int)cdiv(N, bn)};
+    Bf16Args a{M, N, K, A, lda, planes, Kp, C, ldc, bias, accumulate, (int)cdiv(M, 128), (int)cdiv(N, bn), c_bf16,
+               c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3)};
     if (ns == 3) {      // 8 waves per block: half the accumulators / staging registers per lane
         if (bn == 160) return launch_bf16<128, 160, 3, 512>(a, act, st);
         return launch_bf16<128, 128, 3, 512>(a, act, st);

@@ -267,11 +267,17 @@ class DenseLayer(Layer):
             comm = kwargs.get('comm')
             if comm is None:
                 # Z is gathered row-wise by the SpMM: give it the line-aligned pitch
-                zf = K.DMat.empty(input.n if isinstance(input, K.DMat) else input.shape[0], self.num_units,
-                                  y_device(input), ld=K.gather_ld(self.num_units))
-                self._matmul(input, zf, prec)
-                if K.bf16_gather(prec):
-                    zf = K.cast_bf16(zf)      # bf16 configuration: half the bytes per gathered row
+                n_in = input.n if isinstance(input, K.DMat) else input.shape[0]
+                if K.bf16_gather(prec) and isinstance(input, K.DMat) and type(self)._matmul is DenseLayer._matmul:
+                    # bf16 configuration: Z goes from the MFMA accumulators to HBM as bf16 -- half the bytes per
+                    # gathered row in the SpMM, no fp32 round trip
+                    zf = K.HMat(n_in, self.num_units, y_device(input))
+                    self._matmul(input, zf, prec)
+                else:
+                    zf = K.DMat.empty(n_in, self.num_units, y_device(input), ld=K.gather_ld(self.num_units))
+                    self._matmul(input, zf, prec)
+                    if K.bf16_gather(prec):
+                        zf = K.cast_bf16(zf)
                 y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
                 z = comm.matmul_target(self.num_units, tag='fwd')

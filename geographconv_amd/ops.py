@@ -268,6 +268,14 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     ws = _gemm_ws.get(dev)
     if ws is None:
         ws = _gemm_ws[dev] = Workspace(dev)
+    if isinstance(out, HMat):
+        # bf16 configuration: the product lands in bf16, the SpMM's operand format (no fp32 round trip)
+        if transA or accumulate or (precision or GEMM_PRECISION) != 'bf16':
+            raise ValueError("gemm: a bf16 result needs transA=False, accumulate=False, precision='bf16'")
+        w = ws.get(lib.geogcn_gemm_workspace_bytes(0, int(transB), M, N, K, _ffi.GEMM_BF16))
+        check(lib.geogcn_gemm_f32_bf16c(int(transB), M, N, K, _p(A.t), A.ld, _p(B.t), B.ld, _p(out.t), out.ld,
+                                        _p(bias), act, _p(w), w.numel(), _stream()), 'gemm_f32_bf16c')
+        return out
     prec = GEMM_PRECISIONS[precision or GEMM_PRECISION]
     need = lib.geogcn_gemm_workspace_bytes(int(transA), int(transB), M, N, K, prec)
     w = ws.get(need)

@@ -128,6 +128,14 @@ int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_
                     const float* A, int64_t lda, const float* B, int64_t ldb,
                     float* C, int64_t ldc, const float* bias, int32_t act, int32_t accumulate,
                     int32_t precision, void* ws, size_t ws_bytes, void* stream);
+/* bf16 configuration only: the GEOGCN_GEMM_BF16 product (transA = 0, no accumulate) with C stored as
+ * bfloat16 (round to nearest even), the operand format of geogcn_spmm_csr_bf16b -- Z = H.W goes from the
+ * MFMA accumulators to the SpMM without an fp32 round trip through HBM.  ldc is in ELEMENTS, % 8 == 0 and
+ * >= roundup8(N); columns [N, roundup8(N)) are written as zeros.  Workspace as geogcn_gemm_workspace_bytes
+ * (0, transB, M, N, K, GEOGCN_GEMM_BF16).                                                          */
+int geogcn_gemm_f32_bf16c(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                          const float* B, int64_t ldb, uint16_t* C, int64_t ldc, const float* bias,
+                          int32_t act, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */

@@ -233,6 +233,19 @@ def test_gemm_bf16_modes(dev, M, N, K):
     ops.gemm(dA, dB, out=dC, accumulate=True, precision='bf16x3')
     assert np.all(np.abs(dC.numpy() - (ref + C0)) <= 2e-6 * mag + 2e-6)
     assert np.array_equal(ops.gemm(dA, dB, precision='bf16x3').numpy(), ops.gemm(dA, dB, precision='bf16x3').numpy())
+    # bf16 result (geogcn_gemm_f32_bf16c): exactly the round-to-nearest-even of the fp32 result of the same mode;
+    # whole 8-column pieces written, pads as zeros
+    for kw in (dict(), dict(transB=True)):
+        Bop = dBt if kw else dB
+        f32 = ops.gemm(dA, Bop, bias=db, act=ops.ACT_TANH, precision='bf16', **kw)
+        h = ops.HMat(M, N, dev)
+        h.t.fill_(7.0)
+        ops.gemm(dA, Bop, out=h, bias=db, act=ops.ACT_TANH, precision='bf16', **kw)
+        assert torch.equal(h.t[:, :N], f32.t[:, :N].to(torch.bfloat16))
+        n8 = (N + 7) // 8 * 8
+        assert torch.all(h.t[:, N:n8].float() == 0)
+    with pytest.raises(ValueError):
+        ops.gemm(dA, dB, out=ops.HMat(M, N, dev), precision='f32')
 
 
 @pytest.mark.parametrize("R,M,N", [(5000, 300, 300), (4097, 300, 129), (333, 300, 600), (20000, 64, 8)])
