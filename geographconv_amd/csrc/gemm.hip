@@ -13,6 +13,8 @@
 // kernel adds the slabs in slab order: deterministic, no atomics.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace geogcn {
@@ -24,18 +26,27 @@ constexpr int BK = 32;
 constexpr int KPITCH = BK + 4;     // k-contiguous image pitch (floats): 144 B rows, 16-B aligned
 constexpr int TPB = 256;
 
-template <int R>
+template <int R, int NTH>
 struct KContig {                    // R rows x BK floats, row-major, pitch KPITCH
     static constexpr int kFloats = R * KPITCH;
-    static constexpr int kIters = R / 32;          // 256 threads x float4 = 32 rows per pass
+    static constexpr int kRowsPerPass = NTH / 8;    // NTH threads x float4 = NTH/8 rows per pass
+    static constexpr int kIters = (R + kRowsPerPass - 1) / kRowsPerPass;
+    static constexpr bool kExact = (R % kRowsPerPass) == 0;
 };
-template <int Ccols>
+template <int Ccols, int NTH>
 struct KStrided {                   // BK rows x Ccols floats, pitch Ccols + 4
     static constexpr int kPitch = Ccols + 4;
     static constexpr int kFloats = BK * kPitch;
     static constexpr int kF4PerRow = Ccols / 4;
-    static constexpr int kIters = (BK * kF4PerRow) / TPB;   // Ccols multiple of 32 => exact
+    static constexpr int kTotal = BK * kF4PerRow;
+    static constexpr int kIters = (kTotal + NTH - 1) / NTH;
+    static constexpr bool kExact = (kTotal % NTH) == 0;
 };
+
+template <int R, int NTH>
+using KContigRegs = float4[KContig<R, NTH>::kIters];
+template <int Ccols, int NTH>
+using KStridedRegs = float4[KStrided<Ccols, NTH>::kIters];
 
 // ---- global -> registers ----------------------------------------------------------------------
 // Buffer loads (raw, stride 0): the descriptor is rebased on the tile / stage origin, so that
@@ -65,9 +76,10 @@ __device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, uint32_
 }
 
 // k-contiguous operand: memory [R_total][K] row-major (ld), tile rows r0.., k range k0..k0+31
-template <int R>
-__device__ __forceinline__ void gload_kcontig(float4 (&reg)[KContig<R>::kIters], const float* __restrict__ P,
+template <int R, int NTH>
+__device__ __forceinline__ void gload_kcontig(KContigRegs<R, NTH>& reg, const float* __restrict__ P,
                                               int64_t ld, int64_t r0, int64_t Rtot, int64_t k0, int64_t Kend) {
+    using L = KContig<R, NTH>;
     const int tid = threadIdx.x;
     const int f4 = tid & 7;
     const int rr = tid >> 3;
@@ -75,61 +87,75 @@ __device__ __forceinline__ void gload_kcontig(float4 (&reg)[KContig<R>::kIters],
     const bool k_ok = k0 + f4 * 4 < ((Kend + 3) & ~(int64_t)3);
     const uint32_t ld4 = (uint32_t)ld * 4u;
 #pragma unroll
-    for (int i = 0; i < KContig<R>::kIters; ++i) {
-        const uint32_t off = (uint32_t)(rr + 32 * i) * ld4 + (uint32_t)f4 * 16u;
-        reg[i] = buffer_load4(rs, k_ok ? off : kOobOffset);
+    for (int i = 0; i < L::kIters; ++i) {
+        const int row = rr + L::kRowsPerPass * i;
+        const uint32_t off = (uint32_t)row * ld4 + (uint32_t)f4 * 16u;
+        const bool ok = k_ok && (L::kExact || row < R);
+        reg[i] = buffer_load4(rs, ok ? off : kOobOffset);
     }
 }
-template <int R>
-__device__ __forceinline__ void sstore_kcontig(float* __restrict__ S, const float4 (&reg)[KContig<R>::kIters]) {
+template <int R, int NTH>
+__device__ __forceinline__ void sstore_kcontig(float* __restrict__ S, const KContigRegs<R, NTH>& reg) {
+    using L = KContig<R, NTH>;
     const int tid = threadIdx.x;
     const int f4 = tid & 7;
     const int rr = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < KContig<R>::kIters; ++i)
-        *reinterpret_cast<float4*>(S + (rr + 32 * i) * KPITCH + f4 * 4) = reg[i];
+    for (int i = 0; i < L::kIters; ++i) {
+        const int row = rr + L::kRowsPerPass * i;
+        if (L::kExact || row < R) *reinterpret_cast<float4*>(S + row * KPITCH + f4 * 4) = reg[i];
+    }
 }
 // k-strided operand: memory [K][C_total] row-major (ld), tile cols c0.., k range k0..k0+31
-template <int Ccols>
-__device__ __forceinline__ void gload_kstrided(float4 (&reg)[KStrided<Ccols>::kIters], const float* __restrict__ P,
+template <int Ccols, int NTH>
+__device__ __forceinline__ void gload_kstrided(KStridedRegs<Ccols, NTH>& reg, const float* __restrict__ P,
                                                int64_t ld, int64_t c0, int64_t Ctot, int64_t k0, int64_t Kend) {
+    using L = KStrided<Ccols, NTH>;
     const int tid = threadIdx.x;
-    constexpr int F4R = KStrided<Ccols>::kF4PerRow;
+    constexpr int F4R = L::kF4PerRow;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + k0 * ld + c0, ((Kend - k0) * ld - c0) * 4);
     const int64_t c_lim = ((Ctot + 3) & ~(int64_t)3) - c0;       // valid columns of this tile (multiple of 4)
     const uint32_t ld4 = (uint32_t)ld * 4u;
 #pragma unroll
-    for (int i = 0; i < KStrided<Ccols>::kIters; ++i) {
-        const int e = tid + TPB * i;
+    for (int i = 0; i < L::kIters; ++i) {
+        const int e = tid + NTH * i;
         const int kr = e / F4R;
         const int c4 = e % F4R;
         const uint32_t off = (uint32_t)kr * ld4 + (uint32_t)c4 * 16u;
-        reg[i] = buffer_load4(rs, c4 * 4 < c_lim ? off : kOobOffset);
+        const bool ok = c4 * 4 < c_lim && (L::kExact || e < L::kTotal);
+        reg[i] = buffer_load4(rs, ok ? off : kOobOffset);
     }
 }
-template <int Ccols>
-__device__ __forceinline__ void sstore_kstrided(float* __restrict__ S, const float4 (&reg)[KStrided<Ccols>::kIters]) {
+template <int Ccols, int NTH>
+__device__ __forceinline__ void sstore_kstrided(float* __restrict__ S, const KStridedRegs<Ccols, NTH>& reg) {
+    using L = KStrided<Ccols, NTH>;
     const int tid = threadIdx.x;
-    constexpr int F4R = KStrided<Ccols>::kF4PerRow;
+    constexpr int F4R = L::kF4PerRow;
 #pragma unroll
-    for (int i = 0; i < KStrided<Ccols>::kIters; ++i) {
-        const int e = tid + TPB * i;
+    for (int i = 0; i < L::kIters; ++i) {
+        const int e = tid + NTH * i;
         const int kr = e / F4R;
         const int c4 = e % F4R;
-        *reinterpret_cast<float4*>(S + kr * KStrided<Ccols>::kPitch + c4 * 4) = reg[i];
+        if (L::kExact || e < L::kTotal) *reinterpret_cast<float4*>(S + kr * L::kPitch + c4 * 4) = reg[i];
     }
 }
 
-template <int BM, int BN, bool AT, bool BT>
+// WM x WN waves per block (2 x 2 = 256 threads, two blocks per CU; 2 x 4 = 512 threads, one block per CU:
+// the same two waves per SIMD, but one tile spans all of N <= 320, so the streamed operand is staged once)
+template <int BM, int BN, bool AT, bool BT, int WM = 2, int WN = 2>
 struct GemmCfg {
-    static constexpr int kAFloats = AT ? KStrided<BM>::kFloats : KContig<BM>::kFloats;
-    static constexpr int kBFloats = BT ? KContig<BN>::kFloats : KStrided<BN>::kFloats;
-    static constexpr int kAIters = AT ? KStrided<BM>::kIters : KContig<BM>::kIters;
-    static constexpr int kBIters = BT ? KContig<BN>::kIters : KStrided<BN>::kIters;
+    static constexpr int NTH = 64 * WM * WN;
+    static constexpr int kAFloats = AT ? KStrided<BM, NTH>::kFloats : KContig<BM, NTH>::kFloats;
+    static constexpr int kBFloats = BT ? KContig<BN, NTH>::kFloats : KStrided<BN, NTH>::kFloats;
+    static constexpr int kAIters = AT ? KStrided<BM, NTH>::kIters : KContig<BM, NTH>::kIters;
+    static constexpr int kBIters = BT ? KContig<BN, NTH>::kIters : KStrided<BN, NTH>::kIters;
     static constexpr int kStageFloats = kAFloats + kBFloats;
     static constexpr size_t kLdsBytes = 2 * (size_t)kStageFloats * sizeof(float);
-    static constexpr int MR = BM / 32;   // 16x16 tiles per wave along M (wave tile = BM/2)
-    static constexpr int NR = BN / 32;
+    static constexpr int kWaveM = BM / WM, kWaveN = BN / WN;     // wave tile
+    static constexpr int MR = kWaveM / 16;   // 16x16 tiles per wave along M
+    static constexpr int NR = kWaveN / 16;
+    static constexpr int kBlocksPerCU = (NTH == 256 && 2 * kLdsBytes <= 160 * 1024) ? 2 : 1;
+    static_assert(kWaveM % 16 == 0 && kWaveN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA");
 };
 
 struct GemmArgs {
@@ -187,17 +213,18 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int p, int G
 // control (K tail, epilogue, tile advance): loads past the end of the list use an empty buffer descriptor
 // (they return zeros) and their LDS image is written but never multiplied, so the compiler can count its
 // vmcnt waits exactly instead of draining the memory pipeline at control-flow joins.
-template <int BM, int BN, bool AT, bool BT, int ACT, int MODE, int PROBE = 0>
-__global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
+template <int BM, int BN, bool AT, bool BT, int ACT, int MODE, int PROBE = 0, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_kernel(const GemmArgs a) {
     // PROBE (tools/micro/gemm_variants.hip only; 0 in the library): 1 = no global loads, 2 = no C stores,
     // 4 = no K-tail early-out, 8 = no LDS stores
-    using Cfg = GemmCfg<BM, BN, AT, BT>;
+    using Cfg = GemmCfg<BM, BN, AT, BT, WM, WN>;
+    constexpr int NTH = Cfg::NTH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int p = blockIdx.x, G = gridDim.x;
 
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 15, lg = lane >> 4;
 
     f32x4 acc[Cfg::MR][Cfg::NR];
@@ -216,18 +243,18 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
         const int64_t kend = t.nk > 0 ? min(a.K, kbeg + a.kchunk) : k0;
         const int64_t m0 = (int64_t)t.mt * BM, n0 = (int64_t)t.nt * BN;
         const int64_t Mlim = t.nk > 0 ? a.M : 0, Nlim = t.nk > 0 ? a.N : 0;
-        if constexpr (AT) gload_kstrided<BM>(ra, a.A, a.lda, m0, Mlim, k0, kend);
-        else gload_kcontig<BM>(ra, a.A, a.lda, m0, Mlim, k0, kend);
-        if constexpr (BT) gload_kcontig<BN>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
-        else gload_kstrided<BN>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
+        if constexpr (AT) gload_kstrided<BM, NTH>(ra, a.A, a.lda, m0, Mlim, k0, kend);
+        else gload_kcontig<BM, NTH>(ra, a.A, a.lda, m0, Mlim, k0, kend);
+        if constexpr (BT) gload_kcontig<BN, NTH>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
+        else gload_kstrided<BN, NTH>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
     };
     auto sstore = [&](int buf, const float4 (&ra)[Cfg::kAIters], const float4 (&rb)[Cfg::kBIters]) {
         float* As = smem + buf * Cfg::kStageFloats;
         float* Bs = As + Cfg::kAFloats;
-        if constexpr (AT) sstore_kstrided<BM>(As, ra);
-        else sstore_kcontig<BM>(As, ra);
-        if constexpr (BT) sstore_kcontig<BN>(Bs, rb);
-        else sstore_kstrided<BN>(Bs, rb);
+        if constexpr (AT) sstore_kstrided<BM, NTH>(As, ra);
+        else sstore_kcontig<BM, NTH>(As, ra);
+        if constexpr (BT) sstore_kcontig<BN, NTH>(Bs, rb);
+        else sstore_kstrided<BN, NTH>(Bs, rb);
     };
 
     int cj = 0, ckt = 0;                     // compute cursor (tile index in my list, stage)
@@ -262,10 +289,10 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
             float af[Cfg::MR][4], bf[Cfg::NR][4];
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
-                const int mrow = wm * (BM / 2) + i * 16 + li;
+                const int mrow = wm * Cfg::kWaveM + i * 16 + li;
                 if constexpr (AT) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) af[i][t] = As[(kk + 4 * lg + t) * KStrided<BM>::kPitch + mrow];
+                    for (int t = 0; t < 4; ++t) af[i][t] = As[(kk + 4 * lg + t) * KStrided<BM, NTH>::kPitch + mrow];
                 } else {
                     const float4 v = *reinterpret_cast<const float4*>(As + mrow * KPITCH + kk + 4 * lg);
                     af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
@@ -273,13 +300,13 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
             }
 #pragma unroll
             for (int jn = 0; jn < Cfg::NR; ++jn) {
-                const int ncol = wn * (BN / 2) + jn * 16 + li;
+                const int ncol = wn * Cfg::kWaveN + jn * 16 + li;
                 if constexpr (BT) {
                     const float4 v = *reinterpret_cast<const float4*>(Bs + ncol * KPITCH + kk + 4 * lg);
                     bf[jn][0] = v.x; bf[jn][1] = v.y; bf[jn][2] = v.z; bf[jn][3] = v.w;
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) bf[jn][t] = Bs[(kk + 4 * lg + t) * KStrided<BN>::kPitch + ncol];
+                    for (int t = 0; t < 4; ++t) bf[jn][t] = Bs[(kk + 4 * lg + t) * KStrided<BN, NTH>::kPitch + ncol];
                 }
             }
 #pragma unroll
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
             float bcol[Cfg::NR][4];
 #pragma unroll
             for (int jn = 0; jn < Cfg::NR; ++jn) {
-                const int64_t col0 = n0 + wn * (BN / 2) + jn * 16 + lg * 4;
+                const int64_t col0 = n0 + wn * Cfg::kWaveN + jn * 16 + lg * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     bcol[jn][r] = 0.f;
@@ -316,7 +343,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
-                const int64_t row = m0 + wm * (BM / 2) + i * 16 + li;
+                const int64_t row = m0 + wm * Cfg::kWaveM + i * 16 + li;
                 float* crow = Cout + row * a.ldc;
                 const bool row_ok = row < a.M;
                 // all loads of the epilogue (bias above, old C when accumulating) are issued as independent
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
                     if (a.accumulate) {
 #pragma unroll
                         for (int jn = 0; jn < Cfg::NR; ++jn) {
-                            const int64_t col0 = n0 + wn * (BN / 2) + jn * 16 + lg * 4;
+                            const int64_t col0 = n0 + wn * Cfg::kWaveN + jn * 16 + lg * 4;
                             oldv[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (row_ok && col0 < a.N) oldv[jn] = *reinterpret_cast<const float4*>(crow + col0);
                         }
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_kernel(const GemmArgs a) {
                 }
 #pragma unroll
                 for (int jn = 0; jn < Cfg::NR; ++jn) {
-                    const int64_t col0 = n0 + wn * (BN / 2) + jn * 16 + lg * 4;
+                    const int64_t col0 = n0 + wn * Cfg::kWaveN + jn * 16 + lg * 4;
                     float x[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -391,14 +418,11 @@ struct SplitPlan {
     int grid;
 };
 
-template <int BM, int BN, bool AT, bool BT>
-constexpr int blocks_per_cu() { return (2 * GemmCfg<BM, BN, AT, BT>::kLdsBytes <= 160 * 1024) ? 2 : 1; }
-
 // grid = resident persistent blocks; transA additionally slices K so that (tiles x slices) fills the grid
-template <int BM, int BN, bool AT, bool BT>
+template <int BM, int BN, bool AT, bool BT, int WM = 2, int WN = 2>
 SplitPlan plan_grid(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
-    const int G = kNumCU * blocks_per_cu<BM, BN, AT, BT>();
+    const int G = kNumCU * GemmCfg<BM, BN, AT, BT, WM, WN>::kBlocksPerCU;
     SplitPlan sp{1, cdiv(K, BK) * BK, 0};
     if (AT) {
         int64_t ns = std::max<int64_t>(1, G / tiles);
@@ -412,26 +436,26 @@ SplitPlan plan_grid(int64_t M, int64_t N, int64_t K) {
     return sp;
 }
 
-template <int BM, int BN, bool AT, bool BT>
+template <int BM, int BN, bool AT, bool BT, int WM = 2, int WN = 2>
 int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                 float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
                 hipStream_t st) {
-    using Cfg = GemmCfg<BM, BN, AT, BT>;
-    const SplitPlan sp = plan_grid<BM, BN, AT, BT>(M, N, K);
+    using Cfg = GemmCfg<BM, BN, AT, BT, WM, WN>;
+    const SplitPlan sp = plan_grid<BM, BN, AT, BT, WM, WN>(M, N, K);
     GemmArgs a{M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, sp.kchunk, (int)cdiv(M, BM), (int)cdiv(N, BN),
                sp.nsplit, 0};
     a.xcd_order = (a.n_mt >= 4 * kNumXCD) ? 1 : 0;
     const dim3 grid((unsigned)sp.grid);
 #define GEOGCN_GEMM_LAUNCH(ACT, MODE)                                                                    \
     do {                                                                                                  \
-        auto kern = gemm_kernel<BM, BN, AT, BT, ACT, MODE>;                                               \
+        auto kern = gemm_kernel<BM, BN, AT, BT, ACT, MODE, 0, WM, WN>;                                    \
         static bool attr_done = false;                                                                    \
         if (!attr_done) {                                                                                 \
             GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                            (int)Cfg::kLdsBytes));                                         \
             attr_done = true;                                                                             \
         }                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(TPB), Cfg::kLdsBytes, st, a);                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NTH), Cfg::kLdsBytes, st, a);                             \
         GEOGCN_LAUNCH_CHECK("gemm_kernel");                                                               \
     } while (0)
 
@@ -467,10 +491,26 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
 
 // ---- tile selection ------------------------------------------------------------------------------
 // 128 or 160 per dimension, whichever wastes fewer MFMA columns on padding (300 -> 2x160, 256 -> 2x128,
-// 600 -> 4x160).  The long dimension of NN / NT always uses BM = 128 (thousands of tiles).
+// 600 -> 4x160).  The long dimension of NN / NTH always uses BM = 128 (thousands of tiles).
 inline int pick_tile(int64_t n) {
     const int64_t w128 = cdiv(n, 128) * 128, w160 = cdiv(n, 160) * 160;
     return (w160 < w128) ? 160 : 128;
+}
+
+// 8-wave "wide" tiles for transA (dW = H^T.dZ): one tile spans all of N (161..320 columns), 2 x 4 waves, one
+// block per CU.  Both streamed operands are staged once instead of once per N tile, and the 160x160 tile of the
+// 4-wave kernel only fits one block (= one wave per SIMD) per CU: 0.83 -> 0.755 ms at 440000x300x300.  For
+// NN / NT the 4-wave tiles with two blocks per CU measured 3 % faster, so those keep them.  GEOGCN_GEMM_WIDE=0
+// disables (A/B switch).
+inline int wide_bn(int64_t N) {
+    static const int enabled = [] {
+        const char* e = getenv("GEOGCN_GEMM_WIDE");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    if (!enabled) return 0;
+    if (N > 256 && N <= 320) return 320;
+    if (N > 160 && N <= 256) return 256;
+    return 0;
 }
 
 template <bool AT, bool BT>
@@ -480,6 +520,9 @@ int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float*
 #define GEOGCN_T(BM_, BN_)                                                                                   \
     if (bm == BM_ && bn == BN_)                                                                              \
         return launch_gemm<BM_, BN_, AT, BT>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+#define GEOGCN_W(BM_, BN_)                                                                                   \
+    if (bm == BM_ && bn == BN_)                                                                              \
+        return launch_gemm<BM_, BN_, AT, BT, 2, 4>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
     GEOGCN_T(128, 128)
     GEOGCN_T(128, 160)
     if constexpr (BT) {
@@ -488,15 +531,20 @@ int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float*
     if constexpr (AT) {
         GEOGCN_T(160, 128)
         GEOGCN_T(160, 160)
+        GEOGCN_W(128, 256)
+        GEOGCN_W(128, 320)
+        GEOGCN_W(160, 256)
+        GEOGCN_W(160, 320)
     }
 #undef GEOGCN_T
+#undef GEOGCN_W
     set_error("gemm_f32: no kernel for tile %dx%d", bm, bn);
     return GEOGCN_E_ARG;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM = 2, int WN = 2>
 size_t splitk_ws_bytes(int64_t M, int64_t N, int64_t K) {
-    const SplitPlan sp = plan_grid<BM, BN, true, false>(M, N, K);
+    const SplitPlan sp = plan_grid<BM, BN, true, false, WM, WN>(M, N, K);
     return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)((N + 3) & ~(int64_t)3) * sizeof(float);
 }
 
@@ -512,7 +560,9 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
     (void)transB;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!transA) return precision == GEOGCN_GEMM_F32 ? 0 : gemm_bf16_workspace_bytes(precision, N, K);
-    const int bm = pick_tile(M), bn = pick_tile(N);
+    const int bm = pick_tile(M), bn = pick_tile(N), wbn = wide_bn(N);
+    if (wbn == 320) return bm == 160 ? splitk_ws_bytes<160, 320, 2, 4>(M, N, K) : splitk_ws_bytes<128, 320, 2, 4>(M, N, K);
+    if (wbn == 256) return bm == 160 ? splitk_ws_bytes<160, 256, 2, 4>(M, N, K) : splitk_ws_bytes<128, 256, 2, 4>(M, N, K);
     if (bm == 128 && bn == 128) return splitk_ws_bytes<128, 128>(M, N, K);
     if (bm == 128 && bn == 160) return splitk_ws_bytes<128, 160>(M, N, K);
     if (bm == 160 && bn == 128) return splitk_ws_bytes<160, 128>(M, N, K);
@@ -548,13 +598,14 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
                                   ws_bytes, st);
     float* C = (float*)Cv;
-    const int bn = pick_tile(N);
+    const int wbn = transA ? wide_bn(N) : 0;
+    const int bn = wbn ? wbn : pick_tile(N);
     if (transA)
         return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
                                            ws_bytes, st);
     if (transB)
-        return dispatch_tiles<false, true>(bn == 160 ? 96 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate,
-                                           ws, ws_bytes, st);
+        return dispatch_tiles<false, true>((bn == 160) ? 96 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act,
+                                           accumulate, ws, ws_bytes, st);
     return dispatch_tiles<false, false>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
 }
 
