@@ -50,6 +50,8 @@ SIGNATURES = {
     'geogcn_colsum_workspace_bytes': (c_sz, [c_i64, c_i32]),
     'geogcn_colsum_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_dropout_mask_philox': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_u64, c_ptr, c_ptr]),
+    'geogcn_dropout_mask_philox_ctr': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'geogcn_counter_add_i64': (c_i32, [c_ptr, c_i64, c_ptr]),
     'geogcn_dropout_apply_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr]),
     'geogcn_softmax_rows_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     'geogcn_ce_metrics_workspace_bytes': (c_sz, [c_i64]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     'geogcn_unpack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_ptr]),
+    'geogcn_adam_step_ctr_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
+                                         c_ptr, c_f32, c_f32, c_ptr]),
     'geogcn_reg_penalty_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_sz, c_ptr]),
 }
 

@@ -72,6 +72,11 @@ __device__ __forceinline__ float apply_act(float x) {
     }
 }
 
+// Zero-fill by a kernel instead of hipMemsetAsync: inside a captured step (hipGraph) a memset node followed
+// by a kernel that accumulates into the same buffer was observed to race on ROCm 7.2 when the graph is
+// launched on an idle device (tests/test_e2e_gpu.py::test_hip_graph_...); kernel -> kernel edges are safe.
+int zero_fill_async(void* ptr, size_t bytes, hipStream_t st);        // core.hip; bytes % 4 == 0
+
 // gemm_bf16.hip
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K);
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,

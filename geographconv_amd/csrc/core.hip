@@ -1,6 +1,8 @@
 // ABI version + thread-local error text for libgeogcn.so.
 #include "common.h"
 
+#include <algorithm>
+
 #include <stdarg.h>
 
 namespace geogcn {
@@ -13,6 +15,21 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+
+int zero_fill_async(void* ptr, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    const size_t n = bytes / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 16);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, (uint32_t*)ptr, n);
+    GEOGCN_LAUNCH_CHECK("zero_fill_kernel");
+    return 0;
 }
 }  // namespace geogcn
 

@@ -224,8 +224,12 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
     k[1] += 0xBB67AE85u;
 }
 
+// `calls` (nullable): device-resident call counter of a captured step (hipGraph replays cannot change kernel
+// arguments); the stream position is then (calls * per_call + base) / 4 quads, as the host computes it.
 __global__ __launch_bounds__(TPB) void dropout_mask_kernel(int64_t total, float keep_prob, uint64_t seed,
-                                                           uint64_t offset, uint8_t* __restrict__ mask) {
+                                                           uint64_t offset, const int64_t* __restrict__ calls,
+                                                           int64_t per_call, int64_t base, uint8_t* __restrict__ mask) {
+    if (calls) offset = (uint64_t)((*calls * per_call + base) / 4);
     const int64_t quads = (total + 3) / 4;
     for (int64_t qd = (int64_t)blockIdx.x * TPB + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * TPB) {
         const uint64_t ctr = (uint64_t)qd + offset;
@@ -243,6 +247,8 @@ __global__ __launch_bounds__(TPB) void dropout_mask_kernel(int64_t total, float 
         }
     }
 }
+
+__global__ void counter_add_kernel(int64_t* c, int64_t delta) { *c += delta; }
 
 // ---- column sums: pass 1 = per row-chunk partials, pass 2 = partials added in chunk order ----------
 __global__ __launch_bounds__(TPB) void colsum_partial_kernel(int64_t n, int F, const float* __restrict__ X,
@@ -503,7 +509,7 @@ int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* 
     GEOGCN_REQUIRE(out, GEOGCN_E_NULL, "colsum_f32: null out");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        GEOGCN_HIP(hipMemsetAsync(out, 0, (size_t)F * sizeof(float), st));
+        { const int zrc = zero_fill_async(out, (size_t)F * sizeof(float), st); if (zrc) return zrc; }
         return 0;
     }
     GEOGCN_REQUIRE(X && ldx >= F, GEOGCN_E_NULL, "colsum_f32: null X or ldx < F");
@@ -527,8 +533,29 @@ int geogcn_dropout_mask_philox(int64_t n, int32_t F, float p_drop, uint64_t seed
     GEOGCN_REQUIRE(keep_mask, GEOGCN_E_NULL, "dropout_mask_philox: null mask");
     const int64_t total = n * F;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid((total + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream,
-                       total, 1.0f - p_drop, seed, offset, keep_mask);
+                       total, 1.0f - p_drop, seed, offset, (const int64_t*)nullptr, (int64_t)0, (int64_t)0, keep_mask);
     GEOGCN_LAUNCH_CHECK("dropout_mask_kernel");
+    return 0;
+}
+
+int geogcn_dropout_mask_philox_ctr(int64_t n, int32_t F, float p_drop, uint64_t seed, const int64_t* calls_dev,
+                                   int64_t per_call_elems, int64_t base_elems, uint8_t* keep_mask, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0 && per_call_elems >= 0 && base_elems >= 0, GEOGCN_E_SIZE,
+                   "dropout_mask_philox_ctr: negative size");
+    GEOGCN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GEOGCN_E_ARG, "dropout_mask_philox_ctr: p=%f outside [0,1)", p_drop);
+    if (n == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(keep_mask && calls_dev, GEOGCN_E_NULL, "dropout_mask_philox_ctr: null pointer");
+    const int64_t total = n * F;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid((total + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream,
+                       total, 1.0f - p_drop, seed, (uint64_t)0, calls_dev, per_call_elems, base_elems, keep_mask);
+    GEOGCN_LAUNCH_CHECK("dropout_mask_kernel");
+    return 0;
+}
+
+int geogcn_counter_add_i64(int64_t* counter_dev, int64_t delta, void* stream) {
+    GEOGCN_REQUIRE(counter_dev, GEOGCN_E_NULL, "counter_add_i64: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, delta);
+    GEOGCN_LAUNCH_CHECK("counter_add_kernel");
     return 0;
 }
 

@@ -158,10 +158,23 @@ __global__ __launch_bounds__(TPB) void ce_bwd_kernel(int C, const float* __restr
     }
 }
 
+// lasagne.updates.adam: a_t = lr * sqrt(1 - b2^t) / (1 - b1^t), computed in fp32 like floatX=float32
+__host__ __device__ __forceinline__ float adam_a_t(float lr, float b1, float b2, float t) {
+    return lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+}
+// captured steps: t lives on the device.  state[0] = step count (incremented here), state[1] = bits of a_t
+__global__ void adam_next_step_kernel(int64_t* state, float lr, float b1, float b2) {
+    const int64_t t = state[0] + 1;
+    state[0] = t;
+    reinterpret_cast<float*>(state + 1)[0] = adam_a_t(lr, b1, b2, (float)t);
+}
+
 __global__ __launch_bounds__(TPB) void adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ regmask, float a_t, float b1, float b2,
+                                                   const float* __restrict__ regmask, float a_t,
+                                                   const float* __restrict__ a_t_dev, float b1, float b2,
                                                    float eps, float l1, float l2) {
+    if (a_t_dev) a_t = *a_t_dev;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
         const float pi = p[i];
         float gi = g[i];
@@ -244,7 +257,7 @@ int geogcn_ce_metrics_f32(int32_t C, const float* probs, int64_t ldp, const int3
     GEOGCN_REQUIRE(out2, GEOGCN_E_NULL, "ce_metrics_f32: null out");
     hipStream_t st = (hipStream_t)stream;
     if (n_idx == 0) {
-        GEOGCN_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(float), st));
+        { const int zrc = zero_fill_async(out2, 2 * sizeof(float), st); if (zrc) return zrc; }
         return 0;
     }
     GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "ce_metrics_f32: null pointer");
@@ -267,7 +280,7 @@ int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t 
     GEOGCN_REQUIRE(dlogits, GEOGCN_E_NULL, "softmax_ce_bwd_f32: null dlogits");
     GEOGCN_REQUIRE(ldd >= C, GEOGCN_E_SIZE, "softmax_ce_bwd_f32: ldd < C");
     hipStream_t st = (hipStream_t)stream;
-    GEOGCN_HIP(hipMemsetAsync(dlogits, 0, (size_t)n * (size_t)ldd * sizeof(float), st));
+    { const int zrc = zero_fill_async(dlogits, (size_t)n * (size_t)ldd * sizeof(float), st); if (zrc) return zrc; }
     if (n_idx == 0) return 0;
     GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "softmax_ce_bwd_f32: null pointer");
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)cdiv(n_idx, kWavesPerBlock)), dim3(TPB), 0, st, C, probs, ldp, idx,
@@ -281,11 +294,27 @@ int geogcn_adam_step_f32(int64_t n, float* p, float* g, float* m, float* v, cons
     GEOGCN_REQUIRE(n >= 0 && t >= 1, GEOGCN_E_SIZE, "adam_step_f32: n=%lld t=%d", (long long)n, t);
     if (n == 0) return 0;
     GEOGCN_REQUIRE(p && g && m && v, GEOGCN_E_NULL, "adam_step_f32: null pointer");
-    // lasagne.updates.adam: a_t = lr * sqrt(1 - b2^t) / (1 - b1^t), computed in fp32 like floatX=float32
-    const float a_t = lr * sqrtf(1.0f - powf(b2, (float)t)) / (1.0f - powf(b1, (float)t));
+    const float a_t = adam_a_t(lr, b1, b2, (float)t);
     const int64_t blocks = std::min<int64_t>(cdiv(n, TPB), (int64_t)kNumCU * 8);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, n, p, g, m, v,
-                       (l1 != 0.f || l2 != 0.f) ? regmask : nullptr, a_t, b1, b2, eps, l1, l2);
+                       (l1 != 0.f || l2 != 0.f) ? regmask : nullptr, a_t, (const float*)nullptr, b1, b2, eps, l1, l2);
+    GEOGCN_LAUNCH_CHECK("adam_kernel");
+    return 0;
+}
+
+int geogcn_adam_step_ctr_f32(int64_t n, float* p, float* g, float* m, float* v, const float* regmask, float lr,
+                             float b1, float b2, float eps, int64_t* state_dev, float l1, float l2, void* stream) {
+    GEOGCN_REQUIRE(n >= 0, GEOGCN_E_SIZE, "adam_step_ctr_f32: n=%lld", (long long)n);
+    GEOGCN_REQUIRE(state_dev, GEOGCN_E_NULL, "adam_step_ctr_f32: null state");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_next_step_kernel, dim3(1), dim3(1), 0, st, state_dev, lr, b1, b2);
+    GEOGCN_LAUNCH_CHECK("adam_next_step_kernel");
+    if (n == 0) return 0;
+    GEOGCN_REQUIRE(p && g && m && v, GEOGCN_E_NULL, "adam_step_ctr_f32: null pointer");
+    const int64_t blocks = std::min<int64_t>(cdiv(n, TPB), (int64_t)kNumCU * 8);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(TPB), 0, st, n, p, g, m, v,
+                       (l1 != 0.f || l2 != 0.f) ? regmask : nullptr, 0.f, reinterpret_cast<const float*>(state_dev + 1), b1,
+                       b2, eps, l1, l2);
     GEOGCN_LAUNCH_CHECK("adam_kernel");
     return 0;
 }
@@ -296,7 +325,7 @@ int geogcn_reg_penalty_f32(int64_t n, const float* p, const float* regmask, floa
     GEOGCN_REQUIRE(out, GEOGCN_E_NULL, "reg_penalty_f32: null out");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        GEOGCN_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+        { const int zrc = zero_fill_async(out, sizeof(float), st); if (zrc) return zrc; }
         return 0;
     }
     GEOGCN_REQUIRE(p, GEOGCN_E_NULL, "reg_penalty_f32: null p");

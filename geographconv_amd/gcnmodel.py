@@ -10,6 +10,7 @@ them (gcnmain.py:172-179,221,226) and are uploaded once per distinct matrix."""
 from __future__ import annotations
 
 import logging
+import os
 import sys
 
 import numpy as np
@@ -242,7 +243,7 @@ class GraphConv():
     '''
 
     def __init__(self, input_size, output_size, hid_size_list, regul_coef, drop_out, dtype='float32',
-                 batchnorm=False, highway=True, device=None, comm=None, gemm_precision=None):
+                 batchnorm=False, highway=True, device=None, comm=None, gemm_precision=None, hip_graph=None):
         self.input_size = int(input_size)
         self.output_size = int(output_size)
         self.hid_size_list = list(hid_size_list)
@@ -264,6 +265,12 @@ class GraphConv():
         self._injected_mask = None
         self.hub_row_bytes = None         # SpMM cache hint (ops.CSR): off -- no gain at full-row granularity
         self._force_dist = False          # tests: run the partitioned code path at world_size 1
+        # capture the whole f_train step (~110 launches) in a hipGraph after two eager steps and replay it: for
+        # small graphs (CMU shape) the step is bound by launch overhead, not by the GPU.  Opt-in (argument or
+        # GEOGCN_HIP_GRAPH=1); single GPU only; the inputs of f_train must stay the same objects between calls.
+        self.hip_graph = (os.environ.get('GEOGCN_HIP_GRAPH', '0') == '1') if hip_graph is None else bool(hip_graph)
+        self._hg = None
+        self._adam_state_dev = None
         self.best_params = None
         logging.info('highway is {}'.format(self.highway))
 
@@ -305,6 +312,8 @@ class GraphConv():
         self.f_gates = [self._make_f_gate(l) for l in self.gate_layers]
         self.init_params = L.get_all_param_values(self.l_out)
         self._scal = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._hg = None                    # a captured step refers to the old arenas
+        self._adam_state_dev = None
         return self.l_out
 
     def _dist(self, comm):
@@ -390,9 +399,23 @@ class GraphConv():
     def f_train(self, X, y_train, y_dev, A, train_indices, dev_indices):
         """One full-graph forward + backward + Adam step.  -> [train_loss, train_acc, dev_loss,
         dev_acc, output(N x C)]; dev metrics come from the same dropout-ON pass (gcnmodel.py:378)."""
+        g = self._device_graph(X, A)
+        comm = g['comm']
+        if self.hip_graph and not self._dist(comm) and self._injected_mask is None and self.device.type == 'cuda':
+            P, n_tr, n_dv = self._train_step_graphed(g, X, y_train, y_dev, A, train_indices, dev_indices)
+        else:
+            P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, None)
+        s = [float(v) for v in self._scal.cpu().numpy()]   # the one host sync of the step
+        l_tr = s[0] / max(1, n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
+        out = [np.float32(l_tr), np.float64(s[1] / max(1, n_tr)), np.float32(s[2] / max(1, n_dv)),
+               np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm)]
+        return out
+
+    def _train_step(self, g, y_train, y_dev, A, train_indices, dev_indices, counters):
+        """Enqueue one step (no host synchronisation).  `counters`: None = host-side step / dropout counters
+        (kernel arguments); 'sync' / 'captured' = device-resident counters (hipGraph path)."""
         K = backend.active()
         import torch
-        g = self._device_graph(X, A)
         comm = g['comm']
         tr_idx, tr_y, n_tr = self._device_indices(comm, train_indices, y_train)
         dv_idx, dv_y, n_dv = self._device_indices(comm, dev_indices, y_dev)
@@ -404,7 +427,7 @@ class GraphConv():
             mask = torch.from_numpy(np.ascontiguousarray(m)).to(self.device)
         tape = {}
         kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if self._dist(comm) else None,
-                  gemm_precision=self.gemm_precision)
+                  gemm_precision=self.gemm_precision, device_counters=counters)
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
         sc = self._scal
@@ -421,14 +444,56 @@ class GraphConv():
         if self._dist(comm):
             comm.all_reduce_sum_(self.store.g)
             comm.all_reduce_sum_(sc[0:4])
-        self.adam_t += 1
-        K.adam_step(self.store.p, self.store.g, self.store.m, self.store.v, self.store.regmask, self.lr,
-                    self.beta1, self.beta2, self.epsilon, self.adam_t, l1=self.regul_coef, l2=self.regul_coef)
-        s = [float(v) for v in sc.cpu().numpy()]   # the one host sync of the step
-        l_tr = s[0] / max(1, n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
-        out = [np.float32(l_tr), np.float64(s[1] / max(1, n_tr)), np.float32(s[2] / max(1, n_dv)),
-               np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm)]
-        return out
+        st = self.store
+        if counters:
+            if self._adam_state_dev is None:
+                self._adam_state_dev = torch.zeros(2, dtype=torch.int64, device=self.device)
+                counters = 'sync'
+            if counters == 'sync':
+                self._adam_state_dev[0:1].fill_(self.adam_t)
+            K.adam_step_ctr(st.p, st.g, st.m, st.v, st.regmask, self.lr, self.beta1, self.beta2, self.epsilon,
+                            self._adam_state_dev, l1=self.regul_coef, l2=self.regul_coef)
+            self.adam_t += 1
+        else:
+            self.adam_t += 1
+            K.adam_step(st.p, st.g, st.m, st.v, st.regmask, self.lr, self.beta1, self.beta2, self.epsilon,
+                        self.adam_t, l1=self.regul_coef, l2=self.regul_coef)
+        return P, n_tr, n_dv
+
+    def _train_step_graphed(self, g, X, y_train, y_dev, A, train_indices, dev_indices):
+        """Two eager steps (everything allocated, every kernel attribute set), then capture the step once and
+        replay it.  Step and dropout-stream counters live on the device, so each replay is a new step."""
+        import torch
+
+        def ident(a):
+            a = np.asarray(a)
+            return (a.ctypes.data, a.shape, int(a[:16].sum()) if a.size else 0)
+        key = (id(X), id(A), ident(y_train), ident(y_dev), ident(train_indices), ident(dev_indices))
+        hg = self._hg
+        if hg is None or hg['key'] != key:
+            hg = self._hg = {'key': key, 'eager': 0, 'graph': None}
+        if hg['graph'] is not None:
+            hg['graph'].replay()
+            self.adam_t += 1                                   # host mirrors of the device counters
+            for l in hg['dropouts']:
+                l._calls += 1
+            return hg['P'], hg['n_tr'], hg['n_dv']
+        if hg['eager'] < 2:
+            hg['eager'] += 1
+            return self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, 'sync')
+        torch.cuda.synchronize(self.device)
+        # bring the device counters up to date outside the capture, then record one step
+        drops = [l for l in L.get_all_layers(self.l_out) if isinstance(l, L.DropoutLayer) and l.p > 0]
+        for l in drops:
+            if l._calls_dev is not None:
+                l._calls_dev.fill_(l._calls)
+        self._adam_state_dev[0:1].fill_(self.adam_t)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, 'captured')
+        hg.update(graph=graph, P=P, n_tr=n_tr, n_dv=n_dv, dropouts=drops)
+        graph.replay()          # capture records, it does not run: this replay IS the step just counted
+        return P, n_tr, n_dv
 
     def _lazy_output(self, P, comm):
         def fetch():

@@ -351,6 +351,7 @@ class DropoutLayer(Layer):
         super().__init__(incoming, name)
         self._seed = int(np.random.randint(1, 2147462579))
         self._calls = 0
+        self._calls_dev = None
         self.p = p
         self.rescale = rescale
 
@@ -371,8 +372,22 @@ class DropoutLayer(Layer):
             # (rank-consistent when F % 4 == 0: Philox yields 4 values per counter)
             F = input.F
             N_total = input.n if comm is None or comm.part is None else comm.part.N
-            offset_quads = ((self._calls * N_total + r0) * F) // 4
-            mask = K.dropout_mask(input.n, F, self.p, self._seed, offset_quads, input.device)
+            ctr = kwargs.get('device_counters')          # None | 'sync' | 'captured'  (GraphConv hipGraph path)
+            if ctr:
+                # same stream position, read from a device-resident call counter so that a captured step can
+                # be replayed: offset = (calls * N_total * F + r0 * F) / 4
+                import torch
+                if self._calls_dev is None or self._calls_dev.device != input.device:
+                    self._calls_dev = torch.zeros(1, dtype=torch.int64, device=input.device)
+                    ctr = 'sync'
+                if ctr == 'sync':
+                    self._calls_dev.fill_(self._calls)
+                mask = K.dropout_mask_ctr(input.n, F, self.p, self._seed, self._calls_dev, N_total * F, r0 * F,
+                                          input.device)
+                K.counter_add(self._calls_dev, 1)
+            else:
+                offset_quads = ((self._calls * N_total + r0) * F) // 4
+                mask = K.dropout_mask(input.n, F, self.p, self._seed, offset_quads, input.device)
             self._calls += 1
         y = K.dropout_apply(input, mask, self.p)
         if tape is not None:

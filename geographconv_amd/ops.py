@@ -173,9 +173,16 @@ class CSR:
     declared hubs, each row's nonzeros are reordered [hubs | rest] (sorted inside each part) and the
     kernel gathers the rest with non-temporal loads so the hub rows stay in L2."""
 
-    def __init__(self, m: sps.spmatrix, device, long_row_nnz=256, chunk_nnz=128, hub_row_bytes=None):
+    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None, hub_row_bytes=None):
         require_gpu()
         m = sps.csr_matrix(m)
+        if long_row_nnz is None:
+            # a row is walked by ONE 16-lane group, two nonzeros per ~0.7 us round trip: on a small matrix (CMU
+            # shape) a 256-nonzero row alone takes ~90 us, longer than everything else in the launch -- cut rows
+            # earlier there; on a large one the other rows hide it and fewer partial sums are cheaper
+            long_row_nnz, chunk_nnz = (256, chunk_nnz or 128) if m.nnz >= 2_000_000 else (48, chunk_nnz or 48)
+        elif chunk_nnz is None:
+            chunk_nnz = 128
         if not m.has_sorted_indices:
             m = m.copy()
             m.sort_indices()
@@ -359,6 +366,19 @@ def dropout_mask(n, F, p, seed, offset, device, out=None):
     return out
 
 
+def dropout_mask_ctr(n, F, p, seed, calls_dev, per_call_elems, base_elems, device, out=None):
+    """Same stream as dropout_mask, positioned by a device-resident call counter (captured steps)."""
+    if out is None:
+        out = torch.empty((n, F), dtype=torch.uint8, device=device)
+    check(_ffi.lib().geogcn_dropout_mask_philox_ctr(n, F, float(p), int(seed), _p(calls_dev), int(per_call_elems),
+                                                    int(base_elems), _p(out), _stream()), 'dropout_mask_philox_ctr')
+    return out
+
+
+def counter_add(counter_dev, delta=1):
+    check(_ffi.lib().geogcn_counter_add_i64(_p(counter_dev), int(delta), _stream()), 'counter_add_i64')
+
+
 def dropout_apply(X: DMat, keep_mask, p, out: DMat = None):
     out = X.like() if out is None else out
     check(_ffi.lib().geogcn_dropout_apply_f32(X.n, X.F, _p(X.t), X.ld, _p(keep_mask), float(p), _p(out.t),
@@ -425,6 +445,12 @@ def unpack_panels(inp: torch.Tensor, R: int, W: int, wp: int, out: DMat):
 def adam_step(p, g, m, v, regmask, lr, b1, b2, eps, t, l1=0.0, l2=0.0):
     check(_ffi.lib().geogcn_adam_step_f32(p.numel(), _p(p), _p(g), _p(m), _p(v), _p(regmask), lr, b1, b2, eps,
                                           int(t), float(l1), float(l2), _stream()), 'adam_step_f32')
+
+
+def adam_step_ctr(p, g, m, v, regmask, lr, b1, b2, eps, state_dev, l1=0.0, l2=0.0):
+    """adam_step with the step index on the device (state_dev: int64[2], see geogcn.h): graph-capturable."""
+    check(_ffi.lib().geogcn_adam_step_ctr_f32(p.numel(), _p(p), _p(g), _p(m), _p(v), _p(regmask), lr, b1, b2, eps,
+                                              _p(state_dev), float(l1), float(l2), _stream()), 'adam_step_ctr_f32')
 
 
 def reg_penalty(p, regmask, l1, l2, out=None):

@@ -172,6 +172,13 @@ int geogcn_colsum_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* 
  * parity runs inject the mask).  keep_mask[i*F + j] in {0,1}, dense (no pitch).                */
 int geogcn_dropout_mask_philox(int64_t n, int32_t F, float p_drop, uint64_t seed, uint64_t offset,
                                uint8_t* keep_mask, void* stream);
+/* Captured steps (hipGraph): a replay cannot change kernel arguments, so the stream position comes from a
+ * device-resident call counter: offset = (calls_dev[0] * per_call_elems + base_elems) / 4 quads -- the value
+ * the host would have passed to geogcn_dropout_mask_philox.  geogcn_counter_add_i64 advances such a counter
+ * from inside the captured stream.                                                                  */
+int geogcn_dropout_mask_philox_ctr(int64_t n, int32_t F, float p_drop, uint64_t seed, const int64_t* calls_dev,
+                                   int64_t per_call_elems, int64_t base_elems, uint8_t* keep_mask, void* stream);
+int geogcn_counter_add_i64(int64_t* counter_dev, int64_t delta, void* stream);
 /* Y = X * keep_mask / (1-p)  (forward; the backward is the same call on the gradient)          */
 int geogcn_dropout_apply_f32(int64_t n, int32_t F, const float* X, int64_t ld,
                              const uint8_t* keep_mask, float p_drop, float* Y, void* stream);
@@ -220,6 +227,10 @@ int geogcn_unpack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* 
 int geogcn_adam_step_f32(int64_t n, float* p, float* g /* updated to g' when l1|l2 != 0 */, float* m, float* v,
                          const float* regmask, float lr, float b1, float b2, float eps, int32_t t,
                          float l1, float l2, void* stream);
+/* Same update with the step index on the device (captured steps): state_dev[0] = number of steps taken so
+ * far (incremented by this call before use), state_dev[1] = scratch (bits of the fp32 step size a_t).   */
+int geogcn_adam_step_ctr_f32(int64_t n, float* p, float* g, float* m, float* v, const float* regmask, float lr,
+                             float b1, float b2, float eps, int64_t* state_dev, float l1, float l2, void* stream);
 /* penalty value: sum regmask*(l1*|p| + l2*p^2) -> out[0] (deterministic two-pass)               */
 int geogcn_reg_penalty_f32(int64_t n, const float* p, const float* regmask, float l1, float l2,
                            float* out, void* ws, size_t ws_bytes, void* stream);

@@ -246,3 +246,46 @@ def test_config5_bf16_six_layer_600_hidden():
     st = O.AdamState(params)
     _, r, _ = O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.0, None)
     assert abs(o[0] - r[0]) <= 2e-2 * abs(r[0])
+
+
+def test_hip_graph_replay_equals_eager_steps(cmu):
+    """hip_graph=True: two eager steps, one captured, then replays.  The device-resident Adam step index and
+    dropout stream position make every replay a NEW step: losses, probabilities and parameters follow the eager
+    run (same kernels in the same order; the only difference is a_t evaluated by the device's powf)."""
+    import time
+    import torch
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    runs = {}
+    for mode in (False, True):
+        clf = GraphConv(c['X'].shape[1], c['C'], c['hid'], 1e-6, 0.5, highway=True, hip_graph=mode)
+        clf.build_model(c['A'], seed=77)
+        L.set_all_param_values(clf.l_out, c['params'])
+        ytr, ydv = c['Y'][c['tr']], c['Y'][c['dev']]
+        hist = []
+        for step in range(7):
+            if step == 4:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            out = clf.f_train(c['X'], ytr, ydv, c['A'], c['tr'], c['dev'])
+            hist.append((float(out[0]), float(out[1]), float(out[2]), float(out[3])))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        runs[mode] = (hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out), clf.adam_t, dt, clf)
+    (he, Pe, pe, te, dte, _), (hg, Pg, pg, tg, dtg, clfg) = runs[False], runs[True]
+    print('eager ', [h[0] for h in he]); print('graph ', [h[0] for h in hg])
+    assert clfg._hg is not None and clfg._hg['graph'] is not None          # it really replayed a captured graph
+    assert te == tg == 7 and clfg.l_drop._calls == 7
+    assert len(set(h[0] for h in hg)) == 7                                  # seven different steps, not one replayed
+    for a, b in zip(he, hg):
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[2] - b[2]) <= 1e-5 * abs(a[2])
+        assert abs(a[1] - b[1]) <= 2e-3 and abs(a[3] - b[3]) <= 2e-3
+    assert np.abs(Pe - Pg).max() <= 1e-5
+    for q, r in zip(pe, pg):
+        assert np.abs(q - r).max() <= 1e-4 * 0.02 + 1e-7
+    print("CMU step: eager %.3f ms, hipGraph replay %.3f ms" % (dte * 1e3, dtg * 1e3))
+    # changing an input object falls back to eager steps and a new capture
+    ytr2 = c['Y'][c['tr']].copy()
+    out = clfg.f_train(c['X'], ytr2, c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+    assert clfg._hg['graph'] is None and np.isfinite(out[0])
