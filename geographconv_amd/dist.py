@@ -92,7 +92,15 @@ class Comm:
         return K.DMat.empty(self.part.N, F, self.device, ld=K.gather_ld(F))
 
     def graph_spmm(self, A_csr, z, bias, act, F, tag=None):
-        return backend.active().spmm(A_csr, z, bias=bias, act=act, F=F)
+        return self.graph_spmm_end(self.graph_spmm_begin(A_csr, z, bias, act, F, tag))
+
+    # two-phase form: `begin` starts the exchange of Z, `end` waits for it and multiplies.  Work the caller
+    # enqueues between the two (the highway gate's GEMMs) overlaps the collective.
+    def graph_spmm_begin(self, A_csr, z, bias, act, F, tag=None):
+        return dict(A=A_csr, z=z, bias=bias, act=act, F=F, tag=tag, work=None)
+
+    def graph_spmm_end(self, h):
+        return backend.active().spmm(h['A'], h['z'], bias=h['bias'], act=h['act'], F=h['F'])
 
     def all_gather_rows(self, local):
         return local
@@ -171,21 +179,38 @@ class TorchDistComm(Comm):
         K = backend.active()
         return K.pad4((int(F) + self.world - 1) // self.world)
 
-    def graph_spmm(self, A_csr, z, bias, act, F, tag=None):
-        """act(A . Z + bias) for row-partitioned Z -> row-partitioned result (n_local x F)."""
+    def graph_spmm_begin(self, A_csr, z, bias, act, F, tag=None):
+        """Start act(A . Z + bias) for row-partitioned Z: the exchange of Z is issued asynchronously (RCCL runs it
+        on its own stream); finish with graph_spmm_end."""
         K = backend.active()
         part, W = self.part, self.world
+        h = dict(A=A_csr, bias=bias, act=act, F=F, tag=tag)
         if self.exchange == 'allgather':
             buf = self._gather_buffer(F, tag)
             R = part.R
-            self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group)
-            return K.spmm(A_csr, buf, bias=bias, act=act, F=F)
+            h['buf'] = buf
+            h['work'] = self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group,
+                                                         async_op=True)
+            return h
         R, wp = part.R, self.panel_width(F)
         n = W * R * wp
         send = self._flat(('send', wp, tag), n)
         recv = self._flat(('recv', wp, tag), n)
         K.pack_panels(z, R, W, wp, send)
-        self.dist.all_to_all_single(recv, send, group=self.group)
+        h.update(send=send, recv=recv, wp=wp, n=n)
+        h['work'] = self.dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return h
+
+    def graph_spmm_end(self, h):
+        """-> row-partitioned result (n_local x F)."""
+        K = backend.active()
+        part, W = self.part, self.world
+        if h['work'] is not None:
+            h['work'].wait()            # nccl: the compute stream waits for the collective; gloo: the host does
+        A_csr, bias, act, F, tag = h['A'], h['bias'], h['act'], h['F'], h['tag']
+        if self.exchange == 'allgather':
+            return K.spmm(A_csr, h['buf'], bias=bias, act=act, F=F)
+        R, wp, n, send, recv = part.R, h['wp'], h['n'], h['send'], h['recv']
         zslab = K.DMat(part.n_gathered, wp, t=recv.view(part.n_gathered, wp))     # panel `rank` of ALL rows
         bslab = None
         if bias is not None:

@@ -217,6 +217,8 @@ def _accumulate(dst, src):
 class DenseLayer(Layer):
     """y = nonlinearity(x . W + b)   (lasagne DenseLayer; the highway gate, gcnmodel.py:285)."""
 
+    early_starts = {'fwd': 0, 'bwd': 0}     # exchanges started ahead of their layer (diagnostics / tests)
+
     def __init__(self, incoming, num_units, W=_init.GlorotUniform(), b=_init.Constant(0.), nonlinearity=_nl.rectify,
                  name=None, **kwargs):
         super().__init__(incoming, name)
@@ -225,6 +227,7 @@ class DenseLayer(Layer):
         num_inputs = int(np.prod(self.input_shape[1:]))
         self.W = self.add_param(W, (num_inputs, self.num_units), name="W")
         self.b = None if b is None else self.add_param(b, (self.num_units,), name="b", regularizable=False)
+        self._pending = {}          # started exchanges of the two-phase evaluation, keyed by (direction, tape)
 
     def get_output_shape_for(self, input_shape):
         return (input_shape[0], self.num_units)
@@ -280,9 +283,8 @@ class DenseLayer(Layer):
                         zf = K.cast_bf16(zf)
                 y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
-                z = comm.matmul_target(self.num_units, tag='fwd')
-                self._matmul(input, z, prec)
-                y = comm.graph_spmm(A.fwd, z, bias, act, self.num_units, tag='fwd')
+                h = self._pending.pop(('fwd', id(tape)), None) or self._exchange_begin_fwd(input, A, comm, bias, act, prec)
+                y = comm.graph_spmm_end(h)
         if self.nonlinearity.act is not None and not self.nonlinearity.fusable:
             y = K.bias_act(y, None, self.nonlinearity.act)       # relu / selu: bias was added in the epilogue
         if self.nonlinearity is _nl.softmax:
@@ -296,10 +298,71 @@ class DenseLayer(Layer):
             tape[self] = saved
         return y
 
+    # ---- two-phase evaluation (multi-GPU): start the exchange of the SpMM operand early, finish later --------
+    def _exchange_begin_fwd(self, input, A, comm, bias, act, prec):
+        z = comm.matmul_target(self.num_units, tag='fwd')
+        self._matmul(input, z, prec)
+        return comm.graph_spmm_begin(A.fwd, z, bias, act, self.num_units, tag='fwd')
+
+    def can_split(self, kwargs):
+        """True when this layer's work contains an exchange that other layers' work may overlap."""
+        return self._uses_graph(kwargs) and kwargs.get('A') is not None and kwargs.get('comm') is not None
+
+    def forward_begin(self, input, tape, **kwargs):
+        """Z = H.W and the start of its exchange; forward() picks the handle up.  get_output calls this as soon as
+        the input is available, BEFORE the layers that precede this one in the topological order but do not feed
+        it (the highway gate's GEMM then runs while RCCL moves Z)."""
+        self._check_input(input)
+        DenseLayer.early_starts['fwd'] += 1
+        bias = None if self.b is None else self.b.data
+        self._pending[('fwd', id(tape))] = self._exchange_begin_fwd(input, kwargs['A'], kwargs['comm'], bias,
+                                                                    self._fused_act(), kwargs.get('gemm_precision'))
+
+    def backward_begin(self, grad, tape, **kwargs):
+        """Activation gradient, bias gradient and the start of the exchange of dS; backward() finishes."""
+        DenseLayer.early_starts['bwd'] += 1
+        self._pending[('bwd', id(tape))] = self._backward_pre(grad, tape, kwargs)
+
+    def _backward_pre(self, grad, tape, kwargs):
+        """-> (dS, handle): dS = gradient at the pre-activation (bias gradient done); handle = the started
+        exchange of dS when this layer convolves over a partitioned graph, else None."""
+        K = backend.active()
+        s = tape[self]
+        y = s['y']
+        if isinstance(grad, PreAct):
+            dS = grad.m
+        elif self.nonlinearity is _nl.softmax:
+            raise NotImplementedError("softmax output expects the fused CE gradient (PreAct)")
+        elif self.nonlinearity.act == 0:
+            dS = grad
+        else:
+            uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
+            out = K.DMat.empty(grad.n, grad.F, grad.device, ld=K.gather_ld(grad.F)) if uses_graph else None
+            dS = K.act_bwd(grad, y, self.nonlinearity.act, out=out)
+        if self.b is not None and not (isinstance(grad, PreAct) and grad.bias_done):
+            K.colsum(dS, out=self.b.grad)
+        handle = None
+        A = kwargs.get('A') if self._uses_graph(kwargs) else None
+        comm = kwargs.get('comm')
+        if A is not None and comm is not None:
+            A_bwd = A.bwd
+            hint = kwargs.get('A_bwd_rows_hint')
+            if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
+                A_bwd = hint[1]
+            g = comm.matmul_target(self.num_units, tag='bwd')
+            g.copy_from(dS)
+            handle = comm.graph_spmm_begin(A_bwd, g, None, 0, self.num_units, tag='bwd')
+        return dS, handle
+
     def backward(self, grad, tape, into, need_input_grad=True, **kwargs):
         K = backend.active()
         s = tape[self]
         x, y = s['x'], s['y']
+        A = kwargs.get('A') if self._uses_graph(kwargs) else None
+        if A is not None and kwargs.get('comm') is not None:
+            dS, handle = self._pending.pop(('bwd', id(tape)), None) or self._backward_pre(grad, tape, kwargs)
+            dZ = kwargs['comm'].graph_spmm_end(handle)
+            return self._backward_post(x, dZ, into, need_input_grad, kwargs)
         if isinstance(grad, PreAct):
             dS = grad.m
         elif self.nonlinearity is _nl.softmax:
@@ -314,21 +377,19 @@ class DenseLayer(Layer):
             K.colsum(dS, out=self.b.grad)
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
         if A is not None:
-            comm = kwargs.get('comm')
             A_bwd = A.bwd
             # structural zeros: when the incoming gradient is known to be zero outside a set of rows (the CE
             # gradient lives on the training rows only), the caller may pass A^T with the other COLUMNS removed
             hint = kwargs.get('A_bwd_rows_hint')
             if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
                 A_bwd = hint[1]
-            if comm is None:
-                dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
-            else:
-                g = comm.matmul_target(self.num_units, tag='bwd')
-                g.copy_from(dS)
-                dZ = comm.graph_spmm(A_bwd, g, None, 0, self.num_units, tag='bwd')
+            dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
         else:
             dZ = dS
+        return self._backward_post(x, dZ, into, need_input_grad, kwargs)
+
+    def _backward_post(self, x, dZ, into, need_input_grad, kwargs):
+        K = backend.active()
         if isinstance(x, K.DMat):
             K.gemm(x, dZ, out=self.W.grad, transA=True)                    # dW = H^T . dZ
             if not need_input_grad:
@@ -500,7 +561,8 @@ def get_output(layer_or_layers, inputs=None, tape=None, **kwargs):
         if len(ins) != 1:
             raise ValueError("a bare input value needs a network with exactly one InputLayer")
         values[ins[0]] = inputs
-    for layer in all_layers:
+    started = set()
+    for pos, layer in enumerate(all_layers):
         if layer in values:
             continue
         if isinstance(layer, InputLayer):
@@ -512,6 +574,16 @@ def get_output(layer_or_layers, inputs=None, tape=None, **kwargs):
             x = [values[l] for l in layer.input_layers]
         else:
             x = values[layer.input_layer]
+        # partitioned graph: a convolution that comes NEXT in the order and whose input is already there starts
+        # its H.W product and the exchange of the result now, so that this layer's work (the highway gate's
+        # GEMM: both read the same H) overlaps the collective
+        if pos + 1 < len(all_layers):
+            nxt = all_layers[pos + 1]
+            if (nxt not in started and nxt not in values and hasattr(nxt, 'forward_begin') and nxt.can_split(kwargs)
+                    and nxt is not layer and getattr(nxt, 'input_layer', None) in values
+                    and getattr(nxt, 'input_layer', None) is not layer):
+                nxt.forward_begin(values[nxt.input_layer], tape, **kwargs)
+                started.add(nxt)
         values[layer] = layer.forward(x, tape, **kwargs)
     if tape is not None:
         tape['__values__'] = values
@@ -528,9 +600,7 @@ def backward(layer, grad, tape, **kwargs):
     grads = {layer: grad}
     # which layers lie on a path from a parameterised/needed layer: all of them need grads except
     # pure inputs
-    for l in reversed(all_layers):
-        if isinstance(l, InputLayer) or l not in grads:
-            continue
+    def run(l):
         g = grads.pop(l)
         ins = l.input_layers if hasattr(l, 'input_layers') else [l.input_layer]
         into = [grads.get(i) if not isinstance(i, InputLayer) else None for i in ins]
@@ -539,6 +609,25 @@ def backward(layer, grad, tape, **kwargs):
         for i, o in zip(ins, outs):
             if o is not None and not isinstance(i, InputLayer):
                 grads[i] = o
+
+    rev = list(reversed(all_layers))
+    done = set()
+    for pos, l in enumerate(rev):
+        if isinstance(l, InputLayer) or l not in grads or l in done:
+            continue
+        # partitioned graph: start the exchange of this convolution's dS, run the NEXT layer of the sweep first if
+        # it is independent of this one (the highway gate: its gradient is complete and it is not an ancestor of
+        # this layer), then finish -- the gate's two GEMMs overlap the collective.  (Both add into the same dH:
+        # the order of the two additions differs from the single-GPU sweep by one fp32 rounding.)
+        if hasattr(l, 'backward_begin') and l.can_split(kwargs) and pos + 1 < len(rev):
+            nxt = rev[pos + 1]
+            if (not isinstance(nxt, InputLayer) and nxt in grads and nxt not in done
+                    and nxt not in get_all_layers(l)):
+                l.backward_begin(grads[l], tape, **kwargs)
+                run(nxt)
+                done.add(nxt)
+        run(l)
+        done.add(l)
     return grads
 
 

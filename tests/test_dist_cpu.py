@@ -77,7 +77,8 @@ def _worker(rank, world, port, q, exchange):
                 res.append(([float(v) for v in o[:4]], np.asarray(o[4]), clf.get_grads(),
                             L.get_all_param_values(clf.l_out)))
             pred, probs = clf.predict(X, A, z['te'])
-            out[name] = (res, pred, probs)
+            out[name] = (res, pred, probs, dict(L.DenseLayer.early_starts))
+            L.DenseLayer.early_starts.update(fwd=0, bwd=0)
         if rank == 0:
             q.put(out)
     finally:
@@ -99,8 +100,14 @@ def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for name, (res, pred, probs) in out.items():
+    for name, (res, pred, probs, early) in out.items():
         z, A, X, params, cfg = load_case(name)
+        if name == 'tiny_highway':
+            # the highway blocks' convolutions started their exchange ahead of the gate layer in both sweeps
+            # (2 train steps + 1 predict forward; >= 1 block)
+            assert early['fwd'] >= 3 and early['bwd'] >= 2, early
+        else:
+            assert early == {'fwd': 0, 'bwd': 0}, early       # plain GCN: nothing to overlap with
         for step, (sc, P, grads, pv) in enumerate(res):
             ref = z['step%d_scalars' % step]
             assert np.allclose(sc, ref, rtol=1e-5, atol=1e-6), (name, step, sc, ref)

@@ -32,12 +32,12 @@ class FakeDist:
     def get_world_size(self, group=None):
         return self.world
 
-    def all_to_all_single(self, out, inp, group=None):
+    def all_to_all_single(self, out, inp, group=None, async_op=False):
         out.copy_(inp)                                   # same bytes through HBM instead of xGMI
         self.bytes_a2a += inp.numel() * 4 * (self.world - 1) // self.world
         self.n_a2a += 1
 
-    def all_gather_into_tensor(self, out, inp, group=None):
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
         self.bytes_ag += out.numel() * 4 * (self.world - 1) // self.world
         self.n_ag += 1
 
