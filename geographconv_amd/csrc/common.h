@@ -77,7 +77,15 @@ __device__ __forceinline__ float apply_act(float x) {
 // launched on an idle device (tests/test_e2e_gpu.py::test_hip_graph_...); kernel -> kernel edges are safe.
 int zero_fill_async(void* ptr, size_t bytes, hipStream_t st);        // core.hip; bytes % 4 == 0
 
+// gemm.hip: C = act(sum_z W[z] + bias) [+ C], slabs added in index order
+int splitk_reduce_launch(int64_t M, int64_t N, int nsplit, const float* W, int64_t ldw, float* C, int64_t ldc,
+                         const float* bias, int act, int accumulate, hipStream_t st);
+
 // gemm_bf16.hip
+size_t gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
+                          hipStream_t st);
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K);
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,

@@ -412,6 +412,24 @@ __global__ __launch_bounds__(TPB) void splitk_reduce_kernel(int64_t M, int64_t N
     C[row * ldc + col] = acc;
 }
 
+}  // namespace
+
+int splitk_reduce_launch(int64_t M, int64_t N, int nsplit, const float* W, int64_t ldw, float* C, int64_t ldc,
+                         const float* bias, int act, int accumulate, hipStream_t st) {
+    const dim3 rgrid((unsigned)cdiv(M * N, TPB));
+#define GEOGCN_RED(ACT)                                                                                 \
+    hipLaunchKernelGGL((splitk_reduce_kernel<ACT>), rgrid, dim3(TPB), 0, st, M, N, nsplit, W, ldw, C, ldc, bias, \
+                       accumulate)
+    if (act == GEOGCN_ACT_TANH) GEOGCN_RED(GEOGCN_ACT_TANH);
+    else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_RED(GEOGCN_ACT_SIGMOID);
+    else GEOGCN_RED(GEOGCN_ACT_NONE);
+#undef GEOGCN_RED
+    GEOGCN_LAUNCH_CHECK("splitk_reduce_kernel");
+    return 0;
+}
+
+namespace {
+
 struct SplitPlan {
     int nsplit;
     int64_t kchunk;
@@ -478,22 +496,13 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
     a.bias = nullptr;
     a.accumulate = 0;
     GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1);
-    const dim3 rgrid((unsigned)cdiv(M * N, TPB));
-#define GEOGCN_RED(ACT)                                                                                 \
-    hipLaunchKernelGGL((splitk_reduce_kernel<ACT>), rgrid, dim3(TPB), 0, st, M, N, sp.nsplit, W, ldw, C, \
-                       ldc, bias, accumulate)
-    if (act == GEOGCN_ACT_TANH) GEOGCN_RED(GEOGCN_ACT_TANH);
-    else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_RED(GEOGCN_ACT_SIGMOID);
-    else GEOGCN_RED(GEOGCN_ACT_NONE);
-#undef GEOGCN_RED
-    GEOGCN_LAUNCH_CHECK("splitk_reduce_kernel");
-    return 0;
+    return splitk_reduce_launch(M, N, sp.nsplit, W, ldw, C, ldc, bias, act, accumulate, st);
 #undef GEOGCN_GEMM_LAUNCH
 }
 
 // ---- tile selection ------------------------------------------------------------------------------
 // 128 or 160 per dimension, whichever wastes fewer MFMA columns on padding (300 -> 2x160, 256 -> 2x128,
-// 600 -> 4x160).  The long dimension of NN / NTH always uses BM = 128 (thousands of tiles).
+// 600 -> 4x160).  The long dimension of NN / NT always uses BM = 128 (thousands of tiles).
 inline int pick_tile(int64_t n) {
     const int64_t w128 = cdiv(n, 128) * 128, w160 = cdiv(n, 160) * 160;
     return (w160 < w128) ? 160 : 128;
@@ -562,6 +571,10 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
     (void)transB;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (!transA) return precision == GEOGCN_GEMM_F32 ? 0 : gemm_bf16_workspace_bytes(precision, N, K);
+    if (precision == GEOGCN_GEMM_BF16) {
+        const size_t h = gemm_bf16_tn_workspace_bytes(M, N, K);      // 0: shape left to the fp32 kernel
+        if (h) return h;
+    }
     const int bm = pick_tile(M), bn = pick_tile(N), wbn = wide_bn(N);
     if (wbn == 320) return bm == 160 ? splitk_ws_bytes<160, 320, 2, 4>(M, N, K) : splitk_ws_bytes<128, 320, 2, 4>(M, N, K);
     if (wbn == 256) return bm == 160 ? splitk_ws_bytes<160, 256, 2, 4>(M, N, K) : splitk_ws_bytes<128, 256, 2, 4>(M, N, K);
@@ -600,6 +613,10 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
                                   ws_bytes, st);
     float* C = (float*)Cv;
+    if (transA && precision == GEOGCN_GEMM_BF16 && K > 0) {
+        const int rc = gemm_bf16_tn_dispatch(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+        if (rc != 1) return rc;          // 1 = shape not handled by the bf16 kernel: exact fp32 below
+    }
     const int wbn = transA ? wide_bn(N) : 0;
     const int bn = wbn ? wbn : pick_tile(N);
     if (transA)

@@ -329,6 +329,160 @@ int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
     return 0;
 }
 
+
+// ---- dW = A^T . B with bf16 products (bf16 configuration only) -------------------------------------------
+// Both operands are k-STRIDED fp32 in memory ([K][M] and [K][N], K = the node dimension): a thread loads an
+// 8 (k) x 4 (columns) patch as eight float4s, rounds it to bf16 and writes four 16-byte k-contiguous pieces,
+// i.e. the transpose happens in registers and the LDS images are the same [row][32 k] images the MFMA
+// fragments of the forward kernel read.  One 8-wave block per CU, tile BM x BN with BN spanning 256 / 320
+// columns, split-K slabs in fp32 combined in fixed order by splitk_reduce (deterministic).
+constexpr uint32_t kOob = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tn_rsrc(const float* base, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+__device__ __forceinline__ float4 tn_load4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+struct TnArgs {
+    int64_t M, N, K;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* W; int64_t ldw;              // slabs [nsplit][M][ldw]
+    int64_t kchunk;
+    int n_mt, n_nt, nsplit;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
+    constexpr int NTH = 512, kASplit = 192;                  // threads [0,192): A patches, [192,512): B patches
+    constexpr int MR = BM / 32, NR = BN / 64;                // 2 x 4 waves, wave tile (BM/2) x (BN/4)
+    constexpr int kAItems = 4 * (BM / 4), kBItems = 4 * (BN / 4);
+    static_assert(kAItems <= kASplit && kBItems <= NTH - kASplit, "patch lists must fit the thread ranges");
+    constexpr int kImgA = BM * ROWB, kStage = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3, li = lane & 15, lg = lane >> 4;
+
+    const int b = blockIdx.x;
+    const int nt = __builtin_amdgcn_readfirstlane(b % a.n_nt);
+    const int mt = __builtin_amdgcn_readfirstlane((b / a.n_nt) % a.n_mt);
+    const int z = __builtin_amdgcn_readfirstlane(b / (a.n_nt * a.n_mt));
+    const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+    const int64_t kbeg = (int64_t)z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const int nk = (int)((kend - kbeg + BKH - 1) / BKH);
+
+    // my patch: operand, k8 group (8 reduction rows), c4 group (4 columns)
+    const bool isA = tid < kASplit;
+    const int it = isA ? tid : tid - kASplit;
+    const int cols4 = isA ? BM / 4 : BN / 4;
+    const bool active = it < 4 * cols4;
+    const int k8 = it / cols4, c4 = it % cols4;
+    const float* P = isA ? a.A : a.B;
+    const int64_t ld = isA ? a.lda : a.ldb;
+    const int64_t c0 = isA ? m0 : n0;
+    const int64_t ctot = isA ? a.M : a.N;
+    const bool col_ok = active && (c4 * 4 < ((ctot + 3) & ~(int64_t)3) - c0);
+    // (the two operands use different descriptors: built per lane group, uniform within a wave except wave 2/3
+    //  boundary at thread 192 = wave 3 start, so every wave is uniform)
+    float4 r[8];
+    auto gload = [&](int kt) {
+        const int64_t k0 = kbeg + (int64_t)kt * BKH;
+        const __amdgpu_buffer_rsrc_t rs = tn_rsrc(P + k0 * ld + c0, ((kend - k0) * ld - c0) * 4);
+        const uint32_t ld4 = (uint32_t)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t off = (uint32_t)(k8 * 8 + i) * ld4 + (uint32_t)c4 * 16u;
+            r[i] = tn_load4(rs, col_ok ? off : kOob);
+        }
+    };
+    auto sstore = [&](int buf) {
+        if (!active) return;
+        unsigned char* img = smem_raw + buf * kStage + (isA ? 0 : kImgA);
+        const float* f = reinterpret_cast<const float*>(r);          // r[i] = row i of the patch: f[4*i + e]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint4 w;
+            w.x = bf16_rne(f[0 + e]) | (bf16_rne(f[4 + e]) << 16);
+            w.y = bf16_rne(f[8 + e]) | (bf16_rne(f[12 + e]) << 16);
+            w.z = bf16_rne(f[16 + e]) | (bf16_rne(f[20 + e]) << 16);
+            w.w = bf16_rne(f[24 + e]) | (bf16_rne(f[28 + e]) << 16);
+            *reinterpret_cast<uint4*>(img + (c4 * 4 + e) * ROWB + k8 * 16) = w;
+        }
+    };
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const unsigned char* As = smem_raw + cur * kStage;
+        const unsigned char* Bs = As + kImgA;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Bs + (wn * (BN / 4) + j * 16 + li) * ROWB + lg * 16);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(As + (wm * (BM / 2) + i * 16 + li) * ROWB + lg * 16);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af, acc[i][j], 0, 0, 0);   // transposed: see above
+            }
+        }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // slab z: lane (li, lg) holds C[row = li][col = 4*lg + r] of each 16x16 sub-tile
+    float* Wz = a.W + (int64_t)z * a.M * a.ldw;
+    const int64_t n_store = (a.N + 3) & ~(int64_t)3;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int64_t row = m0 + wm * (BM / 2) + i * 16 + li;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int64_t col0 = n0 + wn * (BN / 4) + j * 16 + lg * 4;
+            float x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = (col0 + q < a.N) ? acc[i][j][q] : 0.f;
+            if (row < a.M && col0 < n_store)
+                *reinterpret_cast<float4*>(Wz + row * a.ldw + col0) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+    }
+}
+
+struct TnPlan {
+    int bm, bn, n_mt, n_nt, nsplit;
+    int64_t kchunk;
+};
+inline bool tn_plan(int64_t M, int64_t N, int64_t K, TnPlan& p) {
+    if (N <= 160) return false;                                   // narrow outputs stay on the fp32 kernel
+    p.bm = (cdiv(M, 160) * 160 < cdiv(M, 128) * 128) ? 160 : 128;
+    const int64_t w320 = cdiv(N, 320) * 320, w256 = cdiv(N, 256) * 256;
+    p.bn = (w256 <= w320) ? 256 : 320;
+    p.n_mt = (int)cdiv(M, p.bm);
+    p.n_nt = (int)cdiv(N, p.bn);
+    const int64_t tiles = (int64_t)p.n_mt * p.n_nt;
+    int64_t ns = std::max<int64_t>(1, kNumCU / tiles);
+    ns = std::min(ns, std::max<int64_t>(1, K / (BKH * 4)));
+    p.kchunk = cdiv(cdiv(K, ns), BKH) * BKH;
+    p.nsplit = (int)cdiv(K, p.kchunk);
+    return true;
+}
+
 }  // namespace
 
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
@@ -362,6 +516,46 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
     }
     if (bn == 160) return launch_bf16<128, 160, 1, 256>(a, act, st);
     return launch_bf16<128, 128, 1, 256>(a, act, st);
+}
+
+
+size_t gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    TnPlan p;
+    if (!tn_plan(M, N, K, p)) return 0;
+    return (size_t)p.nsplit * (size_t)M * (size_t)((N + 3) & ~(int64_t)3) * sizeof(float);
+}
+
+// dW = A^T . B (A: K x M, B: K x N, fp32 in memory) with bf16 products; returns 1 if this shape is not handled
+// (the caller then runs the fp32 kernel), 0 on success, an error code otherwise
+int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
+    TnPlan p;
+    if (!tn_plan(M, N, K, p)) return 1;
+    const size_t need = gemm_bf16_tn_workspace_bytes(M, N, K);
+    GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "gemm_f32(bf16, transA): workspace too small (%zu < %zu)",
+                   ws_bytes, need);
+    const int64_t ldw = (N + 3) & ~(int64_t)3;
+    TnArgs a{M, N, K, A, lda, B, ldb, (float*)ws, ldw, p.kchunk, p.n_mt, p.n_nt, p.nsplit};
+    const dim3 grid((unsigned)((int64_t)p.n_mt * p.n_nt * p.nsplit));
+#define GEOGCN_TN(BM_, BN_)                                                                                     \
+    do {                                                                                                        \
+        auto kern = gemm_bf16_tn_kernel<BM_, BN_>;                                                              \
+        constexpr int lds = 2 * (BM_ + BN_) * ROWB;                                                             \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                  \
+        GEOGCN_LAUNCH_CHECK("gemm_bf16_tn_kernel");                                                             \
+    } while (0)
+    if (p.bm == 160 && p.bn == 320) GEOGCN_TN(160, 320);
+    else if (p.bm == 160) GEOGCN_TN(160, 256);
+    else if (p.bn == 320) GEOGCN_TN(128, 320);
+    else GEOGCN_TN(128, 256);
+#undef GEOGCN_TN
+    return splitk_reduce_launch(M, N, p.nsplit, (const float*)ws, ldw, C, ldc, bias, act, accumulate, st);
 }
 
 }  // namespace geogcn

@@ -391,10 +391,10 @@ class DenseLayer(Layer):
     def _backward_post(self, x, dZ, into, need_input_grad, kwargs):
         K = backend.active()
         if isinstance(x, K.DMat):
-            K.gemm(x, dZ, out=self.W.grad, transA=True)                    # dW = H^T . dZ
+            prec = kwargs.get('gemm_precision')
+            K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ
             if not need_input_grad:
                 return [None]
-            prec = kwargs.get('gemm_precision')
             if into[0] is not None:
                 return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True, precision=prec)]
             return [K.gemm(dZ, self.W.data, transB=True, precision=prec)]  # dH = dZ . W^T

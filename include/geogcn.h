@@ -118,7 +118,9 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  *                      per product: fp32-class accuracy (dropped terms O(2^-24 |a||b|)), 2.7x fewer MFMA
  *                      cycles -- the contraction becomes HBM-bound;
  *   GEOGCN_GEMM_BF16   one bf16 term per operand (BASELINE config 5: "bf16 H.W on MFMA, fp32 accumulate").
- * The bf16 modes apply to transA = 0; transA = 1 (dW, reduction over the node dimension) always runs F32. */
+ * BF16X3 applies to transA = 0 only (transA = 1 then runs F32).  BF16 applies to both: transA = 1 (dW, the
+ * reduction over the node dimension) rounds both operands to bf16 on their way into LDS for outputs wider than
+ * 160 columns (narrower ones run F32); split-K slabs and their ordered combination stay fp32.            */
 #define GEOGCN_GEMM_F32    0
 #define GEOGCN_GEMM_BF16X3 1
 #define GEOGCN_GEMM_BF16   2

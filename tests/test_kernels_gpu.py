@@ -263,6 +263,35 @@ def test_gemm_tn_splitk_matches_oracle_and_is_deterministic(dev, R, M, N):
     assert np.all(np.abs(g1 - ref) <= tol), np.abs(g1 - ref).max()
 
 
+@pytest.mark.parametrize("R,M,N", [(5000, 300, 300), (4097, 300, 256), (3333, 600, 600), (1500, 129, 300), (700, 300, 129)])
+def test_gemm_tn_bf16_products(dev, R, M, N):
+    """bf16 configuration: dW = A^T . B with both operands rounded to bf16 (RNE) on their way into LDS, fp32
+    accumulation in split-K slabs combined in fixed order: equals the exact product of the ROUNDED operands to
+    fp32 accumulation error, and is run-to-run identical.  Outputs of <= 160 columns stay on the fp32 kernel."""
+    from geographconv_amd import ops
+    A = _rand((R, M), 1)
+    B = _rand((R, N), 2)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+    got = ops.gemm(dA, dB, transA=True, precision='bf16')
+    Ar = torch.from_numpy(A).to(torch.bfloat16).float().numpy().astype(np.float64)
+    Br = torch.from_numpy(B).to(torch.bfloat16).float().numpy().astype(np.float64)
+    mag = np.abs(Ar).T @ np.abs(Br)
+    if N > 160:
+        assert np.all(np.abs(got.numpy() - Ar.T @ Br) <= 2e-6 * mag + 1e-6)
+        assert np.abs(got.numpy() - A.astype(np.float64).T @ B.astype(np.float64)).max() > 1e-4     # really bf16
+    else:
+        ref = A.astype(np.float64).T @ B.astype(np.float64)
+        assert np.all(np.abs(got.numpy() - ref) <= 2e-6 * (np.abs(A).T @ np.abs(B)) + 1e-6)         # exact fp32 path
+    assert torch.all(got.t[:, N:] == 0)
+    again = ops.gemm(dA, dB, transA=True, precision='bf16')
+    assert torch.equal(got.t, again.t)
+    # accumulate + bias through the ordered combine
+    C0 = _rand((M, N), 3)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm(dA, dB, out=dC, transA=True, accumulate=True, precision='bf16')
+    assert np.allclose(dC.numpy(), got.numpy() + C0, rtol=0, atol=1e-5 + 1e-6 * np.abs(got.numpy()).max())
+
+
 def test_gemm_asymmetric_detects_transposes(dev):
     """A = I check with an asymmetric B (guide rule: symmetric inputs hide row/col swaps)."""
     from geographconv_amd import ops
