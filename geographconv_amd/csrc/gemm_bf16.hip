@@ -95,6 +95,20 @@ struct BCfg {
     static constexpr int kBIters = (kBVec + NT - 1) / NT;
 };
 
+constexpr uint32_t kOob = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tn_rsrc(const float* base, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+__device__ __forceinline__ float4 tn_load4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+
 template <int BM, int BN, int NS, int ACT, int NT>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
     using Cfg = BCfg<BM, BN, NS, NT>;
@@ -114,46 +128,64 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
 #pragma unroll
         for (int j = 0; j < Cfg::NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // XCD-aware persistent tile walk (as gemm.hip): the blocks of one XCD share the A panel through L2
+    // XCD-aware persistent tile walk (as gemm.hip): the blocks of one XCD share the A panel through L2.
+    // Tile j of this block is (mt, nt) = decode(j); valid for j < n_my (mt grows with j).
     const int x = p % kNumXCD, q = p / kNumXCD, Q = G / kNumXCD;
-    auto decode = [&](int j, int64_t& m0, int64_t& n0) -> bool {
+    auto decode = [&](int j, int& mt, int& nt) {
         const int64_t u = (int64_t)q + (int64_t)j * Q;
-        const int nt = (int)(u % a.n_nt);
-        const int mt = (int)(u / a.n_nt) * kNumXCD + x;
-        m0 = (int64_t)mt * BM;
-        n0 = (int64_t)nt * BN;
-        return mt < a.n_mt;
+        nt = __builtin_amdgcn_readfirstlane((int)(u % a.n_nt));
+        mt = __builtin_amdgcn_readfirstlane((int)(u / a.n_nt) * kNumXCD + x);
     };
+    int n_my = 0;
+    {
+        int mt, nt;
+        for (;; ++n_my) {
+            decode(n_my, mt, nt);
+            if (mt >= a.n_mt) break;
+        }
+    }
+    if (n_my == 0) return;
 
     // A (HBM stream) is prefetched TWO stages ahead in two register sets, B (L2-resident weight planes) one
-    // stage ahead: with two blocks per CU that keeps four 16 KB A tiles in flight per CU -- the single-stage
-    // version of this kernel was latency-bound (5 us per stage).
+    // stage ahead.  Everything arrives through raw buffer loads with tile-rebased descriptors (rows past the end
+    // and stages past this block's list read as zeros): the loop body has no data-dependent branches, so the
+    // wait counts are exact (the branchy version drained the memory pipeline at every join, see gemm.hip).
     float4 ra0[Cfg::kAIters], ra1[Cfg::kAIters];
     uint4 rb[Cfg::kBIters];
     const int a_f4 = tid & 7, a_rr = tid >> 3;
-    auto gloadA = [&](float4 (&ra)[Cfg::kAIters], int64_t m0, int kt) {
-        const int64_t k0 = (int64_t)kt * BKH + a_f4 * 4;
-        const int64_t klim = (a.K + 3) & ~(int64_t)3;          // pad columns of A are zero (geogcn.h)
+    auto gloadA = [&](float4 (&ra)[Cfg::kAIters], int j, int kt) {
+        int mt, nt;
+        decode(j, mt, nt);
+        const bool valid = j < n_my;
+        const int64_t m0 = (int64_t)mt * BM;
+        const int64_t k0 = (int64_t)kt * BKH;
+        const int64_t rows = valid ? a.M - m0 : 0;
+        const __amdgpu_buffer_rsrc_t rs = tn_rsrc(a.A + m0 * a.lda + k0, (rows * a.lda - k0) * 4);
+        const bool k_ok = k0 + a_f4 * 4 < ((a.K + 3) & ~(int64_t)3);      // pad columns of A are zero (geogcn.h)
+        const uint32_t ld4 = (uint32_t)a.lda * 4u;
 #pragma unroll
         for (int i = 0; i < Cfg::kAIters; ++i) {
-            const int64_t row = m0 + a_rr + kRowsPerPass * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < a.M && k0 < klim) v = *reinterpret_cast<const float4*>(a.A + row * a.lda + k0);
-            ra[i] = v;
+            const uint32_t off = (uint32_t)(a_rr + kRowsPerPass * i) * ld4 + (uint32_t)a_f4 * 16u;
+            ra[i] = tn_load4(rs, k_ok ? off : kOob);
         }
     };
-    auto gloadB = [&](int64_t n0, int kt) {
+    auto gloadB = [&](int j, int kt) {
+        int mt, nt;
+        decode(j, mt, nt);
+        const bool valid = j < n_my;
+        const int64_t n0 = (int64_t)nt * BN;
+        // planes [NS][N][Kp] bf16: one descriptor over all of them (<= a few MB)
+        const __amdgpu_buffer_rsrc_t rs = tn_rsrc(reinterpret_cast<const float*>(a.Bp),
+                                                  valid ? (int64_t)NS * a.N * a.Kp * 2 : 0);
 #pragma unroll
         for (int i = 0; i < Cfg::kBIters; ++i) {
             const int e = tid + NT * i;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (e < Cfg::kBVec) {
-                const int pl = e / (BN * 4), r = (e / 4) % BN, c = e & 3;
-                const int64_t n = n0 + r;
-                if (n < a.N)
-                    v = *reinterpret_cast<const uint4*>(a.Bp + ((int64_t)pl * a.N + n) * a.Kp + (int64_t)kt * BKH + c * 8);
-            }
-            rb[i] = v;
+            const int pl = e / (BN * 4), r = (e / 4) % BN, c = e & 3;
+            const int64_t n = n0 + r;
+            const bool ok = e < Cfg::kBVec && n < a.N;
+            const uint32_t off = (uint32_t)((((int64_t)pl * a.N + n) * a.Kp + (int64_t)kt * BKH + c * 8) * 2);
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? off : kOob), 0, 0));
+            rb[i] = __builtin_bit_cast(uint4, v);
         }
     };
     auto sstore = [&](int buf, const float4 (&ra)[Cfg::kAIters]) {
@@ -184,29 +216,28 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
         }
     };
 
-    int cj = 0, ckt = 0, lj = 0, lkt = 0;
-    int64_t cm0, cn0, lm0, ln0, pm0 = 0, pn0 = 0;
-    int pkt = 0;
-    if (!decode(0, cm0, cn0)) return;
-    lm0 = cm0; ln0 = cn0;
-    bool lvalid = true, pvalid = false;
-    auto advance_load = [&]() {
-        if (++lkt == nk) { lvalid = decode(++lj, lm0, ln0); lkt = 0; }
+    // cursors: c = stage being multiplied, l = next A stage to load (two ahead), pj/pkt = stage c+1 (its B)
+    int cj = 0, ckt = 0, lj = 0, lkt = 0, pj = 0, pkt = 0;
+    auto adv = [&](int& j, int& kt) {
+        if (++kt == nk) { kt = 0; ++j; }
     };
-    gloadA(ra0, lm0, 0);
-    gloadB(ln0, 0);
+    gloadA(ra0, 0, 0);
+    gloadB(0, 0);
     sstore(0, ra0);
-    advance_load();
-    pvalid = lvalid; pm0 = lm0; pn0 = ln0; pkt = lkt;      // stage 1: its A goes to set 1 now, its B next iteration
-    if (pvalid) { gloadA(ra1, pm0, pkt); advance_load(); }
+    adv(lj, lkt);
+    pj = lj; pkt = lkt;                       // stage 1
+    gloadA(ra1, lj, lkt);
+    adv(lj, lkt);                             // stage 2
     __syncthreads();
     int cur = 0;
-    bool running = true;
+    int cm_t, cn_t;
+    decode(0, cm_t, cn_t);
+    int64_t cm0 = (int64_t)cm_t * BM, cn0 = (int64_t)cn_t * BN;
     // (xa) = free A set, receives stage s+2;  (ya) = A set holding stage s+1
     auto step = [&](float4 (&xa)[Cfg::kAIters], const float4 (&ya)[Cfg::kAIters]) {
-        const bool have_load = lvalid;
-        if (have_load) gloadA(xa, lm0, lkt);
-        if (pvalid) gloadB(pn0, pkt);
+        gloadA(xa, lj, lkt);
+        adv(lj, lkt);
+        gloadB(pj, pkt);
         const unsigned char* As = smem_raw + (Cfg::kDouble ? cur : 0) * Cfg::kStageBytes;
         const unsigned char* Bs = As + Cfg::kABytes;
         // ---- MFMAs on the resident stage ----
@@ -287,20 +318,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
             }
         }
         if constexpr (!Cfg::kDouble) __syncthreads();     // single image: everybody done reading first
-        if (pvalid) sstore(cur ^ 1, ya);
+        sstore(cur ^ 1, ya);
         __syncthreads();
         cur ^= 1;
+        adv(pj, pkt);
         if (++ckt == nk) {
             ckt = 0;
-            if (!decode(++cj, cm0, cn0)) running = false;
+            ++cj;
+            decode(cj, cm_t, cn_t);
+            cm0 = (int64_t)cm_t * BM;
+            cn0 = (int64_t)cn_t * BN;
         }
-        pvalid = have_load; pm0 = lm0; pn0 = ln0; pkt = lkt;
-        if (have_load) advance_load();
     };
-    while (running) {
+    while (true) {
         step(ra0, ra1);
-        if (!running) break;
+        if (cj >= n_my) break;
         step(ra1, ra0);
+        if (cj >= n_my) break;
     }
 }
 
@@ -336,19 +370,6 @@ int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
 // i.e. the transpose happens in registers and the LDS images are the same [row][32 k] images the MFMA
 // fragments of the forward kernel read.  One 8-wave block per CU, tile BM x BN with BN spanning 256 / 320
 // columns, split-K slabs in fp32 combined in fixed order by splitk_reduce (deterministic).
-constexpr uint32_t kOob = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tn_rsrc(const float* base, int64_t bytes) {
-    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
-    const uint64_t b = reinterpret_cast<uint64_t>(base);
-    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
-}
-__device__ __forceinline__ float4 tn_load4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
 struct TnArgs {
     int64_t M, N, K;
     const float* A; int64_t lda;
