@@ -31,6 +31,8 @@ SIGNATURES = {
     'geogcn_spmm_csr_bf16b': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                       c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_cast_bf16_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'geogcn_spmm_csr_highway_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                                            c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_timer_create': (c_i32, [c_i32, C.POINTER(c_ptr)]),
     'geogcn_timer_destroy': (None, [c_ptr]),
     'geogcn_timer_attach_spmm': (c_i32, [c_ptr, c_i32, c_i64]),

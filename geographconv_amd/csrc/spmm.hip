@@ -183,17 +183,31 @@ __device__ __forceinline__ float4 epilogue4(float4 r, int col0, int F, const flo
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// Highway epilogue (gcnmodel.py:266 fused into the producing SpMM): with hw.T != nullptr the kernel stores
+// Hc = act(A.B + bias) to C as usual AND Hout = T*Hc + (1-T)*H, reading the T and H rows it needs (coalesced,
+// row-contiguous) instead of a separate elementwise pass re-reading Hc.
+struct HwArgs {
+    const float* T;
+    const float* H;
+    float* Hout;
+    int64_t ld;          // common pitch of T, H, Hout
+};
+__device__ __forceinline__ float4 highway_mix(const float4 t, const float4 hc, const float4 h) {
+    return make_float4(t.x * hc.x + (1.0f - t.x) * h.x, t.y * hc.y + (1.0f - t.y) * h.y,
+                       t.z * hc.z + (1.0f - t.z) * h.z, t.w * hc.w + (1.0f - t.w) * h.w);
+}
+
 // ONE launch covers every stored edge: the leading `n_chunk_blocks` blocks take the 128-nonzero chunks
 // of the long rows (raw partial sums into the workspace P), the remaining blocks take one CSR row per
 // 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
 // that it overlaps the bulk instead of running as an under-occupied launch of its own.
-template <int K4, int ACT, int NTT, int G, int BF>
+template <int K4, int ACT, int NTT, int G, int BF, int HW = 0>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
-    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split) {
+    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split, const HwArgs hw) {
     const int lane16 = threadIdx.x % G;
     const int nF4 = (F + 3) >> 2;
     float4 acc[K4];
@@ -226,15 +240,24 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
 #pragma unroll
     for (int k = 0; k < K4; ++k) {
         const int q = f4_index<G, BF>(lane16, k);
-        if (q < nF4) out[q] = epilogue4<ACT>(acc[k], q * 4, F, bias);
+        if (q < nF4) {
+            const float4 hc = epilogue4<ACT>(acc[k], q * 4, F, bias);
+            out[q] = hc;
+            if constexpr (HW) {
+                const float4 t = reinterpret_cast<const float4*>(hw.T + (int64_t)row * hw.ld)[q];
+                const float4 h = reinterpret_cast<const float4*>(hw.H + (int64_t)row * hw.ld)[q];
+                reinterpret_cast<float4*>(hw.Hout + (int64_t)row * hw.ld)[q] = highway_mix(t, hc, h);
+            }
+        }
     }
 }
 
 // long rows: one block per row, thread per output column, partials added in chunk order.
-template <int ACT>
+template <int ACT, int HW = 0>
 __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(
     const int* __restrict__ long_rows, const int* __restrict__ long_first, const float* __restrict__ P,
-    int64_t ldp, float* __restrict__ C, int64_t ldc, int F, int Fpad, const float* __restrict__ bias) {
+    int64_t ldp, float* __restrict__ C, int64_t ldc, int F, int Fpad, const float* __restrict__ bias,
+    const HwArgs hw) {
     const int lr = blockIdx.x;
     const int row = long_rows[lr];
     const int c0 = long_first[lr];
@@ -256,6 +279,10 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(
             o = apply_act<ACT>(acc);
         }
         C[(int64_t)row * ldc + col] = o;
+        if constexpr (HW) {
+            const float t = hw.T[(int64_t)row * hw.ld + col], h = hw.H[(int64_t)row * hw.ld + col];
+            hw.Hout[(int64_t)row * hw.ld + col] = t * o + (1.0f - t) * h;
+        }
     }
 }
 
@@ -280,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
 template <int K4, int G, int BF>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
               const float* val, const void* B, int64_t ldb, float* C, int64_t ldc, int F,
-              const float* bias, int act, float* ws, hipStream_t st, int64_t nnz);
+              const float* bias, int act, float* ws, hipStream_t st, int64_t nnz, const HwArgs& hw);
 
 }  // namespace
 }  // namespace geogcn
@@ -314,7 +341,7 @@ int64_t g_spmm_timer_nnz = 0;
 template <int K4, int G, int BF>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
               const float* val, const void* B, int64_t ldb, float* C, int64_t ldc, int F,
-              const float* bias, int act, float* ws, hipStream_t st, int64_t nnz) {
+              const float* bias, int act, float* ws, hipStream_t st, int64_t nnz, const HwArgs& hw) {
     constexpr int kGroupsPerBlock = kBlock / G;
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
@@ -324,7 +351,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     geogcn_timer* tm = g_spmm_timer;
     const bool timed = tm && (g_spmm_timer_F == 0 || g_spmm_timer_F == F) &&
                        (g_spmm_timer_nnz == 0 || g_spmm_timer_nnz == nnz) && tm->used < (int)tm->begin.size() &&
-                       n_rows > 0;
+                       n_rows > 0 && !hw.T;        // (the fused highway launches move other bytes: not the kernel bench.py prices)
     if (timed) GEOGCN_HIP(hipEventRecord(tm->begin[tm->used], st));
     static const int nt_tail = [] {
         const char* e = getenv("GEOGCN_SPMM_NT");      // experiment switch: 0 = plain loads for the tail too
@@ -337,13 +364,15 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         GEOGCN_ROWS_(ACT, 1);                                                                    \
     else                                                                                         \
         GEOGCN_ROWS_(ACT, 0)
-#define GEOGCN_ROWS_(ACT, NTT)                                                                   \
-    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
+#define GEOGCN_ROWS_(ACT, NTT) GEOGCN_ROWS__(ACT, NTT, 0)
+#define GEOGCN_ROWS__(ACT, NTT, HW_)                                                             \
+    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF, HW_>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
-                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr)
+                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw)
     if (n_rows > 0) {
-        if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }
+        if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 0, 1); }        // highway epilogue: tanh branch only (checked by the caller)
+        else if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }
         else if (act == GEOGCN_ACT_SIGMOID) { GEOGCN_ROWS(GEOGCN_ACT_SIGMOID); }
         else { GEOGCN_ROWS(GEOGCN_ACT_NONE); }
         GEOGCN_LAUNCH_CHECK("spmm_rows_kernel");
@@ -354,16 +383,20 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     }
 #undef GEOGCN_ROWS
 #undef GEOGCN_ROWS_
+#undef GEOGCN_ROWS__
     if (n_chunks > 0) {
         const int Fpad = (int)std::min<int64_t>(ldc, ldp);
         const dim3 rgrid((unsigned)plan->n_long);
-#define GEOGCN_RED(ACT)                                                                          \
-    hipLaunchKernelGGL((spmm_long_reduce_kernel<ACT>), rgrid, dim3(kBlock), 0, st,               \
-                       plan->d_long_rows, plan->d_long_first, ws, ldp, C, ldc, F, Fpad, bias)
-        if (act == GEOGCN_ACT_TANH) GEOGCN_RED(GEOGCN_ACT_TANH);
+#define GEOGCN_RED(ACT) GEOGCN_RED_(ACT, 0)
+#define GEOGCN_RED_(ACT, HW_)                                                                    \
+    hipLaunchKernelGGL((spmm_long_reduce_kernel<ACT, HW_>), rgrid, dim3(kBlock), 0, st,          \
+                       plan->d_long_rows, plan->d_long_first, ws, ldp, C, ldc, F, Fpad, bias, hw)
+        if (hw.T) GEOGCN_RED_(GEOGCN_ACT_TANH, 1);
+        else if (act == GEOGCN_ACT_TANH) GEOGCN_RED(GEOGCN_ACT_TANH);
         else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_RED(GEOGCN_ACT_SIGMOID);
         else GEOGCN_RED(GEOGCN_ACT_NONE);
 #undef GEOGCN_RED
+#undef GEOGCN_RED_
         GEOGCN_LAUNCH_CHECK("spmm_long_reduce_kernel");
     }
     return 0;
@@ -379,7 +412,7 @@ template <int BF>
 int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
                   const int32_t* rowptr, const int32_t* colidx, const float* val, const void* B, int64_t ldb,
                   float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* ws, size_t ws_bytes,
-                  void* stream) {
+                  void* stream, const HwArgs hw = HwArgs{nullptr, nullptr, nullptr, 0}) {
     GEOGCN_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && F >= 0, GEOGCN_E_SIZE,
                    "%s: negative size", fn);
     if (n_rows == 0 || F == 0) return 0;
@@ -409,7 +442,7 @@ int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, 
         // 8 lanes per row while that keeps <= 5 passes (F <= 320: every lane of a wave fetches 16 useful bytes,
         // 8 rows in flight per wave); 16 lanes per row beyond
 #define GEOGCN_BF(K16, G_)                                                                                       \
-    return launch_k4<2 * K16, G_, 1>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz)
+    return launch_k4<2 * K16, G_, 1>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz, hw)
         const int k8 = (F8 + 7) / 8, k16 = (F8 + 15) / 16;
         if (k8 <= 5) {
             switch (k8) {
@@ -433,6 +466,7 @@ int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, 
     const bool vec_ok = (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
                         ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 16;      // F <= 1024
     if (!vec_ok) {
+        GEOGCN_REQUIRE(!hw.T, GEOGCN_E_ALIGN, "%s: the highway epilogue needs float4-addressable operands", fn);
         const dim3 grid((unsigned)cdiv(n_rows, kBlock / kWave));
 #define GEOGCN_SC(ACT)                                                                              \
     hipLaunchKernelGGL((spmm_scalar_kernel<ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr, colidx, \
@@ -450,12 +484,12 @@ int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, 
     float* wsf = (float*)ws;
     // narrow operands (F <= 32, e.g. the per-rank feature panels of C = 256 over 8 GPUs): 8 lanes per row,
     // twice as many rows in flight per wave (measured 0.306 -> 0.267 ms at F = 16); otherwise 16 lanes per row
-    if (F4 <= 8) return launch_k4<1, 8, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
+    if (F4 <= 8) return launch_k4<1, 8, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz, hw);
     const int K4 = (F4 + kGroup - 1) / kGroup;
     switch (K4) {
 #define GEOGCN_CASE(K)                                                                             \
     case K:                                                                                        \
-        return launch_k4<K, kGroup, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz);
+        return launch_k4<K, kGroup, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz, hw);
         GEOGCN_CASE(1)
         GEOGCN_CASE(2)
         GEOGCN_CASE(3)
@@ -619,6 +653,24 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
                         const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream) {
     return spmm_csr_impl<0>("spmm_csr_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, C, ldc, F, bias,
                             act, ws, ws_bytes, stream);
+}
+
+// Hc = tanh(A.B + bias) and Hout = T*Hc + (1-T)*H in one launch; `b_bf16` selects the bf16 gathered operand
+int geogcn_spmm_csr_highway_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                                const int32_t* rowptr, const int32_t* colidx, const float* val, const void* B,
+                                int64_t ldb, int32_t b_bf16, int32_t F, const float* bias, const float* T,
+                                const float* H, int64_t ld, float* Hc, float* Hout, void* ws, size_t ws_bytes,
+                                void* stream) {
+    GEOGCN_REQUIRE(T && H && Hc && Hout, GEOGCN_E_NULL, "spmm_csr_highway_f32: null pointer");
+    GEOGCN_REQUIRE(ld % 4 == 0 && ld >= (int64_t)((F + 3) / 4) * 4 && aligned16(T) && aligned16(H) && aligned16(Hout),
+                   GEOGCN_E_ALIGN, "spmm_csr_highway_f32: T, H, Hc, Hout need 16-byte bases and a pitch %% 4 == 0 (ld=%lld)",
+                   (long long)ld);
+    const HwArgs hw{T, H, Hout, ld};
+    if (b_bf16)
+        return spmm_csr_impl<1>("spmm_csr_highway_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, Hc, ld, F,
+                                bias, GEOGCN_ACT_TANH, ws, ws_bytes, stream, hw);
+    return spmm_csr_impl<0>("spmm_csr_highway_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, Hc, ld, F,
+                            bias, GEOGCN_ACT_TANH, ws, ws_bytes, stream, hw);
 }
 
 int geogcn_spmm_csr_bf16b(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,

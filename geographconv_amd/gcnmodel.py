@@ -162,7 +162,11 @@ class MultiplicativeGatingLayer(L.MergeLayer):
     def forward(self, inputs, tape, **kwargs):
         K = backend.active()
         t, h1, h2 = inputs
-        y = K.highway_fwd(t, h1, h2)
+        fused = tape.get(self.input_layers[1], {}) if tape is not None else {}
+        if fused.get('highway_out') is not None and fused.get('y') is h1 and fused.get('x') is h2:
+            y = fused['highway_out']             # already mixed in the epilogue of the convolution's SpMM
+        else:
+            y = K.highway_fwd(t, h1, h2)
         if tape is not None:
             tape[self] = {'t': t, 'h1': h1, 'h2': h2}
         return y
@@ -200,6 +204,7 @@ def highway_dense(incoming, gconv=False, Wh=_init.GlorotUniform(), bh=_init.Cons
     else:
         l_h = DenseLayer(incoming, num_units=num_inputs, W=Wh, b=bh, nonlinearity=nonlinearity)
     l_t = DenseLayer(incoming, num_units=num_inputs, W=Wt, b=bt, nonlinearity=NL.sigmoid)
+    l_h.highway_gate = l_t           # lets the convolution fuse the gating mix into its SpMM epilogue
     return MultiplicativeGatingLayer(gate=l_t, input1=l_h, input2=incoming), l_t
 
 

@@ -281,7 +281,15 @@ class DenseLayer(Layer):
                     self._matmul(input, zf, prec)
                     if K.bf16_gather(prec):
                         zf = K.cast_bf16(zf)
-                y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
+                gate = getattr(self, 'highway_gate', None)
+                T = tape.get(gate, {}).get('y') if (gate is not None and tape is not None) else None
+                if (T is not None and self.nonlinearity is _nl.tanh and bias is not None and isinstance(input, K.DMat)
+                        and tape[gate]['x'] is input and T.ld == input.ld and hasattr(K, 'spmm_highway')):
+                    # highway block: the gating mix T*Hc + (1-T)*H rides in the SpMM's epilogue (the gate was
+                    # evaluated just before this layer); MultiplicativeGatingLayer picks the result up
+                    y, saved['highway_out'] = K.spmm_highway(A.fwd, zf, bias, T, input)
+                else:
+                    y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
                 h = self._pending.pop(('fwd', id(tape)), None) or self._exchange_begin_fwd(input, A, comm, bias, act, prec)
                 y = comm.graph_spmm_end(h)

@@ -251,6 +251,25 @@ def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F
     return out
 
 
+def spmm_highway(A: CSR, B, bias: torch.Tensor, T: DMat, H: DMat, Hc: DMat = None, Hout: DMat = None):
+    """(Hc, Hout) = (tanh(A . B + bias), T*Hc + (1-T)*H) in one launch -- the highway block's convolution with
+    the gating mix (reference gcnmodel.py:266) fused into the SpMM's epilogue."""
+    lib = _ffi.lib()
+    F = H.F
+    if B.n != A.shape[1] or T.n != A.shape[0] or H.n != A.shape[0] or T.ld != H.ld:
+        raise ValueError("spmm_highway: shapes / pitches do not match")
+    Hc = DMat.empty(H.n, F, H.device, ld=H.ld) if Hc is None else Hc
+    Hout = DMat.empty(H.n, F, H.device, ld=H.ld) if Hout is None else Hout
+    if Hc.ld != H.ld or Hout.ld != H.ld:
+        raise ValueError("spmm_highway: T, H, Hc, Hout must share one pitch")
+    need = lib.geogcn_spmm_workspace_bytes(A._plan, F)
+    ws = A._ws.get(need)
+    check(lib.geogcn_spmm_csr_highway_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val),
+                                          _p(B.t), B.ld, int(isinstance(B, HMat)), F, _p(bias), _p(T.t), _p(H.t), H.ld,
+                                          _p(Hc.t), _p(Hout.t), _p(ws), ws.numel(), _stream()), 'spmm_csr_highway_f32')
+    return Hc, Hout
+
+
 _gemm_ws = {}
 
 # How the activation x weight products are formed (include/geogcn.h GEOGCN_GEMM_*): 'f32' = exact fp32

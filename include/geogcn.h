@@ -85,8 +85,20 @@ int geogcn_spmm_csr_bf16b(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t 
                           const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
 int geogcn_cast_bf16_f32(int64_t n, int32_t F, const float* X, int64_t ldx, uint16_t* Y, int64_t ldy, void* stream);
 
+/* Highway block in one launch (gcnmodel.py:130-136 + :266): Hc = tanh(A.B + bias) and
+ * Hout = T*Hc + (1-T)*H, with the gate T and the carried input H read row by row in the SpMM's epilogue
+ * instead of a separate elementwise pass over Hc.  T, H, Hc, Hout share the pitch `ld` (% 4 == 0, 16-byte
+ * bases; pad columns stay zero).  B is fp32 (b_bf16 = 0) or bf16 bit patterns (b_bf16 = 1, ldb in
+ * elements, see geogcn_spmm_csr_bf16b).  Element for element the same arithmetic as
+ * geogcn_spmm_csr_f32(act = tanh) followed by geogcn_highway_fwd_f32.                                */
+int geogcn_spmm_csr_highway_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                                const int32_t* rowptr, const int32_t* colidx, const float* val, const void* B,
+                                int64_t ldb, int32_t b_bf16, int32_t F, const float* bias, const float* T,
+                                const float* H, int64_t ld, float* Hc, float* Hout, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* profiling aid (bench.py's roofline leg): a pool of hipEvent pairs owned by the library.  While a
- * timer is attached, every geogcn_spmm_csr_f32 / _bf16b call whose F equals `only_F` and whose nnz equals
+ * timer is attached, every geogcn_spmm_csr_f32 / _bf16b call (not the fused _highway one) whose F equals `only_F` and whose nnz equals
  * `only_nnz` (0 = any) records one
  * (begin, end) pair immediately around its main row kernel (spmm_rows_kernel) on the call's stream,
  * until the pool is full.  geogcn_timer_read_ms synchronises the recorded events and returns the

@@ -111,6 +111,28 @@ def test_spmm_bf16_gathered_operand(dev, F):
     assert rc == -3
 
 
+@pytest.mark.parametrize("F,bf", [(300, False), (129, False), (64, False), (300, True), (600, True)])
+def test_spmm_highway_epilogue(dev, F, bf):
+    """geogcn_spmm_csr_highway_f32 = geogcn_spmm_csr_f32(tanh) followed by geogcn_highway_fwd_f32, element for
+    element (long rows go through the reduce kernel's copy of the epilogue)."""
+    from geographconv_amd import ops
+    A = _skewed_csr(700, 700, seed=F)
+    dA = ops.CSR(A, dev)
+    assert dA.n_long_rows >= 1
+    Z = ops.DMat.from_numpy(_rand((700, F), 1), dev)
+    if bf:
+        Z = ops.cast_bf16(Z)
+    bias = torch.from_numpy(np.pad(_rand((F,), 2), (0, ops.pad4(F) - F))).to(dev)
+    T = ops.DMat.from_numpy(O.sigmoid(_rand((700, F), 3)).astype(np.float32), dev)
+    H = ops.DMat.from_numpy(_rand((700, F), 4), dev)
+    Hc, Hout = ops.spmm_highway(dA, Z, bias, T, H)
+    Hc_ref = ops.spmm(dA, Z, bias=bias, act=ops.ACT_TANH, F=F)
+    Hout_ref = ops.highway_fwd(T, Hc_ref, H)
+    assert torch.equal(Hc.t, Hc_ref.t)
+    assert torch.allclose(Hout.t, Hout_ref.t, rtol=1e-6, atol=1e-6)      # (fma contraction may differ by an ulp)
+    assert torch.all(Hout.t[:, F:] == 0) and torch.all(Hc.t[:, F:] == 0)
+
+
 def test_spmm_short_rows_bitwise_reproducible_and_sequential(dev):
     """Rows below the split threshold accumulate in stored order with fmaf: two runs are bitwise
     equal and equal to a sequential fp32 fma chain (checked via float64 emulation bound)."""
