@@ -121,6 +121,18 @@ class PreAct:
         self.bias_done = bias_done        # the producer already wrote this layer's bias gradient
 
 
+class Masked:
+    """Gradient token: the true gradient is m * keep_mask * scale (a dropout layer's backward that has not been
+    applied yet) -- a DenseLayer below fuses it into its activation-gradient kernel (geogcn_act_bwd_f32 takes the
+    mask), saving one pass over the N x hid gradient."""
+
+    def __init__(self, m, keep_mask, scale):
+        self.m, self.keep_mask, self.scale = m, keep_mask, scale
+
+    def materialise(self, p):
+        return backend.active().dropout_apply(self.m, self.keep_mask, p)
+
+
 # --------------------------------------------------------------------------------------------
 # base classes (lasagne.layers.base)
 # --------------------------------------------------------------------------------------------
@@ -345,8 +357,10 @@ class DenseLayer(Layer):
             dS = grad
         else:
             uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
-            out = K.DMat.empty(grad.n, grad.F, grad.device, ld=K.gather_ld(grad.F)) if uses_graph else None
-            dS = K.act_bwd(grad, y, self.nonlinearity.act, out=out)
+            km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
+            g_in = grad.m if isinstance(grad, Masked) else grad
+            out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None
+            dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
         if self.b is not None and not (isinstance(grad, PreAct) and grad.bias_done):
             K.colsum(dS, out=self.b.grad)
         handle = None
@@ -379,8 +393,10 @@ class DenseLayer(Layer):
             dS = grad
         else:
             uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
-            out = K.DMat.empty(grad.n, grad.F, grad.device, ld=K.gather_ld(grad.F)) if uses_graph else None
-            dS = K.act_bwd(grad, y, self.nonlinearity.act, out=out)
+            km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
+            g_in = grad.m if isinstance(grad, Masked) else grad
+            out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None
+            dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
         if self.b is not None and not (isinstance(grad, PreAct) and grad.bias_done):
             K.colsum(dS, out=self.b.grad)
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
@@ -466,6 +482,11 @@ class DropoutLayer(Layer):
     def backward(self, grad, tape, into, **kwargs):
         K = backend.active()
         mask = tape[self]['mask']
+        below = self.input_layer
+        if (mask is not None and into[0] is None and isinstance(below, DenseLayer) and not isinstance(grad, (PreAct, Masked))
+                and below.nonlinearity.act not in (None, 0) and below.nonlinearity.fusable and hasattr(K, 'act_bwd')):
+            # the layer below applies mask and 1/(1-p) inside its activation-gradient kernel
+            return [Masked(grad, mask, 1.0 / (1.0 - self.p))]
         g = grad if mask is None else K.dropout_apply(grad, mask, self.p)
         if into[0] is not None:
             return [_accumulate(into[0], g)]
