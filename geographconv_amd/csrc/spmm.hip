@@ -252,36 +252,50 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     }
 }
 
-// long rows: one block per row, thread per output column, partials added in chunk order.
+// long rows: one block per row.  The hub of the TwitterUS-shape graph has 587 partial rows: one thread per column
+// adding them one after the other was latency-bound (0.15 ms for 28 MB of partials).  Four wave-wide chunk
+// groups (one block per row and 64-column slice) walk the partials in an interleaved, FIXED order (group g takes chunks
+// g, g+4, ...; four loads in flight each) and the four sums are combined as (s0+s1)+(s2+s3): no atomics, the
+// same association every run.
 template <int ACT, int HW = 0>
 __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(
     const int* __restrict__ long_rows, const int* __restrict__ long_first, const float* __restrict__ P,
     int64_t ldp, float* __restrict__ C, int64_t ldc, int F, int Fpad, const float* __restrict__ bias,
     const HwArgs hw) {
+    __shared__ float red[4][kWave];
     const int lr = blockIdx.x;
     const int row = long_rows[lr];
     const int c0 = long_first[lr];
     const int c1 = long_first[lr + 1];
-    for (int col = threadIdx.x; col < Fpad; col += kBlock) {
+    const int cg = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    {
+        const int col = blockIdx.y * kWave + lane;          // one 64-column slice per block (grid.y slices)
         float acc = 0.f;
-        int ch = c0;
-        for (; ch + 4 <= c1; ch += 4) {
-            const float p0 = P[(int64_t)(ch + 0) * ldp + col];
-            const float p1 = P[(int64_t)(ch + 1) * ldp + col];
-            const float p2 = P[(int64_t)(ch + 2) * ldp + col];
-            const float p3 = P[(int64_t)(ch + 3) * ldp + col];
-            acc = ((acc + p0) + p1) + p2 + p3;
+        if (col < Fpad) {
+            int ch = c0 + cg;
+            for (; ch + 12 < c1; ch += 16) {
+                const float p0 = P[(int64_t)(ch + 0) * ldp + col];
+                const float p1 = P[(int64_t)(ch + 4) * ldp + col];
+                const float p2 = P[(int64_t)(ch + 8) * ldp + col];
+                const float p3 = P[(int64_t)(ch + 12) * ldp + col];
+                acc = (((acc + p0) + p1) + p2) + p3;
+            }
+            for (; ch < c1; ch += 4) acc += P[(int64_t)ch * ldp + col];
         }
-        for (; ch < c1; ++ch) acc += P[(int64_t)ch * ldp + col];
-        float o = 0.f;
-        if (col < F) {
-            if (bias) acc += bias[col];
-            o = apply_act<ACT>(acc);
-        }
-        C[(int64_t)row * ldc + col] = o;
-        if constexpr (HW) {
-            const float t = hw.T[(int64_t)row * hw.ld + col], h = hw.H[(int64_t)row * hw.ld + col];
-            hw.Hout[(int64_t)row * hw.ld + col] = t * o + (1.0f - t) * h;
+        red[cg][lane] = acc;
+        __syncthreads();
+        if (cg == 0 && col < Fpad) {
+            acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            float o = 0.f;
+            if (col < F) {
+                if (bias) acc += bias[col];
+                o = apply_act<ACT>(acc);
+            }
+            C[(int64_t)row * ldc + col] = o;
+            if constexpr (HW) {
+                const float t = hw.T[(int64_t)row * hw.ld + col], h = hw.H[(int64_t)row * hw.ld + col];
+                hw.Hout[(int64_t)row * hw.ld + col] = t * o + (1.0f - t) * h;
+            }
         }
     }
 }
@@ -386,7 +400,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
 #undef GEOGCN_ROWS__
     if (n_chunks > 0) {
         const int Fpad = (int)std::min<int64_t>(ldc, ldp);
-        const dim3 rgrid((unsigned)plan->n_long);
+        const dim3 rgrid((unsigned)plan->n_long, (unsigned)cdiv(Fpad, kWave));
 #define GEOGCN_RED(ACT) GEOGCN_RED_(ACT, 0)
 #define GEOGCN_RED_(ACT, HW_)                                                                    \
     hipLaunchKernelGGL((spmm_long_reduce_kernel<ACT, HW_>), rgrid, dim3(kBlock), 0, st,          \
