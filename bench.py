@@ -11,8 +11,9 @@ V=10,000, C=256, fp32, dropout 0.5) with (A_hat, X, Y) already resident in HBM. 
 
     value = n_conv_layers * nnz(A_hat) * K / t_K        [GCN-layer fwd+bwd edges/s, whole job]
 
-With --gpus N the SAME graph is row-partitioned over N ranks (strong scaling; one in-place RCCL
-all-gather of Z / dS per conv layer and direction).  The JSON line also carries
+With --gpus N the SAME graph is row-partitioned over N ranks (strong scaling; per conv layer and
+direction the SpMM operand is exchanged over RCCL: in-place all-gather at 2 ranks, a feature
+repartition with two all-to-alls from 3 ranks -- DESIGN.md section 5).  The JSON line also carries
   roofline     : the dominant kernel (spmm_rows_kernel, A_hat.Z at F=300), algorithmic bytes / its
                  average launch duration measured live with hipEvents on the launch stream;
   cpu_baseline : the NumPy/SciPy oracle (oracle/gcn_oracle.py, kind "port") timed on this box's
@@ -38,9 +39,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def spmm_algorithmic_bytes(n_rows_out, n_cols, nnz, F):
-    """every operand touched exactly once (fp32 values, int32 indices)."""
-    return 8 * nnz + 4 * (n_rows_out + 1) + 4 * n_cols * F + 4 * n_rows_out * F
+def spmm_algorithmic_bytes(n_rows_out, n_cols, nnz, F, b_bytes=4):
+    """every operand touched exactly once (fp32 values, int32 indices); the gathered operand B is
+    fp32, or bf16 (b_bytes = 2) in the bf16 configuration."""
+    return 8 * nnz + 4 * (n_rows_out + 1) + b_bytes * n_cols * F + 4 * n_rows_out * F
 
 
 def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample):
@@ -168,13 +170,14 @@ def main():
         F = F_spmm
         # one launch of spmm_rows_kernel covers every stored edge of the local row block (short rows with
         # the fused epilogue + the 128-nonzero chunks of the long rows): algorithmic bytes = SURVEY.md §8d
-        alg = spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F)
+        bf16_operand = args.gemm_precision == 'bf16' and world == 1       # (the partitioned path exchanges fp32)
+        alg = spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F, 2 if bf16_operand else 4)
         e_short = int(csr.nnz)
         avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = alg / (avg_ms * 1e-3) / 1e9 if kern_ms else None
         traffic = None            # PMC passes are collected at 1 GPU, F = hid (profiles/pmc_spmm_latest.json)
-        pmc_file = os.path.join(ROOT, 'profiles', 'pmc_spmm_latest.json')
-        if os.path.exists(pmc_file) and world == 1 and F == 300:
+        pmc_file = os.path.join(ROOT, 'profiles', 'pmc_spmm_bf16_latest.json' if bf16_operand else 'pmc_spmm_latest.json')
+        if os.path.exists(pmc_file) and world == 1 and F == 300 and args.shape == 'twus':
             try:
                 traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
             except Exception:
