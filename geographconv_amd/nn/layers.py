@@ -218,6 +218,13 @@ class InputLayer(Layer):
         return self.shape
 
 
+def _fuse_highway(fp32_operand):
+    """GEOGCN_FUSE_HIGHWAY = f32 (default) | all | none: which SpMM operand formats get the gating mix fused."""
+    import os
+    mode = os.environ.get('GEOGCN_FUSE_HIGHWAY', 'f32')
+    return mode == 'all' or (mode == 'f32' and fp32_operand)
+
+
 def _accumulate(dst, src):
     backend.active().add_inplace(src, dst)
     return dst
@@ -295,8 +302,11 @@ class DenseLayer(Layer):
                         zf = K.cast_bf16(zf)
                 gate = getattr(self, 'highway_gate', None)
                 T = tape.get(gate, {}).get('y') if (gate is not None and tape is not None) else None
+                # (fp32 operand only: on the bf16 operand the epilogue's T / H loads cost more than the separate pass:
+                #  1.82 ms fused against 1.10 + 0.41 ms)
                 if (T is not None and self.nonlinearity is _nl.tanh and bias is not None and isinstance(input, K.DMat)
-                        and tape[gate]['x'] is input and T.ld == input.ld and hasattr(K, 'spmm_highway')):
+                        and _fuse_highway(isinstance(zf, K.DMat)) and tape[gate]['x'] is input and T.ld == input.ld
+                        and hasattr(K, 'spmm_highway')):
                     # highway block: the gating mix T*Hc + (1-T)*H rides in the SpMM's epilogue (the gate was
                     # evaluated just before this layer); MultiplicativeGatingLayer picks the result up
                     y, saved['highway_out'] = K.spmm_highway(A.fwd, zf, bias, T, input)
