@@ -216,7 +216,7 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int p, int G
 template <int BM, int BN, bool AT, bool BT, int ACT, int MODE, int PROBE = 0, int WM = 2, int WN = 2>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_kernel(const GemmArgs a) {
     // PROBE (tools/micro/gemm_variants.hip only; 0 in the library): 1 = no global loads, 2 = no C stores,
-    // 4 = no K-tail early-out, 8 = no LDS stores
+    // 4 = no K-tail early-out, 8 = no LDS stores, 16 = s_setprio around the MFMA section
     using Cfg = GemmCfg<BM, BN, AT, BT, WM, WN>;
     constexpr int NTH = Cfg::NTH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
         const int64_t ckbeg = (int64_t)ct.z * a.kchunk;
         const int64_t ckend = min(a.K, ckbeg + a.kchunk);
         const int64_t k_stage = ckbeg + (int64_t)ckt * BK;
+        if (PROBE & 16) __builtin_amdgcn_s_setprio(1);       // experiment: MFMA section at raised wave priority
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             if (!(PROBE & 4) && kk > 0 && k_stage + kk >= ckend) break;      // K tail: nothing but zero padding left
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
                         // CONSECUTIVE COLUMNS of one row of C, and the epilogue stores float4s
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[jn][t], af[i][t], acc[i][jn], 0, 0, 0);
         }
+        if (PROBE & 16) __builtin_amdgcn_s_setprio(0);
         // stage s+1: registers -> the other LDS buffer.  BEFORE the epilogue's stores in program order, so
         // that the wait for these registers never has to drain the C stores behind them.
         if (!(PROBE & 8)) sstore(cur ^ 1, sa, sb);

@@ -16,8 +16,12 @@ void set_error(const char* fmt, ...) {
     fputc('\n', stderr);
 }
 size_t gemm_bf16_workspace_bytes(int, int64_t, int64_t) { return 0; }
-int gemm_bf16_dispatch(int, int, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t,
+size_t gemm_bf16_tn_workspace_bytes(int64_t, int64_t, int64_t) { return 0; }
+int gemm_bf16_dispatch(int, int, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, void*, int64_t, int,
                        const float*, int, int, void*, size_t, hipStream_t) { return -1; }
+int gemm_bf16_tn_dispatch(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t,
+                          const float*, int, int, void*, size_t, hipStream_t) { return 1; }
+int zero_fill_async(void*, size_t, hipStream_t) { return 0; }
 }  // namespace geogcn
 
 template <int BM, int BN, bool BT, int PROBE>
@@ -54,6 +58,7 @@ int main() {
     hipMemset(A, 0, M * ld * 4);
     hipMemset(B, 0, 320 * 320 * 4);
     run<128, 160, false, 0>("NN 128x160 as shipped", M, N, K, A, ld, B, ldw, C, ld);
+    run<128, 160, false, 16>("NN  + s_setprio(1) around the MFMA section", M, N, K, A, ld, B, ldw, C, ld);
     run<128, 160, false, 4>("NN  no K-tail early-out", M, N, K, A, ld, B, ldw, C, ld);
     run<128, 160, false, 2>("NN  no C stores", M, N, K, A, ld, B, ldw, C, ld);
     run<128, 160, false, 1>("NN  no global loads", M, N, K, A, ld, B, ldw, C, ld);
@@ -61,6 +66,7 @@ int main() {
     run<128, 160, false, 11>("NN  no global loads, no C stores, no LDS stores", M, N, K, A, ld, B, ldw, C, ld);
     run<128, 160, false, 15>("NN  ... and no K-tail early-out", M, N, K, A, ld, B, ldw, C, ld);
     run<96, 160, true, 0>("NT 96x160 as shipped", M, N, K, A, ld, B, ldw, C, ld);
+    run<96, 160, true, 16>("NT  + s_setprio(1) around the MFMA section", M, N, K, A, ld, B, ldw, C, ld);
     run<96, 160, true, 2>("NT  no C stores", M, N, K, A, ld, B, ldw, C, ld);
     run<96, 160, true, 1>("NT  no global loads", M, N, K, A, ld, B, ldw, C, ld);
     run<96, 160, true, 11>("NT  no global loads, no C stores, no LDS stores", M, N, K, A, ld, B, ldw, C, ld);
