@@ -504,7 +504,7 @@ class SparseOperand:
         self.shape = fwd.shape
 
     @staticmethod
-    def from_scipy(m, device, need_transpose=True, long_row_nnz=256, chunk_nnz=128, dense_head=True,
+    def from_scipy(m, device, need_transpose=True, long_row_nnz=None, chunk_nnz=None, dense_head=True,
                    hub_row_bytes=None):
         m = sps.csr_matrix(m).astype(np.float32)
         m.sort_indices()

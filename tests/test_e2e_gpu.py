@@ -274,7 +274,6 @@ def test_hip_graph_replay_equals_eager_steps(cmu):
         dt = (time.perf_counter() - t0) / 3
         runs[mode] = (hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out), clf.adam_t, dt, clf)
     (he, Pe, pe, te, dte, _), (hg, Pg, pg, tg, dtg, clfg) = runs[False], runs[True]
-    print('eager ', [h[0] for h in he]); print('graph ', [h[0] for h in hg])
     assert clfg._hg is not None and clfg._hg['graph'] is not None          # it really replayed a captured graph
     assert te == tg == 7 and clfg.l_drop._calls == 7
     assert len(set(h[0] for h in hg)) == 7                                  # seven different steps, not one replayed
@@ -283,7 +282,10 @@ def test_hip_graph_replay_equals_eager_steps(cmu):
         assert abs(a[1] - b[1]) <= 2e-3 and abs(a[3] - b[3]) <= 2e-3
     assert np.abs(Pe - Pg).max() <= 1e-5
     for q, r in zip(pe, pg):
-        assert np.abs(q - r).max() <= 1e-4 * 0.02 + 1e-7
+        # (a_t comes from the device's powf in one run and the host's in the other: entries whose gradient is ~0 see
+        #  m/sqrt(v) move by a visible fraction of the 2e-3 step, as in test_cmu_train_step_matches_oracle)
+        assert np.abs(q - r).max() <= 2e-3 * 0.05 + 1e-7
+        assert np.mean(np.abs(q - r)) <= 1e-7
     print("CMU step: eager %.3f ms, hipGraph replay %.3f ms" % (dte * 1e3, dtg * 1e3))
     # changing an input object falls back to eager steps and a new capture
     ytr2 = c['Y'][c['tr']].copy()
