@@ -42,14 +42,59 @@ class SparseInputDenseLayer(DenseLayer):
             raise ValueError("Input for this layer must be sparse")
 
 
-class ConvolutionDenseLayer2(DenseLayer):
-    """act(A . (H . W) + b), A passed through get_output (reference gcnmodel.py:114-136)."""
+def _device_index(idx, device):
+    import torch
+    if isinstance(idx, torch.Tensor):
+        return idx.to(device=device, dtype=torch.int32)
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(idx), dtype=np.int32)).to(device)
+
+
+class _TargetRows:
+    """`activation[target_indices, :]` of the reference's layers (gcnmodel.py:134-135,:110,:199-200,:218-219):
+    with `use_target_indices` the layer returns only the rows named by the `target_indices` kwarg of get_output.
+    The reference gathers BEFORE the nonlinearity; the nonlinearities here act per row (elementwise or softmax),
+    so gathering the finished rows is the same thing and keeps bias + activation fused in the producing kernel.
+    The backward scatters the incoming gradient into a zero matrix of all rows (rows named twice: last one
+    wins -- the reference's index vectors are unique, gcnmain.py:207)."""
+
+    def _target(self, kwargs):
+        return kwargs.get('target_indices') if getattr(self, 'use_target_indices', False) else None
+
+    def forward(self, input, tape, **kwargs):
+        K = backend.active()
+        y = super().forward(input, tape, **kwargs)
+        idx = self._target(kwargs)
+        if idx is None:
+            return y
+        t_idx = _device_index(idx, y.device)
+        out = K.DMat.empty(int(t_idx.numel()), y.F, y.device)
+        if out.ld != y.F:
+            out.t.zero_()
+        K.gather_rows(y, t_idx, out=out.t)
+        if tape is not None:
+            tape[self]['target_idx'] = t_idx
+            tape[self]['n_full'] = y.n
+        return out
+
+    def backward(self, grad, tape, into, **kwargs):
+        K = backend.active()
+        s = tape[self]
+        if s.get('target_idx') is not None:
+            if isinstance(grad, L.PreAct):
+                raise NotImplementedError("a fused pre-activation gradient cannot pass through a row gather")
+            full = K.DMat(s['n_full'], grad.F, grad.device)          # zeros
+            K.scatter_rows(grad, s['target_idx'], full)
+            grad = full
+        return super().backward(grad, tape, into, **kwargs)
+
+
+class ConvolutionDenseLayer2(_TargetRows, DenseLayer):
+    """act(A . (H . W) + b), A passed through get_output (reference gcnmodel.py:114-136); with
+    use_target_indices only the rows in the `target_indices` kwarg are returned (never enabled by GraphConv)."""
 
     def __init__(self, incoming, use_target_indices=False, **kwargs):
         super().__init__(incoming, **kwargs)
         self.use_target_indices = use_target_indices
-        if use_target_indices:
-            raise NotImplementedError("use_target_indices is never enabled by the reference (gcnmodel.py:121)")
 
     def _uses_graph(self, kwargs):
         return kwargs.get('A') is not None
@@ -99,6 +144,13 @@ class ConvolutionDenseLayer_zero(_BoundA):
     """reference gcnmodel.py:159-179"""
 
 
+class ConvolutionDenseLayer(_TargetRows, _BoundA):
+    """reference gcnmodel.py:94-112: A bound at construction, and the output is ALWAYS indexed by the
+    `target_indices` kwarg.  (Without that kwarg the reference evaluates `activation[None, :]`, which in Theano
+    prepends a broadcast axis -- an accident of the unused class; here no kwarg means all rows.)"""
+    use_target_indices = True
+
+
 class SparseConvolutionDenseLayer(_BoundA):
     """reference gcnmodel.py:72-92"""
 
@@ -110,13 +162,11 @@ class SparseConvolutionDenseLayer(_BoundA):
         return backend.active().spmm(input.fwd, self.W.data, out=out)
 
 
-class ConvolutionLayer(L.Layer):
+class _ConvolutionCore(L.Layer):
     """A . H only -- no weights (reference gcnmodel.py:181-201); A bound at construction."""
 
     def __init__(self, incoming, use_target_indices=False, A=None, nonlinearity=NL.linear, **kwargs):
         super().__init__(incoming, **kwargs)
-        if use_target_indices:
-            raise NotImplementedError("use_target_indices is never enabled by the reference")
         self.use_target_indices = use_target_indices
         self.A = A
         self.nonlinearity = NL.resolve(nonlinearity)
@@ -140,8 +190,12 @@ class ConvolutionLayer(L.Layer):
         return [dx]
 
 
-class DenseLayer2(DenseLayer):
-    """Plain dense layer with the (never enabled) row gather flag (reference gcnmodel.py:203-221)."""
+class ConvolutionLayer(_TargetRows, _ConvolutionCore):
+    """act(A . H) with the optional row gather (reference gcnmodel.py:181-201)."""
+
+
+class DenseLayer2(_TargetRows, DenseLayer):
+    """Plain dense layer with the row gather flag (reference gcnmodel.py:203-221)."""
 
     def __init__(self, incoming, use_target_indices=False, **kwargs):
         super().__init__(incoming, **kwargs)

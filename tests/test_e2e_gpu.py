@@ -207,6 +207,34 @@ def test_layer_zoo_variants_match_oracle(cmu):
     l5 = M.ConvolutionDenseLayer2(d_in, num_units=32, W=W2, b=None, nonlinearity=NL.rectify)
     L.ParamStore(L.get_all_params(l5), dev)
     assert np.abs(L.get_output(l5, {d_in: H}, A=A).numpy() - np.maximum(O.spmm(c['A'], ref @ W2), 0)).max() < 2e-5
+    # target_indices (gcnmodel.py:110,134-135,199-200,218-219): only the named rows come out; the gradient of the
+    # other rows is zero.  ConvolutionDenseLayer (A bound, always indexed), ConvolutionDenseLayer2 / ConvolutionLayer /
+    # DenseLayer2 with use_target_indices=True
+    idx = rng.permutation(c['A'].shape[0])[:777].astype(np.int32)
+    b2 = (rng.randn(32) * 0.1).astype(np.float32)
+    full = np.tanh(O.spmm(c['A'], ref @ W2) + b2)
+    l6 = M.ConvolutionDenseLayer(d_in, A=A, num_units=32, W=W2, b=b2, nonlinearity=NL.tanh)
+    L.ParamStore(L.get_all_params(l6), dev)
+    tape = {}
+    y6 = L.get_output(l6, {d_in: H}, tape=tape, target_indices=idx)
+    assert y6.n == 777 and np.abs(y6.numpy() - full[idx]).max() < 2e-5
+    assert np.abs(L.get_output(l6, {d_in: H}).numpy() - full).max() < 2e-5            # no indices: all rows
+    G6 = rng.randn(777, 32).astype(np.float32)
+    L.backward(l6, ops.DMat.from_numpy(G6, dev), tape)
+    Gfull = np.zeros_like(full)
+    Gfull[idx] = G6
+    dZ = O.spmm_t(c['A'], Gfull * (1 - full * full))
+    p6 = L.get_all_params(l6)
+    assert np.abs(p6[0]._store.read_grad(p6[0]) - ref.T @ dZ).max() <= 2e-4 * np.abs(ref.T @ dZ).max()
+    assert np.abs(p6[1]._store.read_grad(p6[1]) - (Gfull * (1 - full * full)).sum(0)).max() <= 1e-4
+    l7 = M.ConvolutionDenseLayer2(d_in, use_target_indices=True, num_units=32, W=W2, b=b2, nonlinearity=NL.tanh)
+    L.ParamStore(L.get_all_params(l7), dev)
+    assert np.abs(L.get_output(l7, {d_in: H}, A=A, target_indices=idx).numpy() - full[idx]).max() < 2e-5
+    l8 = M.ConvolutionLayer(d_in, use_target_indices=True, A=A)
+    assert np.abs(L.get_output(l8, {d_in: H}, target_indices=idx).numpy() - O.spmm(c['A'], ref)[idx]).max() < 2e-5
+    l9 = M.DenseLayer2(d_in, use_target_indices=True, num_units=32, W=W2, b=b2, nonlinearity=NL.sigmoid)
+    L.ParamStore(L.get_all_params(l9), dev)
+    assert np.abs(L.get_output(l9, {d_in: H}, target_indices=idx).numpy() - O.sigmoid(ref @ W2 + b2)[idx]).max() < 2e-5
 
 
 def test_config5_bf16_six_layer_600_hidden():
