@@ -91,6 +91,11 @@ class Comm:
         K = backend.active()
         return K.DMat.empty(self.part.N, F, self.device, ld=K.gather_ld(F))
 
+    def stage_operand(self, m, F, tag=None):
+        """An existing matrix as the SpMM's dense operand (the backward's dS): used in place on one GPU; the
+        partitioned communicator copies it into its exchange buffer."""
+        return m
+
     def graph_spmm(self, A_csr, z, bias, act, F, tag=None):
         return self.graph_spmm_end(self.graph_spmm_begin(A_csr, z, bias, act, F, tag))
 
@@ -107,6 +112,40 @@ class Comm:
 
     def all_reduce_sum_(self, t: torch.Tensor):
         return t
+
+
+class StreamOverlapComm(Comm):
+    """Single GPU: the graph SpMM runs on a SIDE HIP stream between graph_spmm_begin and _end, so that the work the
+    layer sweep enqueues in between (the highway gate's GEMMs) shares the device with it.  The SpMM is bound by
+    gather traffic from beyond the L2 and leaves MFMA pipes and most issue slots idle; the fp32 GEMM is
+    MFMA-bound -- measured with tools/cu_mask_probe.py: (SpMM, gate GEMM) 2.70 -> 2.50 ms, (SpMM^T, dWt, dH)
+    3.59 -> 3.34 ms.  Same kernels, same arithmetic; only the launch streams differ."""
+    exchange = 'stream'
+
+    def __init__(self, N, device):
+        super().__init__(N, device)
+        self.side = torch.cuda.Stream(device=device)
+
+    def graph_spmm_begin(self, A_csr, z, bias, act, F, tag=None):
+        K = backend.active()
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self.side.wait_event(ready)                  # the operand was produced on the main stream
+        with torch.cuda.stream(self.side):
+            out = K.spmm(A_csr, z, bias=bias, act=act, F=F)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        # caching-allocator bookkeeping: both tensors are used on a stream other than the one that allocated them
+        z.t.record_stream(self.side)
+        out.t.record_stream(main)
+        if bias is not None:
+            bias.record_stream(self.side)
+        return dict(out=out, done=done, work=None)
+
+    def graph_spmm_end(self, h):
+        torch.cuda.current_stream(self.device).wait_event(h['done'])
+        return h['out']
 
 
 class TorchDistComm(Comm):
@@ -173,6 +212,11 @@ class TorchDistComm(Comm):
             lo = self.rank * self.part.R
             return buf.rows(lo, lo + self.part.n_local)         # the GEMM writes straight into my slot
         return K.DMat.empty(self.part.n_local, F, self.device)
+
+    def stage_operand(self, m, F, tag=None):
+        g = self.matmul_target(F, tag=tag)
+        g.copy_from(m)
+        return g
 
     # -- the exchange around A . Z ----------------------------------------------------------------------
     def panel_width(self, F):

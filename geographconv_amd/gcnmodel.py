@@ -330,6 +330,8 @@ class GraphConv():
         self.hip_graph = (os.environ.get('GEOGCN_HIP_GRAPH', '0') == '1') if hip_graph is None else bool(hip_graph)
         self._hg = None
         self._adam_state_dev = None
+        self.stream_overlap = os.environ.get('GEOGCN_STREAM_OVERLAP', '0') == '1'      # measured: no net gain, off
+        self._overlap_comm = None
         self.best_params = None
         logging.info('highway is {}'.format(self.highway))
 
@@ -377,6 +379,22 @@ class GraphConv():
 
     def _dist(self, comm):
         return comm.world > 1 or (self._force_dist and hasattr(comm, 'dist'))
+
+    def _layer_comm(self, comm):
+        """What the layers get as `comm`: the communicator when the graph is partitioned; on one GPU the
+        stream-overlap helper (SpMM on a side stream under the highway gate's GEMMs) when switched on
+        (GEOGCN_STREAM_OVERLAP=1; off by default: in the model it gave 30.4 ms against 30.1 ms -- the pairs overlap
+        by 6-7 % but the gating mix can no longer ride in the SpMM's epilogue), never in the bf16 configuration
+        (its SpMM operand format is not wired through the two-phase path) or when the step is captured as a hipGraph."""
+        if self._dist(comm):
+            return comm
+        if (self.highway and self.stream_overlap and not self.hip_graph and self.device.type == 'cuda'
+                and (self.gemm_precision or backend.active().GEMM_PRECISION) != 'bf16'):
+            if self._overlap_comm is None or self._overlap_comm.part.N != comm.part.N:
+                from .dist import StreamOverlapComm
+                self._overlap_comm = StreamOverlapComm(comm.part.N, self.device)
+            return self._overlap_comm
+        return None
 
     # -- device residency of the constant inputs ------------------------------------------------
     def _comm_for(self, N):
@@ -485,7 +503,7 @@ class GraphConv():
                 m = m[comm.part.r0:comm.part.r1]
             mask = torch.from_numpy(np.ascontiguousarray(m)).to(self.device)
         tape = {}
-        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=comm if self._dist(comm) else None,
+        kw = dict(A=g['A'], deterministic=False, dropout_mask=mask, comm=self._layer_comm(comm),
                   gemm_precision=self.gemm_precision, device_counters=counters)
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
@@ -567,7 +585,7 @@ class GraphConv():
         import torch
         g = self._device_graph(X, A)
         comm = g['comm']
-        kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None,
+        kw = dict(A=g['A'], deterministic=True, comm=self._layer_comm(comm),
                   gemm_precision=self.gemm_precision)
         tape = {}
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
@@ -586,7 +604,7 @@ class GraphConv():
         def f_gate(X, A):
             g = self._device_graph(X, A)
             comm = g['comm']
-            kw = dict(A=g['A'], deterministic=True, comm=comm if self._dist(comm) else None,
+            kw = dict(A=g['A'], deterministic=True, comm=self._layer_comm(comm),
                       gemm_precision=self.gemm_precision)
             T = L.get_output(layer, {self.l_in: g['X']}, **kw)
             return T.numpy()

@@ -381,8 +381,7 @@ class DenseLayer(Layer):
             hint = kwargs.get('A_bwd_rows_hint')
             if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
                 A_bwd = hint[1]
-            g = comm.matmul_target(self.num_units, tag='bwd')
-            g.copy_from(dS)
+            g = comm.stage_operand(dS, self.num_units, tag='bwd')
             handle = comm.graph_spmm_begin(A_bwd, g, None, 0, self.num_units, tag='bwd')
         return dS, handle
 
