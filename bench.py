@@ -50,6 +50,14 @@ def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample):
     from oracle import gcn_oracle as O
     nnz = A.nnz
     threads = os.cpu_count() or 1
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     if sample == 'layer':
         rng = np.random.RandomState(1)
         H = rng.randn(A.shape[0], 300).astype(np.float32)
@@ -59,7 +67,7 @@ def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample):
         t0 = time.time()
         O.conv_layer_fwd_bwd(H, W, b, A, G)
         t = time.time() - t0
-        return {"value": nnz / t, "unit": "edges/s", "cores": threads, "kind": "port", "seconds": round(t, 2),
+        return {"value": nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": model, "kind": "port", "seconds": round(t, 2),
                 "sample": "1 ConvolutionDenseLayer2 fwd+bwd (300->300) on the full %s graph; scipy CSR SpMM is "
                           "single-threaded like Theano's StructuredDot, BLAS sgemm uses %d threads" % (shape, threads)}
     params = O.random_params(X.shape[1], hid, C, True, seed=7)
@@ -69,7 +77,7 @@ def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample):
     O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.5, mask)
     t = time.time() - t0
     n_conv = len(hid)
-    return {"value": n_conv * nnz / t, "unit": "edges/s", "cores": threads, "kind": "port", "seconds": round(t, 2),
+    return {"value": n_conv * nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": model, "kind": "port", "seconds": round(t, 2),
             "sample": "1 full f_train step (same workload, same unit: %d conv layers x nnz / step time) on the full %s "
                       "graph; scipy CSR SpMM is single-threaded like Theano's StructuredDot, BLAS sgemm uses %d "
                       "threads" % (n_conv, shape, threads)}
