@@ -195,6 +195,50 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, 
     }
 }
 
+// act_bwd with the bias gradient (column sums of dS) in the same pass -- same block / thread layout and the same
+// fixed summation order as highway_bwd_colsum_kernel
+template <int ACT>
+__global__ __launch_bounds__(TPB) void act_bwd_colsum_kernel(int64_t n, int F, int ld4, const float4* __restrict__ G,
+                                                              const float4* __restrict__ Y,
+                                                              const uint8_t* __restrict__ mask, float scale,
+                                                              float4* __restrict__ dS, int ld4_dS, int64_t rows_per_block,
+                                                              float4* __restrict__ P) {
+    __shared__ float4 red[TPB];
+    const int W = ld4, rpi = TPB / W;
+    const int q = threadIdx.x % W, ri = threadIdx.x / W;
+    const int c0 = q * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    float4 aS = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ri < rpi) {
+        for (int64_t row = r0 + ri; row < r1; row += rpi) {
+            const float4 g = G[row * ld4 + q], y = Y[row * ld4 + q];
+            float go[4] = {g.x, g.y, g.z, g.w};
+            const float yo[4] = {y.x, y.y, y.z, y.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float gg = go[i];
+                if (mask) gg = (c0 + i < F) ? gg * ((float)mask[row * F + c0 + i] * scale) : 0.f;
+                if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = gg * (1.0f - yo[i] * yo[i]);
+                else if constexpr (ACT == GEOGCN_ACT_SIGMOID) o[i] = gg * (yo[i] * (1.0f - yo[i]));
+                else o[i] = gg;
+            }
+            const float4 s = mask_pad(make_float4(o[0], o[1], o[2], o[3]), c0, F);
+            dS[row * ld4_dS + q] = s;
+            aS.x += s.x; aS.y += s.y; aS.z += s.z; aS.w += s.w;
+        }
+    }
+    red[threadIdx.x] = aS;
+    __syncthreads();
+    if (ri == 0) {
+        for (int k = 1; k < rpi; ++k) {
+            const float4 a = red[k * W + q];
+            aS.x += a.x; aS.y += a.y; aS.z += a.z; aS.w += a.w;
+        }
+        P[(int64_t)blockIdx.x * W + q] = aS;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void dropout_apply_kernel(int64_t n, int F, int F4, const float* __restrict__ X,
                                                             int64_t ld, const uint8_t* __restrict__ mask,
                                                             float scale, float* __restrict__ Y) {
@@ -633,6 +677,42 @@ int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t
     hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(n_idx * F)), dim3(TPB), 0, (hipStream_t)stream, F, X, ldx,
                        idx, n_idx, out, ldo);
     GEOGCN_LAUNCH_CHECK("gather_rows_kernel");
+    return 0;
+}
+
+int geogcn_act_bwd_colsum_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
+                              const uint8_t* keep_mask, float scale, float* dS, int64_t ld_dS, float* db, void* ws,
+                              size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "act_bwd_colsum_f32: negative size");
+    GEOGCN_REQUIRE(db, GEOGCN_E_NULL, "act_bwd_colsum_f32: null db");
+    if (n == 0 || F == 0) return 0;
+    const int64_t F4 = (F + 3) / 4;
+    const bool fused = (act == GEOGCN_ACT_TANH || act == GEOGCN_ACT_SIGMOID || act == GEOGCN_ACT_NONE) && ld == F4 * 4 &&
+                       F4 <= TPB;
+    if (!fused) {          // odd pitch / other activations: two passes, same results
+        int rc = geogcn_act_bwd_f32(n, F, G, Y, ld, act, keep_mask, scale, dS, ld_dS, stream);
+        if (rc) return rc;
+        return geogcn_colsum_f32(n, F, dS, ld_dS, db, ws, ws_bytes, stream);
+    }
+    CHECK_VEC("act_bwd_colsum_f32", ld, G, Y, dS);
+    GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= ld, GEOGCN_E_ALIGN, "act_bwd_colsum_f32: bad ld_dS=%lld", (long long)ld_dS);
+    const int64_t parts = hw_parts(n);
+    const int64_t rpb = cdiv(n, parts);
+    const int nparts = (int)cdiv(n, rpb);
+    GEOGCN_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)nparts * ld * sizeof(float), GEOGCN_E_ARG,
+                   "act_bwd_colsum_f32: workspace too small (see geogcn_highway_bwd_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    const int ld4 = (int)(ld / 4);
+#define GEOGCN_AB(ACT)                                                                                               \
+    hipLaunchKernelGGL((act_bwd_colsum_kernel<ACT>), dim3((unsigned)nparts), dim3(TPB), 0, st, n, F, ld4, (const float4*)G, \
+                       (const float4*)Y, keep_mask, scale, (float4*)dS, (int)(ld_dS / 4), rpb, (float4*)ws)
+    if (act == GEOGCN_ACT_TANH) GEOGCN_AB(GEOGCN_ACT_TANH);
+    else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_AB(GEOGCN_ACT_SIGMOID);
+    else GEOGCN_AB(GEOGCN_ACT_NONE);
+#undef GEOGCN_AB
+    GEOGCN_LAUNCH_CHECK("act_bwd_colsum_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, (const float*)ws, ld, db);
+    GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
 }
 

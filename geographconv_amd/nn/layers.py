@@ -359,6 +359,7 @@ class DenseLayer(Layer):
         K = backend.active()
         s = tape[self]
         y = s['y']
+        bias_done = False
         if isinstance(grad, PreAct):
             dS = grad.m
         elif self.nonlinearity is _nl.softmax:
@@ -370,8 +371,13 @@ class DenseLayer(Layer):
             km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
             g_in = grad.m if isinstance(grad, Masked) else grad
             out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None
-            dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
-        if self.b is not None and not (isinstance(grad, PreAct) and grad.bias_done):
+            if self.b is not None and hasattr(K, 'act_bwd_colsum'):
+                # activation gradient and bias gradient (its column sums) in one pass
+                dS = K.act_bwd_colsum(g_in, y, self.nonlinearity.act, self.b.grad, out=out, keep_mask=km, scale=sc)
+                bias_done = True
+            else:
+                dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
+        if self.b is not None and not bias_done and not (isinstance(grad, PreAct) and grad.bias_done):
             K.colsum(dS, out=self.b.grad)
         handle = None
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
@@ -394,6 +400,7 @@ class DenseLayer(Layer):
             dS, handle = self._pending.pop(('bwd', id(tape)), None) or self._backward_pre(grad, tape, kwargs)
             dZ = kwargs['comm'].graph_spmm_end(handle)
             return self._backward_post(x, dZ, into, need_input_grad, kwargs)
+        bias_done = False
         if isinstance(grad, PreAct):
             dS = grad.m
         elif self.nonlinearity is _nl.softmax:
@@ -405,8 +412,13 @@ class DenseLayer(Layer):
             km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
             g_in = grad.m if isinstance(grad, Masked) else grad
             out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None
-            dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
-        if self.b is not None and not (isinstance(grad, PreAct) and grad.bias_done):
+            if self.b is not None and hasattr(K, 'act_bwd_colsum'):
+                # activation gradient and bias gradient (its column sums) in one pass
+                dS = K.act_bwd_colsum(g_in, y, self.nonlinearity.act, self.b.grad, out=out, keep_mask=km, scale=sc)
+                bias_done = True
+            else:
+                dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
+        if self.b is not None and not bias_done and not (isinstance(grad, PreAct) and grad.bias_done):
             K.colsum(dS, out=self.b.grad)
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
         if A is not None:

@@ -347,6 +347,17 @@ def act_bwd(G: DMat, Y: DMat, act, out: DMat = None, keep_mask=None, scale=1.0):
     return out
 
 
+def act_bwd_colsum(G: DMat, Y: DMat, act, db: torch.Tensor, out: DMat = None, keep_mask=None, scale=1.0):
+    """act_bwd plus the bias gradient db = column sums of dS in the same pass."""
+    lib = _ffi.lib()
+    out = G.like() if out is None else out
+    w = _ws_for(G.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(G.n, G.F),
+                                  lib.geogcn_colsum_workspace_bytes(G.n, G.F)))
+    check(lib.geogcn_act_bwd_colsum_f32(G.n, G.F, _p(G.t), _p(Y.t), G.ld, int(act), _p(keep_mask), float(scale),
+                                        _p(out.t), out.ld, _p(db), _p(w), w.numel(), _stream()), 'act_bwd_colsum_f32')
+    return out
+
+
 def tanh_bwd(G: DMat, Y: DMat, out: DMat = None, keep_mask=None, scale=1.0):
     return act_bwd(G, Y, ACT_TANH, out, keep_mask, scale)
 

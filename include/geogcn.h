@@ -173,6 +173,11 @@ size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F);
  * mask folds in the dropout that follows layer 0 (gcnmodel.py:357); mask may be NULL.           */
 int geogcn_act_bwd_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
                        const uint8_t* keep_mask, float scale, float* dS, int64_t ld_dS, void* stream);
+/* the same with the bias gradient db[F] = column sums of dS in the same pass (deterministic: fixed block / thread
+ * partition, partials combined in order); workspace: geogcn_highway_bwd_workspace_bytes(n, F) suffices       */
+int geogcn_act_bwd_colsum_f32(int64_t n, int32_t F, const float* G, const float* Y, int64_t ld, int32_t act,
+                              const uint8_t* keep_mask, float scale, float* dS, int64_t ld_dS, float* db,
+                              void* ws, size_t ws_bytes, void* stream);
 /* Y += X over n_floats contiguous floats (gradient accumulation where a layer output feeds
  * several consumers: Theano's Elemwise{add} in the autodiff graph of gcnmodel.py:266,288)      */
 int geogcn_add_inplace_f32(int64_t n_floats, const float* X, float* Y, void* stream);

@@ -405,6 +405,31 @@ def test_highway_and_tanh_kernels(dev, n, F):
     assert np.array_equal(got, H * mask * np.float32(2.0))
 
 
+@pytest.mark.parametrize("n,F,act", [(5000, 300, 1), (257, 129, 2), (3, 5, 0), (777, 300, 4)])
+def test_act_bwd_colsum_fused(dev, n, F, act):
+    """geogcn_act_bwd_colsum_f32 = act_bwd followed by colsum (the fused kernel for tanh / sigmoid / none at the
+    natural pitch, the two-pass fallback otherwise), with and without the dropout mask; deterministic."""
+    from geographconv_amd import ops
+    G = ops.DMat.from_numpy(_rand((n, F), 1), dev)
+    Y = ops.DMat.from_numpy(np.tanh(_rand((n, F), 2)), dev)
+    mask = torch.from_numpy((np.random.RandomState(3).rand(n, F) < 0.5).astype(np.uint8)).to(dev)
+    for km, sc in ((None, 1.0), (mask, 2.0)):
+        ref = ops.act_bwd(G, Y, act, keep_mask=km, scale=sc)
+        db_ref = ops.colsum(ref)
+        db = torch.zeros(ops.pad4(F), dtype=torch.float32, device=dev)
+        got = ops.act_bwd_colsum(G, Y, act, db, keep_mask=km, scale=sc)
+        assert torch.equal(got.t, ref.t)
+        col = np.abs(ref.numpy()).sum(0)
+        assert np.all(np.abs(db[:F].cpu().numpy() - db_ref[:F].cpu().numpy()) <= 2e-6 * col + 1e-7)
+        db2 = torch.zeros_like(db)
+        ops.act_bwd_colsum(G, Y, act, db2, keep_mask=km, scale=sc)
+        assert torch.equal(db, db2)
+        # line-aligned output pitch (what the graph convolutions ask for)
+        out = ops.DMat.empty(n, F, dev, ld=ops.gather_ld(F))
+        ops.act_bwd_colsum(G, Y, act, db2, out=out, keep_mask=km, scale=sc)
+        assert torch.equal(out.t[:, :ops.pad4(F)], ref.t) and torch.equal(db, db2)
+
+
 def test_colsum_gather_deterministic(dev):
     from geographconv_amd import ops
     X = _rand((70001, 300), 1)
