@@ -77,6 +77,9 @@ __device__ __forceinline__ float apply_act(float x) {
 // launched on an idle device (tests/test_e2e_gpu.py::test_hip_graph_...); kernel -> kernel edges are safe.
 int zero_fill_async(void* ptr, size_t bytes, hipStream_t st);        // core.hip; bytes % 4 == 0
 
+// elementwise.hip: out[col] = sum over parts of P[part * stride + col], fixed tree (deterministic)
+int colsum_final_launch(int nparts, int F, const float* P, int64_t stride, float* out, hipStream_t st);
+
 // gemm.hip: C = act(sum_z W[z] + bias) [+ C], slabs added in index order
 int splitk_reduce_launch(int64_t M, int64_t N, int nsplit, const float* W, int64_t ldw, float* C, int64_t ldc,
                          const float* bias, int act, int accumulate, hipStream_t st);

@@ -395,6 +395,13 @@ __global__ __launch_bounds__(TPB) void unpack_panels_kernel(int64_t n_rows, int6
 int64_t colsum_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(n, 64))); }
 
 }  // namespace
+
+int colsum_final_launch(int nparts, int F, const float* P, int64_t stride, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, P, stride, out);
+    GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
 }  // namespace geogcn
 
 using namespace geogcn;

@@ -158,6 +158,51 @@ __global__ __launch_bounds__(TPB) void ce_bwd_kernel(int C, const float* __restr
     }
 }
 
+// The same scatter with the output layer's bias gradient (column sums of dlogits) in the same pass: wave w takes
+// the index entries w, w + n_waves, ... and keeps their column sums in registers (C <= 1024: 16 per lane); the four
+// waves of a block are combined in wave order through LDS, one partial row per block, added in fixed order
+// afterwards (colsum_final) -- no pass over the N x C matrix.
+constexpr int kCeBlocks = 1024;
+constexpr int kCeWaves = kCeBlocks * kWavesPerBlock;
+__global__ __launch_bounds__(TPB) void ce_bwd_db_kernel(int C, const float* __restrict__ P, int64_t ldp,
+                                                        const int* __restrict__ idx, int64_t n_idx,
+                                                        const int* __restrict__ y, float inv_n,
+                                                        float* __restrict__ D, int64_t ldd, float* __restrict__ part,
+                                                        int cpad) {
+    __shared__ float red[kWavesPerBlock][kWave];
+    const int wv = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int w = blockIdx.x * kWavesPerBlock + wv;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int64_t j = w; j < n_idx; j += kCeWaves) {
+        const int64_t row = idx[j];
+        const int yy = y[j];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = lane + kWave * k;
+            if (c < C) {
+                const float g = (P[row * ldp + c] - (c == yy ? 1.0f : 0.0f)) * inv_n;
+                atomicAdd(D + row * ldd + c, g);
+                acc[k] += g;
+            }
+        }
+    }
+    for (int k = 0; k < 16; ++k) {
+        const int c = lane + kWave * k;
+        if (kWave * k >= cpad) break;
+        red[wv][lane] = acc[k];
+        __syncthreads();
+        if (wv == 0 && c < cpad) {
+            float t = red[0][lane];
+#pragma unroll
+            for (int i = 1; i < kWavesPerBlock; ++i) t += red[i][lane];
+            part[(int64_t)blockIdx.x * cpad + c] = (c < C) ? t : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
 // lasagne.updates.adam: a_t = lr * sqrt(1 - b2^t) / (1 - b1^t), computed in fp32 like floatX=float32
 __host__ __device__ __forceinline__ float adam_a_t(float lr, float b1, float b2, float t) {
     return lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
@@ -287,6 +332,31 @@ int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t 
                        n_idx, y, inv_n, dlogits, ldd);
     GEOGCN_LAUNCH_CHECK("ce_bwd_kernel");
     return 0;
+}
+
+size_t geogcn_softmax_ce_bwd_db_workspace_bytes(int32_t C) {
+    return C <= 0 ? 0 : (size_t)kCeBlocks * (size_t)((C + 3) / 4) * 4 * sizeof(float);
+}
+
+int geogcn_softmax_ce_bwd_db_f32(int64_t n, int32_t C, const float* probs, int64_t ldp, const int32_t* idx,
+                                 int64_t n_idx, const int32_t* y, float inv_n, float* dlogits, int64_t ldd, float* db,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && C >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "softmax_ce_bwd_db_f32: negative size");
+    if (n == 0 || C == 0) return 0;
+    GEOGCN_REQUIRE(dlogits && db, GEOGCN_E_NULL, "softmax_ce_bwd_db_f32: null pointer");
+    GEOGCN_REQUIRE(ldd >= C, GEOGCN_E_SIZE, "softmax_ce_bwd_db_f32: ldd < C");
+    GEOGCN_REQUIRE(C <= 16 * kWave, GEOGCN_E_ARG, "softmax_ce_bwd_db_f32: C=%d > %d", C, 16 * kWave);
+    hipStream_t st = (hipStream_t)stream;
+    { const int zrc = zero_fill_async(dlogits, (size_t)n * (size_t)ldd * sizeof(float), st); if (zrc) return zrc; }
+    const int cpad = (C + 3) / 4 * 4;
+    if (n_idx == 0) return zero_fill_async(db, (size_t)cpad * sizeof(float), st);
+    GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "softmax_ce_bwd_db_f32: null pointer");
+    GEOGCN_REQUIRE(ws && ws_bytes >= geogcn_softmax_ce_bwd_db_workspace_bytes(C), GEOGCN_E_ARG,
+                   "softmax_ce_bwd_db_f32: workspace too small");
+    hipLaunchKernelGGL(ce_bwd_db_kernel, dim3(kCeBlocks), dim3(TPB), 0, st, C, probs, ldp, idx, n_idx, y,
+                       inv_n, dlogits, ldd, (float*)ws, cpad);
+    GEOGCN_LAUNCH_CHECK("ce_bwd_db_kernel");
+    return colsum_final_launch(kCeBlocks, C, (const float*)ws, cpad, db, st);
 }
 
 int geogcn_adam_step_f32(int64_t n, float* p, float* g, float* m, float* v, const float* regmask, float lr,

@@ -513,11 +513,13 @@ class GraphConv():
         if self.regul_coef > 0:
             K.reg_penalty(self.store.p, self.store.regmask, self.regul_coef, self.regul_coef, out=sc[4:5])
         # backward: d(mean CE over train rows)/d logits, then the reverse sweep
+        fuse_db = self.l_out.b is not None and self.l_out.b.grad is not None and P.F <= 1024
         dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr),
-                                   out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)))
+                                   out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)),
+                                   **({'db': self.l_out.b.grad} if fuse_db else {}))
         # dlogits is zero outside the training rows: A^T . dlogits only needs the training COLUMNS of A^T
         kw_b = dict(kw, A_bwd_rows_hint=(self.l_out, self._train_columns_operand(g, A, train_indices)))
-        L.backward(self.l_out, L.PreAct(dlogits), tape, **kw_b)
+        L.backward(self.l_out, L.PreAct(dlogits, bias_done=fuse_db), tape, **kw_b)
         if self._dist(comm):
             comm.all_reduce_sum_(self.store.g)
             comm.all_reduce_sum_(sc[0:4])

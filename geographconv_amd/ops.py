@@ -434,10 +434,18 @@ def ce_metrics(P: DMat, idx: torch.Tensor, y: torch.Tensor, argmax: torch.Tensor
     return out2
 
 
-def softmax_ce_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, out: DMat = None, inv_n=None):
+def softmax_ce_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, out: DMat = None, inv_n=None, db: torch.Tensor = None):
+    """dlogits of the mean cross-entropy over the indexed rows; with `db` also its column sums (bias gradient)."""
     out = P.like() if out is None else out
     if inv_n is None:
         inv_n = 1.0 / max(1, idx.numel())
+    if db is not None:
+        lib = _ffi.lib()
+        w = _ws_for(P.device).get(lib.geogcn_softmax_ce_bwd_db_workspace_bytes(P.F))
+        check(lib.geogcn_softmax_ce_bwd_db_f32(P.n, P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y), float(inv_n),
+                                               _p(out.t), out.ld, _p(db), _p(w), w.numel(), _stream()),
+              'softmax_ce_bwd_db_f32')
+        return out
     check(_ffi.lib().geogcn_softmax_ce_bwd_f32(P.n, P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y), float(inv_n),
                                                _p(out.t), out.ld, _stream()), 'softmax_ce_bwd_f32')
     return out

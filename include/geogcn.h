@@ -220,6 +220,12 @@ int geogcn_ce_metrics_f32(int32_t C, const float* probs, int64_t ldp, const int3
 int geogcn_softmax_ce_bwd_f32(int64_t n, int32_t C, const float* probs, int64_t ldp,
                               const int32_t* idx, int64_t n_idx, const int32_t* y, float inv_n,
                               float* dlogits, int64_t ldd, void* stream);
+/* the same plus db[C] = column sums of dlogits (the output layer's bias gradient, gcnmodel.py:155-157 autodiff)
+ * computed from the indexed rows while they are scattered -- no pass over the N x C matrix.  C <= 1024.     */
+size_t geogcn_softmax_ce_bwd_db_workspace_bytes(int32_t C);
+int geogcn_softmax_ce_bwd_db_f32(int64_t n, int32_t C, const float* probs, int64_t ldp, const int32_t* idx,
+                                 int64_t n_idx, const int32_t* y, float inv_n, float* dlogits, int64_t ldd,
+                                 float* db, void* ws, size_t ws_bytes, void* stream);
 /* out[j, :] = X[idx[j], :]   AdvancedSubtensor1 (gcnmodel.py:376,378,393); dense out (pitch F)  */
 int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t* idx, int64_t n_idx,
                            float* out, int64_t ldo, void* stream);

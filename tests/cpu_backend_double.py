@@ -166,7 +166,7 @@ def ce_metrics(P, idx, y, argmax=None, out2=None):
     return out2
 
 
-def softmax_ce_bwd(P, idx, y, out=None, inv_n=None):
+def softmax_ce_bwd(P, idx, y, out=None, inv_n=None, db=None):
     out = DMat(P.n, P.F, P.device) if out is None else out
     out.t.zero_()
     i, yy = idx.numpy(), y.numpy()
@@ -175,6 +175,8 @@ def softmax_ce_bwd(P, idx, y, out=None, inv_n=None):
     d[i] = _v(P)[i]
     d[i, yy] -= 1
     d[i] *= np.float32(inv_n)
+    if db is not None:
+        db.numpy()[:P.F] = d.sum(axis=0)
     return out
 
 

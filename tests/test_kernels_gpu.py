@@ -492,6 +492,29 @@ def test_softmax_ce_head(dev, n, Cc):
     assert np.all(D.numpy()[untouched] == 0)
 
 
+@pytest.mark.parametrize("n,Cc", [(3000, 256), (500, 129), (40, 930)])
+def test_softmax_ce_bwd_with_bias_gradient(dev, n, Cc):
+    """geogcn_softmax_ce_bwd_db_f32: the same dlogits as geogcn_softmax_ce_bwd_f32 plus their column sums (the
+    output layer's bias gradient) without a pass over the N x C matrix; deterministic."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(Cc)
+    P = ops.softmax_rows(ops.DMat.from_numpy(_rand((n, Cc), 1), dev))
+    idx = torch.from_numpy(rng.permutation(n)[:n * 2 // 3].astype(np.int32)).to(dev)
+    y = torch.from_numpy(rng.randint(0, Cc, idx.numel()).astype(np.int32)).to(dev)
+    ref = ops.softmax_ce_bwd(P, idx, y, inv_n=1.0 / idx.numel())
+    db_ref = ref.numpy().astype(np.float64).sum(0)
+    db = torch.full((ops.pad4(Cc),), 7.0, dtype=torch.float32, device=dev)
+    got = ops.softmax_ce_bwd(P, idx, y, inv_n=1.0 / idx.numel(), db=db)
+    assert torch.equal(got.t, ref.t)
+    assert np.all(np.abs(db[:Cc].cpu().numpy() - db_ref) <= 2e-6 * np.abs(ref.numpy()).sum(0) + 1e-8)
+    db2 = torch.zeros_like(db)
+    ops.softmax_ce_bwd(P, idx, y, inv_n=1.0 / idx.numel(), db=db2)
+    assert torch.equal(db[:Cc], db2[:Cc])
+    empty = torch.zeros(0, dtype=torch.int32, device=dev)
+    ops.softmax_ce_bwd(P, empty, empty, inv_n=1.0, db=db2)
+    assert torch.all(db2[:Cc] == 0)
+
+
 def test_adam_matches_lasagne_formula(dev):
     from geographconv_amd import ops
     n = 100003
