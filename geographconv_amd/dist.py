@@ -84,7 +84,7 @@ class Comm:
 
     def graph_operand(self, A_host, hub_row_bytes=None):
         K = backend.active()
-        return K.SparseOperand.from_scipy(A_host, self.device, hub_row_bytes=hub_row_bytes)
+        return K.SparseOperand.from_scipy(A_host, self.device, dense_head=False, hub_row_bytes=hub_row_bytes)
 
     def matmul_target(self, F, tag=None):
         """Where the GEMM that produces the SpMM's dense operand should write (n_local x F)."""

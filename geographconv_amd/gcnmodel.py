@@ -183,7 +183,7 @@ class _ConvolutionCore(L.Layer):
     def backward(self, grad, tape, into, **kwargs):
         K = backend.active()
         g = grad if self.nonlinearity.act == 0 else K.act_bwd(grad, tape[self]['y'], self.nonlinearity.act)
-        dx = K.spmm(self.A.bwd, g)
+        dx = K.spmm_t(self.A, g) if getattr(self.A, 'head_dense', None) is not None else K.spmm(self.A.bwd, g)
         if into[0] is not None:
             K.add_inplace(dx, into[0])
             dx = into[0]
@@ -421,7 +421,9 @@ class GraphConv():
             dA = comm.graph_operand(A, hub_row_bytes=self.hub_row_bytes)
             dX = K.SparseOperand.from_scipy(part.local_rows(sps.csr_matrix(X)), self.device)
         else:
-            dA = K.SparseOperand.from_scipy(A, self.device, hub_row_bytes=self.hub_row_bytes)
+            # (dense_head=False: the dense-panel split of the transpose is for X; the graph convolution multiplies by
+            #  A^T as one CSR -- it only exists when A is not symmetric)
+            dA = K.SparseOperand.from_scipy(A, self.device, dense_head=False, hub_row_bytes=self.hub_row_bytes)
             dX = K.SparseOperand.from_scipy(X, self.device)
         hit = {'X_ref': X, 'A_ref': A, 'X': dX, 'A': dA, 'N': N, 'comm': comm}
         self._graph_cache = {key: hit}          # one graph resident at a time

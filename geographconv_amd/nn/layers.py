@@ -384,6 +384,9 @@ class DenseLayer(Layer):
         comm = kwargs.get('comm')
         if A is not None and comm is not None:
             A_bwd = A.bwd
+            if getattr(A, 'head_dense', None) is not None:
+                raise ValueError("a graph operand with a split transpose (dense head panel) cannot be exchanged: build "
+                                 "it with SparseOperand.from_scipy(..., dense_head=False)")
             hint = kwargs.get('A_bwd_rows_hint')
             if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
                 A_bwd = hint[1]
@@ -428,7 +431,10 @@ class DenseLayer(Layer):
             hint = kwargs.get('A_bwd_rows_hint')
             if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
                 A_bwd = hint[1]
-            dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
+            if A_bwd is A.bwd and getattr(A, 'head_dense', None) is not None:
+                dZ = K.spmm_t(A, dS)          # an operand whose transpose is split (dense head panel + CSR tail)
+            else:
+                dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
         else:
             dZ = dS
         return self._backward_post(x, dZ, into, need_input_grad, kwargs)

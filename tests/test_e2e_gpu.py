@@ -348,3 +348,58 @@ def test_stream_overlap_path_equals_default(cmu):
         assert a[1] == b[1] and a[3] == b[3]
     assert np.abs(P0 - P1).max() <= 2e-6
     assert np.array_equal(pr0, pr1) and np.abs(pb0 - pb1).max() <= 2e-6
+
+
+def test_asymmetric_adjacency_uses_explicit_transpose():
+    """The reference's A_hat is symmetric (unit weights), and then one CSR serves A.Z and A^T.dS.  That is checked at
+    upload, not assumed: a row-normalised D^-1 (A + I) is NOT symmetric, the backward must multiply by the explicit
+    transpose (also in the training-columns shortcut of the output layer) -- gradients against the oracle."""
+    import scipy.sparse as sps
+    import torch
+    from geographconv_amd import ops
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    A0, X, Y = synth.small_graph(600, 9.0, 400, 20, 7, seed=5, hub=True, empty_rows=2)
+    B = sps.csr_matrix((A0 != 0).astype(np.float64))
+    d = np.asarray(B.sum(1)).ravel()
+    A = sps.csr_matrix(sps.diags(1.0 / d) @ B, dtype=np.float32)        # random-walk normalisation: rows sum to 1
+    A.sort_indices()
+    assert abs(A - A.T).max() > 1e-3
+    op = ops.SparseOperand.from_scipy(A, torch.device('cuda:0'))
+    assert not op.symmetric and op.bwd is not op.fwd
+    hid = [32, 32]
+    params = O.random_params(X.shape[1], hid, 7, True, seed=11)
+    idx = np.random.RandomState(1).permutation(600)
+    tr, dev = idx[:360].astype(np.int32), idx[360:480].astype(np.int32)
+    clf = GraphConv(X.shape[1], 7, hid, 1e-5, 0.0, highway=True)
+    clf.build_model(A, seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    out = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    st = O.AdamState(params)
+    new, ref, grads = O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.0, None, 1e-5)
+    assert abs(out[0] - ref[0]) <= 1e-5 * abs(ref[0]) and out[1] == ref[1]
+    assert np.abs(np.asarray(out[4]) - ref[4]).max() <= PROB_ATOL
+    for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+        assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max() + 1e-9, i
+    # an operand built with the default dense-head split of its transpose (what SparseOperand.from_scipy gives a
+    # non-symmetric matrix with hub columns) still backpropagates correctly through a convolution layer
+    from geographconv_amd import gcnmodel as M
+    from geographconv_amd.nn import nonlinearities as NL
+    assert op.head_dense is not None
+    d_in = L.InputLayer((None, 32))
+    Wz = (np.random.RandomState(4).randn(32, 16) * 0.3).astype(np.float32)
+    lz = M.ConvolutionDenseLayer_zero(d_in, A=op, num_units=16, W=Wz, b=None, nonlinearity=NL.tanh)
+    L.ParamStore(L.get_all_params(lz), torch.device('cuda:0'))
+    Hn = np.random.RandomState(5).randn(600, 32).astype(np.float32)
+    Gn = np.random.RandomState(6).randn(600, 16).astype(np.float32)
+    tape = {}
+    yz = L.get_output(lz, {d_in: ops.DMat.from_numpy(Hn, torch.device('cuda:0'))}, tape=tape).numpy()
+    assert np.abs(yz - np.tanh(O.spmm(A, Hn @ Wz))).max() < 2e-5
+    L.backward(lz, ops.DMat.from_numpy(Gn, torch.device('cuda:0')), tape)
+    dWz = Hn.T @ O.spmm_t(A, Gn * (1 - yz * yz))
+    pz = L.get_all_params(lz)[0]
+    assert np.abs(pz._store.read_grad(pz) - dWz).max() <= 2e-4 * np.abs(dWz).max()
+    # with the transpose swapped for A itself the gradients are visibly different (the test can fail)
+    wrong = O.backward(params, O.forward(params, X, A, hid, True, 0.0, None, deterministic=False), X, sps.csr_matrix(A.T), tr,
+                       Y[tr], hid, True, 1e-5)
+    assert max(np.abs(w - r).max() / (np.abs(r).max() + 1e-12) for w, r in zip(wrong, grads)) > 1e-2
