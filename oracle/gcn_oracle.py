@@ -185,10 +185,13 @@ def backward(params, cache, X, A, train_idx, y_train, hid, highway=True, reg=0.0
     P = cache['P']
     N, C = P.shape
     n_tr = len(train_idx)
+    # gradient of mean CE over output[train_idx]: Theano's AdvancedIncSubtensor1 ACCUMULATES rows that are indexed
+    # more than once (the reference's index vectors are unique, gcnmain.py:207; duplicates are still well defined)
+    g_rows = P[train_idx].copy()
+    g_rows[np.arange(n_tr), y_train] -= dt.type(1.0)
+    g_rows /= dt.type(max(1, n_tr))
     dSo = np.zeros((N, C), dtype=dt)
-    dSo[train_idx] = P[train_idx]
-    dSo[train_idx, y_train] -= dt.type(1.0)
-    dSo[train_idx] /= dt.type(n_tr)
+    np.add.at(dSo, np.asarray(train_idx), g_rows)
     dbo = dSo.sum(axis=0)
     dZo = spmm_t(A, dSo)
     Hl = cache['Hlast']

@@ -119,3 +119,68 @@ def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
                 assert np.allclose(q_, z['step%d_param%d' % (step, i)], atol=2e-5), (name, step, i)
         assert np.array_equal(pred, z['val_pred'])
         assert np.allclose(probs, z['val_probs'], rtol=1e-3, atol=5e-5)
+
+
+def _asym_case():
+    """Row-normalised D^-1 (A + I): NOT symmetric, so every rank must multiply by its block of the explicit transpose."""
+    import scipy.sparse as sps
+    from geographconv_amd import synth
+    A0, X, Y = synth.small_graph(157, 7.0, 90, 9, 5, seed=4, hub=True, empty_rows=2)
+    B = sps.csr_matrix((A0 != 0).astype(np.float64))
+    A = sps.csr_matrix(sps.diags(1.0 / np.asarray(B.sum(1)).ravel()) @ B, dtype=np.float32)
+    A.sort_indices()
+    rng = np.random.RandomState(3)
+    idx = rng.permutation(157)
+    tr, dev, te = idx[:90].astype(np.int32), idx[90:120].astype(np.int32), idx[120:].astype(np.int32)
+    cfg = dict(N=157, V=90, C=5, hid=[24, 24], highway=True, p=0.0, reg=1e-5)
+    return A, X, Y, tr, dev, te, cfg
+
+
+def _asym_worker(rank, world, port, q, exchange):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from geographconv_amd import backend
+        from geographconv_amd.dist import TorchDistComm
+        from tests import cpu_backend_double
+        from tests.helpers import make_clf
+        from oracle import gcn_oracle as O
+        backend.use(cpu_backend_double)
+        A, X, Y, tr, dev, te, cfg = _asym_case()
+        params = O.random_params(cfg['V'], cfg['hid'], cfg['C'], True, seed=9)
+        comm = TorchDistComm(cfg['N'], torch.device('cpu'), exchange=exchange)
+        clf = make_clf(cfg, params, device=torch.device('cpu'), comm=comm)
+        o = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+        res = ([float(v) for v in o[:4]], np.asarray(o[4]), clf.get_grads())     # (fetching P is a collective: all ranks)
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 2)])
+def test_multi_rank_asymmetric_adjacency(exchange, world):
+    import torch.multiprocessing as mp
+    from oracle import gcn_oracle as O
+    assert abs(_asym_case()[0] - _asym_case()[0].T).max() > 1e-3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_asym_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    sc, P, grads = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A, X, Y, tr, dev, te, cfg = _asym_case()
+    params = O.random_params(cfg['V'], cfg['hid'], cfg['C'], True, seed=9)
+    new, ref, rg = O.f_train(params, O.AdamState(params), X, Y[tr], Y[dev], A, tr, dev, cfg['hid'], True, 0.0, None, cfg['reg'])
+    assert np.allclose(sc, [ref[0], ref[1], ref[2], ref[3]], rtol=1e-5, atol=1e-6)
+    assert np.allclose(P, ref[4], rtol=1e-4, atol=2e-6)
+    for i, (g, r) in enumerate(zip(grads, rg)):
+        assert np.allclose(g, r, rtol=2e-4, atol=2e-7 + 1e-5 * np.abs(r).max()), i

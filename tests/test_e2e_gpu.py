@@ -403,3 +403,38 @@ def test_asymmetric_adjacency_uses_explicit_transpose():
     wrong = O.backward(params, O.forward(params, X, A, hid, True, 0.0, None, deterministic=False), X, sps.csr_matrix(A.T), tr,
                        Y[tr], hid, True, 1e-5)
     assert max(np.abs(w - r).max() / (np.abs(r).max() + 1e-12) for w, r in zip(wrong, grads)) > 1e-2
+
+
+def test_duplicate_and_empty_index_sets():
+    """Index vectors with repeated entries (Theano's AdvancedIncSubtensor1 accumulates them: mean over the LIST,
+    not over the set) and an empty dev set (the reference's mean over nothing is NaN; here the sums are 0 and the
+    step still runs)."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    A, X, Y = synth.small_graph(500, 8.0, 300, 15, 9, seed=2, hub=True, empty_rows=3)
+    hid = [40, 40]
+    params = O.random_params(X.shape[1], hid, 9, True, seed=5)
+    rng = np.random.RandomState(0)
+    tr = rng.randint(0, 500, size=700).astype(np.int32)              # with replacement: many repeats
+    assert len(np.unique(tr)) < len(tr)
+    dev = rng.randint(0, 500, size=50).astype(np.int32)
+    clf = GraphConv(X.shape[1], 9, hid, 0.0, 0.0, highway=True)
+    clf.build_model(A, seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    out = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    new, ref, grads = O.f_train(params, O.AdamState(params), X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.0, None, 0.0)
+    assert abs(out[0] - ref[0]) <= 2e-6 * abs(ref[0]) + 1e-6 and abs(out[2] - ref[2]) <= 2e-6 * abs(ref[2]) + 1e-6
+    assert out[1] == ref[1] and out[3] == ref[3]
+    for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+        assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max() + 1e-9, i
+    # empty dev set
+    clf2 = GraphConv(X.shape[1], 9, hid, 0.0, 0.0, highway=True)
+    clf2.build_model(A, seed=77)
+    L.set_all_param_values(clf2.l_out, params)
+    empty = np.zeros(0, dtype=np.int32)
+    out2 = clf2.f_train(X, Y[tr], Y[empty], A, tr, empty)
+    assert abs(out2[0] - ref[0]) <= 2e-6 * abs(ref[0]) + 1e-6 and out2[2] == 0.0 and out2[3] == 0.0
+    for g, r in zip(clf2.get_grads(), grads):
+        assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max() + 1e-9
+    pred, probs = clf2.predict(X, A, empty)
+    assert pred.shape == (0,) and probs.shape == (0, 9)
