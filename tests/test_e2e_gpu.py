@@ -438,3 +438,67 @@ def test_duplicate_and_empty_index_sets():
         assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max() + 1e-9
     pred, probs = clf2.predict(X, A, empty)
     assert pred.shape == (0,) and probs.shape == (0, 9)
+
+
+@pytest.mark.parametrize("N,V,C,hid,highway", [(1, 3, 2, [1], True), (2, 5, 2, [3, 3], True), (3, 4, 3, [5], False),
+                                                 (17, 9, 4, [8, 8, 8], True), (33, 40, 6, [7, 7], True)])
+def test_degenerate_shapes_train_and_predict(N, V, C, hid, highway):
+    """One node, one hidden unit, a single layer, widths below every vector width: the step and predict still match
+    the oracle (fp32), and the bf16 configuration runs on them."""
+    import scipy.sparse as sps
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    rng = np.random.RandomState(N * 7 + V)
+    B = sps.random(N, N, density=min(1.0, 3.0 / N), random_state=rng, format='csr')
+    B = sps.csr_matrix(((B + B.T) != 0).astype(np.float64))
+    A = synth.normalize_adjacency(B)
+    X = sps.random(N, V, density=0.6, random_state=rng, format='csr', dtype=np.float32)
+    X.sort_indices()
+    Y = rng.randint(0, C, N).astype(np.int32)
+    tr = np.arange(N, dtype=np.int32)[: max(1, N * 2 // 3)]
+    dev = np.arange(N, dtype=np.int32)[max(1, N * 2 // 3):]
+    params = O.random_params(V, hid, C, highway, seed=3)
+    clf = GraphConv(V, C, hid, 1e-4, 0.0, highway=highway)
+    clf.build_model(A, seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    out = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    new, ref, grads = O.f_train(params, O.AdamState(params), X, Y[tr], Y[dev], A, tr, dev, hid, highway, 0.0, None, 1e-4)
+    assert abs(out[0] - ref[0]) <= 1e-5 * abs(ref[0]) + 1e-6
+    assert np.abs(np.asarray(out[4]) - ref[4]).max() <= 5e-6
+    for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+        assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-8, i
+    pred, probs = clf.predict(X, A, np.arange(N, dtype=np.int32))
+    assert pred.shape == (N,) and probs.shape == (N, C) and np.all(np.isfinite(probs))
+    clf16 = GraphConv(V, C, hid, 0.0, 0.5, highway=highway, gemm_precision='bf16')
+    clf16.build_model(A, seed=77)
+    L.set_all_param_values(clf16.l_out, params)
+    o16 = clf16.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    assert np.isfinite(o16[0]) and np.all(np.isfinite(np.asarray(o16[4])))
+
+
+def test_world_configuration_widths():
+    """The reference's WORLD run uses hid 900 and 930 classes (README.md:180): widest supported SpMM operand
+    (K4 = 15), 6 x 160 GEMM tiles, the 16-register softmax / CE kernels -- against the oracle on a small graph."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    A, X, Y = synth.small_graph(700, 8.0, 500, 25, 930, seed=8, hub=True, empty_rows=1)
+    hid = [900, 900]
+    params = O.random_params(X.shape[1], hid, 930, True, seed=2)
+    idx = np.random.RandomState(0).permutation(700)
+    tr, dev = idx[:420].astype(np.int32), idx[420:560].astype(np.int32)
+    clf = GraphConv(X.shape[1], 930, hid, 0.0, 0.0, highway=True)
+    clf.build_model(A, seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    out = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    new, ref, grads = O.f_train(params, O.AdamState(params), X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.0, None, 0.0)
+    assert abs(out[0] - ref[0]) <= 1e-5 * abs(ref[0]) and abs(out[2] - ref[2]) <= 1e-5 * abs(ref[2])
+    assert np.abs(np.asarray(out[4]) - ref[4]).max() <= PROB_ATOL
+    for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+        assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-9, i
+    for mode in ('bf16', 'bf16x3'):
+        c2 = GraphConv(X.shape[1], 930, hid, 0.0, 0.0, highway=True, gemm_precision=mode)
+        c2.build_model(A, seed=77)
+        L.set_all_param_values(c2.l_out, params)
+        o2 = c2.f_train(X, Y[tr], Y[dev], A, tr, dev)
+        tol = 2e-2 if mode == 'bf16' else 1e-5
+        assert abs(o2[0] - ref[0]) <= tol * abs(ref[0]), (mode, o2[0], ref[0])
