@@ -566,3 +566,59 @@ def test_cmu_shape_spmm_full_size(dev):
     assert np.all(np.abs(got - ref64) <= 3e-6 * mag + 1e-5), np.abs(got - ref64).max()
     got2 = ops.spmm_t(sx, ops.DMat.from_numpy(H, dev)).numpy()
     assert np.array_equal(got, got2)                     # deterministic
+
+
+def test_randomised_shape_sweep(dev):
+    """Seeded sweep over awkward shapes (every K4 / lane-group / tile / tail path of the SpMM and GEMM kernels):
+    fp32 against fp64 references with the accumulation-error envelope, bf16 modes against their own envelopes."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(20260928)
+    # ---- SpMM (fp32 and bf16 operand, bias + tanh epilogue on half of the cases)
+    for case in range(36):
+        n_rows, n_cols = int(rng.randint(1, 400)), int(rng.randint(1, 400))
+        F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 320, 321, 511,
+                            600, 640, 641, 900, 1023, 1024]))
+        dens = float(rng.choice([0.02, 0.2, 0.9]))
+        A = sps.random(n_rows, n_cols, density=dens, random_state=rng, format='csr', dtype=np.float32)
+        if n_rows > 3:                                          # one long row (chunked) and one empty row
+            A = A.tolil()
+            A[0, :] = rng.randn(n_cols).astype(np.float32)
+            A[n_rows - 1, :] = 0
+            A = sps.csr_matrix(A, dtype=np.float32)
+        A.eliminate_zeros()
+        A.sort_indices()
+        B = rng.randn(n_cols, F).astype(np.float32)
+        use_epi = case % 2 == 0
+        bias = rng.randn(F).astype(np.float32) if use_epi else None
+        dA = ops.CSR(A, dev)
+        dB = ops.DMat.from_numpy(B, dev)
+        db = torch.from_numpy(np.pad(bias, (0, ops.pad4(F) - F))).to(dev) if use_epi else None
+        for bf in (False, True):
+            Bop = ops.cast_bf16(dB) if bf else dB
+            Bref = (torch.from_numpy(B).to(torch.bfloat16).float().numpy() if bf else B).astype(np.float64)
+            ref = np.asarray(A.astype(np.float64) @ Bref)
+            mag = np.asarray(abs(A).astype(np.float64) @ np.abs(Bref))
+            if use_epi:
+                ref, mag = np.tanh(ref + bias), mag + np.abs(bias)
+            out = ops.spmm(dA, Bop, bias=db, act=ops.ACT_TANH if use_epi else ops.ACT_NONE)
+            err = np.abs(out.numpy() - ref)
+            assert np.all(err <= 2e-6 * mag + 2e-6), (case, n_rows, n_cols, F, bf, err.max())
+            assert torch.all(out.t[:, F:] == 0)
+    # ---- GEMM
+    for case in range(36):
+        M, N, K = int(rng.randint(1, 1500)), int(rng.randint(1, 700)), int(rng.randint(1, 700))
+        if case % 6 == 0:
+            M, N, K = int(rng.choice([1, 127, 128, 129, 4096])), int(rng.choice([1, 159, 160, 161, 320, 321])), int(rng.choice([1, 31, 32, 33, 300]))
+        A = rng.randn(M, K).astype(np.float32)
+        B = rng.randn(K, N).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        mag = np.abs(A).astype(np.float64) @ np.abs(B)
+        dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+        dBt = ops.DMat.from_numpy(np.ascontiguousarray(B.T), dev)
+        dAt = ops.DMat.from_numpy(np.ascontiguousarray(A.T), dev)
+        for prec, tol in (('f32', 2e-6), ('bf16x3', 2e-6), ('bf16', 2 ** -7)):
+            for name, got in (('nn', ops.gemm(dA, dB, precision=prec)), ('nt', ops.gemm(dA, dBt, transB=True, precision=prec)),
+                              ('tn', ops.gemm(dAt, dB, transA=True, precision=prec))):
+                err = np.abs(got.numpy() - ref)
+                assert np.all(err <= tol * mag + 2e-6), (case, M, N, K, prec, name, err.max())
+                assert torch.all(got.t[:, N:] == 0)
