@@ -502,3 +502,26 @@ def test_world_configuration_widths():
         o2 = c2.f_train(X, Y[tr], Y[dev], A, tr, dev)
         tol = 2e-2 if mode == 'bf16' else 1e-5
         assert abs(o2[0] - ref[0]) <= tol * abs(ref[0]), (mode, o2[0], ref[0])
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+def test_training_step_is_bitwise_reproducible(cmu, prec):
+    """No float atomics on a reduction path, fixed-order partial sums everywhere (split-K slabs, long-row chunks,
+    column sums): two runs of three training steps give identical losses, gradients and parameters, bit for bit."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    runs = []
+    for rep in range(2):
+        clf = GraphConv(c['X'].shape[1], c['C'], c['hid'], 1e-6, 0.5, highway=True, gemm_precision=prec)
+        clf.build_model(c['A'], seed=77)
+        L.set_all_param_values(clf.l_out, c['params'])
+        hist = []
+        for step in range(3):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+        runs.append((hist, [g.copy() for g in clf.get_grads()], L.get_all_param_values(clf.l_out), np.asarray(out[4]).copy()))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1] + runs[0][2], runs[1][1] + runs[1][2]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(runs[0][3], runs[1][3])
