@@ -56,6 +56,8 @@ SIGNATURES = {
     'geogcn_dropout_mask_philox': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_u64, c_ptr, c_ptr]),
     'geogcn_dropout_mask_philox_ctr': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'geogcn_counter_add_i64': (c_i32, [c_ptr, c_i64, c_ptr]),
+    'geogcn_dropout_csr_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_f32, c_u64, c_u64, c_ptr]),
+    'geogcn_dropout_panel_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_u64, c_u64, c_ptr, c_ptr]),
     'geogcn_dropout_apply_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr]),
     'geogcn_softmax_rows_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     'geogcn_ce_metrics_workspace_bytes': (c_sz, [c_i64]),

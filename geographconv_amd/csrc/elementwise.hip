@@ -292,6 +292,45 @@ __global__ __launch_bounds__(TPB) void dropout_mask_kernel(int64_t total, float 
     }
 }
 
+// ---- dropout on the VALUES of a sparse matrix (reference gcnmodel.py:44-70, SparseInputDropoutLayer) -------------
+// Element (i, j) of the logical matrix is kept iff the Philox draw keyed by its POSITION e = i * n_cols + j is below
+// the keep probability -- the same bit whichever device layout holds the element (CSR of X, CSR of the tail of X^T,
+// dense head panel), so the three layouts stay one matrix.
+__device__ __forceinline__ float philox_uniform_at(uint64_t seed, uint64_t call_quads, int64_t e) {
+    const uint64_t ctr = (uint64_t)(e >> 2) + call_quads;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    return (float)(c[e & 3] >> 8) * (1.0f / 16777216.0f);
+}
+__global__ __launch_bounds__(TPB) void dropout_csr_kernel(int64_t n_rows, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ colidx, const float* __restrict__ vin,
+                                                          float* __restrict__ vout, int64_t n_cols_logical, int transposed,
+                                                          float keep, float scale, uint64_t seed, uint64_t call_quads) {
+    const int64_t row = (int64_t)blockIdx.x * (TPB / kWave) + threadIdx.x / kWave;
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x % kWave;
+    for (int j = rowptr[row] + lane; j < rowptr[row + 1]; j += kWave) {
+        const int64_t col = colidx[j];
+        const int64_t e = transposed ? col * n_cols_logical + row : row * n_cols_logical + col;
+        vout[j] = philox_uniform_at(seed, call_quads, e) < keep ? vin[j] * scale : 0.f;
+    }
+}
+__global__ __launch_bounds__(TPB) void dropout_panel_kernel(int64_t n, int K, const float* __restrict__ Pin, int64_t ld,
+                                                            const int* __restrict__ head_idx, int64_t n_cols_logical,
+                                                            float keep, float scale, uint64_t seed, uint64_t call_quads,
+                                                            float* __restrict__ Pout) {
+    const int64_t total = n * K;
+    for (int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TPB) {
+        const int64_t i = t / K;
+        const int k = (int)(t - i * K);
+        const int64_t e = i * n_cols_logical + head_idx[k];
+        const float v = Pin[i * ld + k];
+        Pout[i * ld + k] = (v != 0.f && philox_uniform_at(seed, call_quads, e) < keep) ? v * scale : 0.f;
+    }
+}
+
 __global__ void counter_add_kernel(int64_t* c, int64_t delta) { *c += delta; }
 
 // ---- column sums: pass 1 = per row-chunk partials, pass 2 = partials added in chunk order ----------
@@ -720,6 +759,35 @@ int geogcn_act_bwd_colsum_f32(int64_t n, int32_t F, const float* G, const float*
     GEOGCN_LAUNCH_CHECK("act_bwd_colsum_kernel");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, (const float*)ws, ld, db);
     GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
+int geogcn_dropout_csr_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* colidx, const float* val_in, float* val_out,
+                           int64_t n_rows_logical, int64_t n_cols_logical, int32_t transposed, float p_drop, uint64_t seed,
+                           uint64_t call, void* stream) {
+    GEOGCN_REQUIRE(n_rows >= 0 && n_rows_logical >= 0 && n_cols_logical >= 0, GEOGCN_E_SIZE, "dropout_csr_f32: negative size");
+    GEOGCN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GEOGCN_E_ARG, "dropout_csr_f32: p=%f outside [0,1)", p_drop);
+    if (n_rows == 0) return 0;
+    GEOGCN_REQUIRE(rowptr && colidx && val_in && val_out, GEOGCN_E_NULL, "dropout_csr_f32: null pointer");
+    const uint64_t quads = (uint64_t)((n_rows_logical * n_cols_logical + 3) / 4);
+    hipLaunchKernelGGL(dropout_csr_kernel, dim3((unsigned)cdiv(n_rows, TPB / kWave)), dim3(TPB), 0, (hipStream_t)stream, n_rows,
+                       rowptr, colidx, val_in, val_out, n_cols_logical, transposed, 1.0f - p_drop, 1.0f / (1.0f - p_drop), seed,
+                       call * quads);
+    GEOGCN_LAUNCH_CHECK("dropout_csr_kernel");
+    return 0;
+}
+
+int geogcn_dropout_panel_f32(int64_t n, int32_t K, const float* panel_in, int64_t ld, const int32_t* head_idx,
+                             int64_t n_cols_logical, float p_drop, uint64_t seed, uint64_t call, float* panel_out,
+                             void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && K >= 0 && n_cols_logical >= 0, GEOGCN_E_SIZE, "dropout_panel_f32: negative size");
+    GEOGCN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GEOGCN_E_ARG, "dropout_panel_f32: p=%f outside [0,1)", p_drop);
+    if (n == 0 || K == 0) return 0;
+    GEOGCN_REQUIRE(panel_in && panel_out && head_idx && ld >= K, GEOGCN_E_NULL, "dropout_panel_f32: null pointer / ld < K");
+    const uint64_t quads = (uint64_t)((n * n_cols_logical + 3) / 4);
+    hipLaunchKernelGGL(dropout_panel_kernel, dim3(stream_grid(n * K)), dim3(TPB), 0, (hipStream_t)stream, n, K, panel_in, ld,
+                       head_idx, n_cols_logical, 1.0f - p_drop, 1.0f / (1.0f - p_drop), seed, call * quads, panel_out);
+    GEOGCN_LAUNCH_CHECK("dropout_panel_kernel");
     return 0;
 }
 

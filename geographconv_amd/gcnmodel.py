@@ -88,6 +88,27 @@ class _TargetRows:
         return super().backward(grad, tape, into, **kwargs)
 
 
+class SparseInputDropoutLayer(DropoutLayer):
+    """Dropout on a SPARSE input (reference gcnmodel.py:44-70): stored values are dropped with probability p and the
+    survivors scaled by 1/(1-p); identity when deterministic or p == 0; dense input is refused like the reference
+    does.  The input of the network carries no gradient, so there is no backward."""
+
+    def forward(self, input, tape, deterministic=False, **kwargs):
+        if not _is_sparse_operand(input):
+            raise ValueError("Input for this layer must be sparse")
+        if deterministic or self.p == 0:
+            return input
+        if not self.rescale:
+            raise NotImplementedError("rescale=False is not used by the reference path")
+        K = backend.active()
+        y = K.sparse_dropout(input, self.p, self._seed, self._calls)
+        self._calls += 1
+        return y
+
+    def backward(self, grad, tape, into, **kwargs):
+        return [None]
+
+
 class ConvolutionDenseLayer2(_TargetRows, DenseLayer):
     """act(A . (H . W) + b), A passed through get_output (reference gcnmodel.py:114-136); with
     use_target_indices only the rows in the `target_indices` kwarg are returned (never enabled by GraphConv)."""

@@ -560,6 +560,45 @@ class SparseOperand:
         return SparseOperand(fwd, bwd, False, head_idx, head_dense)
 
 
+class _CSRValues:
+    """A CSR with the structure (and split plan, workspace) of `base` and its own values -- what value dropout on a
+    sparse input produces every step.  Keeps `base` alive; does not own the plan."""
+
+    def __init__(self, base: CSR, val: torch.Tensor):
+        self._base = base
+        self.val = val
+        for k in ('shape', 'nnz', 'rowptr', 'colidx', 'rowptr_host', 'device', '_plan', '_ws', 'n_long_rows', 'n_chunks',
+                  'n_hubs'):
+            setattr(self, k, getattr(base, k))
+
+
+def sparse_dropout(x: SparseOperand, p, seed, call):
+    """x with every stored value dropped with probability p and the rest scaled by 1/(1-p) (reference
+    gcnmodel.py:44-70).  The keep decision is keyed by the element's position, so the forward CSR, the CSR of the
+    transposed tail and the dense head panel of the result are still one matrix."""
+    lib = _ffi.lib()
+    n, V = x.shape
+    def csr(c, transposed):
+        out = torch.empty_like(c.val)
+        check(lib.geogcn_dropout_csr_f32(c.shape[0], _p(c.rowptr), _p(c.colidx), _p(c.val), _p(out), n, V, int(transposed),
+                                         float(p), int(seed), int(call), _stream()), 'dropout_csr_f32')
+        return _CSRValues(c, out)
+    fwd = csr(x.fwd, False)
+    if x.bwd is None:
+        return SparseOperand(fwd, None, False)
+    if x.symmetric or x.bwd is x.fwd:
+        # a symmetric matrix stops being symmetric under an element-wise mask: its transpose needs its own values
+        bwd = csr(x.fwd, True)
+        return SparseOperand(fwd, bwd, False)
+    bwd = csr(x.bwd, True)
+    head = None
+    if x.head_dense is not None:
+        head = DMat(x.head_dense.n, x.head_dense.F, x.head_dense.device, ld=x.head_dense.ld)
+        check(lib.geogcn_dropout_panel_f32(head.n, head.F, _p(x.head_dense.t), head.ld, _p(x.head_idx), V, float(p), int(seed),
+                                           int(call), _p(head.t), _stream()), 'dropout_panel_f32')
+    return SparseOperand(fwd, bwd, False, x.head_idx, head)
+
+
 def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff)."""
     out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)

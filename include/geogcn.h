@@ -198,6 +198,17 @@ int geogcn_dropout_mask_philox(int64_t n, int32_t F, float p_drop, uint64_t seed
 int geogcn_dropout_mask_philox_ctr(int64_t n, int32_t F, float p_drop, uint64_t seed, const int64_t* calls_dev,
                                    int64_t per_call_elems, int64_t base_elems, uint8_t* keep_mask, void* stream);
 int geogcn_counter_add_i64(int64_t* counter_dev, int64_t delta, void* stream);
+/* Dropout on the VALUES of a sparse matrix (SparseInputDropoutLayer, gcnmodel.py:44-70): element (i, j) of the
+ * logical n_rows_logical x n_cols_logical matrix is kept (and scaled by 1/(1-p)) iff the Philox draw keyed by its
+ * position i * n_cols_logical + j (stream `call`) is below 1-p -- the same decision in every device layout of the
+ * matrix: its CSR (transposed = 0), the CSR of (a part of) its transpose (transposed = 1: row = j, colidx = i) and a
+ * dense panel of selected columns (head_idx[k] = j).                                                          */
+int geogcn_dropout_csr_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* colidx, const float* val_in,
+                           float* val_out, int64_t n_rows_logical, int64_t n_cols_logical, int32_t transposed,
+                           float p_drop, uint64_t seed, uint64_t call, void* stream);
+int geogcn_dropout_panel_f32(int64_t n, int32_t K, const float* panel_in, int64_t ld, const int32_t* head_idx,
+                             int64_t n_cols_logical, float p_drop, uint64_t seed, uint64_t call, float* panel_out,
+                             void* stream);
 /* Y = X * keep_mask / (1-p)  (forward; the backward is the same call on the gradient)          */
 int geogcn_dropout_apply_f32(int64_t n, int32_t F, const float* X, int64_t ld,
                              const uint8_t* keep_mask, float p_drop, float* Y, void* stream);

@@ -525,3 +525,58 @@ def test_training_step_is_bitwise_reproducible(cmu, prec):
     for a, b in zip(runs[0][1] + runs[0][2], runs[1][1] + runs[1][2]):
         assert np.array_equal(a, b)
     assert np.array_equal(runs[0][3], runs[1][3])
+
+
+def test_sparse_input_dropout_layer(cmu):
+    """SparseInputDropoutLayer (gcnmodel.py:44-70): values of the sparse input dropped with p and rescaled; the three
+    device layouts of the result (CSR, CSR of the transposed tail, dense head panel) stay ONE matrix, so the layer on
+    top trains with the consistent X^T; identity when deterministic; dense input refused."""
+    import scipy.sparse as sps
+    import torch
+    from geographconv_amd import gcnmodel as M, ops
+    from geographconv_amd.nn import layers as L, nonlinearities as NL
+    c = cmu
+    dev = torch.device('cuda:0')
+    X = sps.csr_matrix(c['X'], dtype=np.float32)
+    X.sort_indices()
+    op = ops.SparseOperand.from_scipy(X, dev)
+    assert op.head_dense is not None                     # the split-transpose layout is exercised
+    d0 = ops.sparse_dropout(op, 0.4, 1234, 0)
+    v = d0.fwd.val.cpu().numpy()
+    Xd = sps.csr_matrix((v, X.indices, X.indptr), shape=X.shape)
+    kept = v != 0
+    assert abs(kept.mean() - 0.6) < 0.01
+    assert np.allclose(v[kept], X.data[kept] / np.float32(0.6), rtol=1e-6)
+    rng = np.random.RandomState(0)
+    G = rng.randn(X.shape[0], 48).astype(np.float32)
+    W = rng.randn(X.shape[1], 48).astype(np.float32)
+    got_t = ops.spmm_t(d0, ops.DMat.from_numpy(G, dev)).numpy()
+    ref_t = np.asarray(Xd.T.astype(np.float64) @ G)
+    assert np.abs(got_t - ref_t).max() <= 2e-6 * np.asarray(abs(Xd).T @ np.abs(G)).max() + 1e-6      # same matrix, transposed
+    got_f = ops.spmm(d0.fwd, ops.DMat.from_numpy(W, dev)).numpy()
+    assert np.abs(got_f - np.asarray(Xd.astype(np.float64) @ W)).max() <= 1e-4
+    again = ops.sparse_dropout(op, 0.4, 1234, 0)
+    assert torch.equal(again.fwd.val, d0.fwd.val)                      # counter-based: same call, same mask
+    other = ops.sparse_dropout(op, 0.4, 1234, 1)
+    assert (other.fwd.val != d0.fwd.val).float().mean() > 0.3          # next call, next mask
+    # as a layer under SparseInputDenseLayer
+    l_in = L.InputLayer((None, X.shape[1]))
+    l_dr = M.SparseInputDropoutLayer(l_in, p=0.4)
+    Wn = (rng.randn(X.shape[1], 32) * 0.05).astype(np.float32)
+    l_h = M.SparseInputDenseLayer(l_dr, num_units=32, W=Wn, b=np.zeros(32, np.float32), nonlinearity=NL.tanh)
+    L.ParamStore(L.get_all_params(l_h), dev)
+    y_det = L.get_output(l_h, {l_in: op}, deterministic=True).numpy()
+    assert np.abs(y_det - np.tanh(np.asarray(X @ Wn))).max() < 2e-5
+    tape = {}
+    y = L.get_output(l_h, {l_in: op}, tape=tape, deterministic=False)
+    xd = tape[l_h]['x']
+    Xl = sps.csr_matrix((xd.fwd.val.cpu().numpy(), X.indices, X.indptr), shape=X.shape)
+    assert np.abs(y.numpy() - np.tanh(np.asarray(Xl @ Wn))).max() < 2e-5
+    Gy = rng.randn(X.shape[0], 32).astype(np.float32)
+    L.backward(l_h, ops.DMat.from_numpy(Gy, dev), tape)
+    dS = Gy * (1 - y.numpy() ** 2)
+    pW = L.get_all_params(l_h)[0]
+    dW_ref = np.asarray(Xl.T.astype(np.float64) @ dS)
+    assert np.abs(pW._store.read_grad(pW) - dW_ref).max() <= 2e-4 * np.abs(dW_ref).max()
+    with pytest.raises(ValueError):
+        L.get_output(l_h, {l_in: ops.DMat.from_numpy(G[:, :X.shape[1]] if G.shape[1] >= X.shape[1] else np.zeros((4, X.shape[1]), np.float32), dev)})
