@@ -538,6 +538,10 @@ int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float*
         return launch_gemm<BM_, BN_, AT, BT, 2, 4>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
     GEOGCN_T(128, 128)
     GEOGCN_T(128, 160)
+    if constexpr (!AT) {
+        GEOGCN_T(64, 128)           // few rows (CMU shape): twice the tiles, so that more than half the CUs get one
+        GEOGCN_T(64, 160)
+    }
     if constexpr (BT) {
         GEOGCN_T(96, 160)           // two k-contiguous images of 128+160 rows would not fit twice in 160 KB
     }
@@ -624,10 +628,13 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
     if (transA)
         return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
                                            ws_bytes, st);
+    // short operands: with 128-row tiles fewer tiles than CUs -> 64-row tiles (M = 9,475: 150 -> 298 tiles)
+    const bool few = cdiv(M, 128) * cdiv(N, bn) < kNumCU;
     if (transB)
-        return dispatch_tiles<false, true>((bn == 160) ? 96 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act,
-                                           accumulate, ws, ws_bytes, st);
-    return dispatch_tiles<false, false>(128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+        return dispatch_tiles<false, true>(few ? 64 : ((bn == 160) ? 96 : 128), bn, M, N, K, A, lda, B, ldb, C, ldc, bias,
+                                           act, accumulate, ws, ws_bytes, st);
+    return dispatch_tiles<false, false>(few ? 64 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
+                                        ws_bytes, st);
 }
 
 int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
