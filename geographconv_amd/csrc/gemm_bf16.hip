@@ -528,7 +528,8 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
     else
         hipLaunchKernelGGL((prep_b_planes_kernel<1>), dim3(pgrid), dim3(TPB), 0, st, B, ldb, (int)K, (int)N, Kp, transB, planes);
     GEOGCN_LAUNCH_CHECK("prep_b_planes_kernel");
-    const int bn = (cdiv(N, 160) * 160 < cdiv(N, 128) * 128) ? 160 : 128;
+    // (ties -> 160: fewer N tiles, and every N tile converts its A tile from fp32 again)
+    const int bn = (cdiv(N, 160) * 160 <= cdiv(N, 128) * 128) ? 160 : 128;
     Bf16Args a{M, N, K, A, lda, planes, Kp, C, ldc, bias, accumulate, (int)cdiv(M, 128), (int)cdiv(N, bn), c_bf16,
                c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3)};
     if (ns == 3) {      // 8 waves per block: half the accumulators / staging registers per lane
