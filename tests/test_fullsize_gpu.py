@@ -162,3 +162,32 @@ def test_forward_full_size_matches_oracle_argmax_exact(twus):
     clear = (top2[:, 1] - top2[:, 0]) > 2 * (tol + 3e-5 * top2[:, 1])
     assert clear.mean() > 0.99
     assert np.array_equal(pred[clear], ref.argmax(-1)[clear])
+
+
+def test_train_step_full_size_matches_oracle(twus):
+    """One complete f_train step (forward, backward, Adam) at the FULL TwitterUS shape against the oracle's step on the
+    same (A, X, Y), same parameters, same injected dropout mask: losses, hit counts, every gradient and the updated
+    parameters (~20 s of CPU for the oracle)."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    from oracle import gcn_oracle as O
+    t = twus
+    hid = [300, 300, 300]
+    N = t['A'].shape[0]
+    params = O.random_params(t['X'].shape[1], hid, t['C'], True, seed=7)
+    mask = (np.random.RandomState(3).rand(N, 300) < 0.5).astype(np.uint8)
+    clf = GraphConv(t['X'].shape[1], t['C'], hid, 0.0, 0.5, highway=True)
+    clf.build_model(t['A'], seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    clf.inject_dropout_mask(mask)
+    ytr, ydv = t['Y'][t['tr']], t['Y'][t['dev_idx']]
+    out = clf.f_train(t['X'], ytr, ydv, t['A'], t['tr'], t['dev_idx'])
+    new, ref, grads = O.f_train(params, O.AdamState(params), t['X'], ytr, ydv, t['A'], t['tr'], t['dev_idx'], hid, True, 0.5,
+                                mask.astype(np.float32))
+    assert abs(out[0] - ref[0]) <= 2e-6 * abs(ref[0]) and abs(out[2] - ref[2]) <= 2e-6 * abs(ref[2])
+    assert abs(out[1] - ref[1]) <= 2.0 / len(ytr) and abs(out[3] - ref[3]) <= 2.0 / len(ydv)      # hit counts (ties aside)
+    for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+        assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-10, (i, float(np.abs(g - r).max()), float(np.abs(r).max()))
+    for i, (q, r) in enumerate(zip(L.get_all_param_values(clf.l_out), new)):
+        assert np.abs(q - r).max() <= 2e-3 * 0.05 + 1e-7, i        # Adam's normalised step (see test_e2e_gpu)
+        assert np.mean(np.abs(q - r)) <= 2e-6
