@@ -86,7 +86,7 @@ def _worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3)])
+@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3), ("a2a", 8), ("allgather", 4)])
 def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     import torch.multiprocessing as mp
     from tests.helpers import load_case
