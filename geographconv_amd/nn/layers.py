@@ -353,13 +353,12 @@ class DenseLayer(Layer):
         DenseLayer.early_starts['bwd'] += 1
         self._pending[('bwd', id(tape))] = self._backward_pre(grad, tape, kwargs)
 
-    def _backward_pre(self, grad, tape, kwargs):
-        """-> (dS, handle): dS = gradient at the pre-activation (bias gradient done); handle = the started
-        exchange of dS when this layer convolves over a partitioned graph, else None."""
+    def _pre_activation_grad(self, grad, tape, kwargs):
+        """dS = gradient at the pre-activation, with this layer's bias gradient written on the way (fused into the
+        activation-gradient kernel where there is one; skipped when the producer of `grad` already wrote it)."""
         K = backend.active()
-        s = tape[self]
-        y = s['y']
-        bias_done = False
+        y = tape[self]['y']
+        bias_done = isinstance(grad, PreAct) and grad.bias_done
         if isinstance(grad, PreAct):
             dS = grad.m
         elif self.nonlinearity is _nl.softmax:
@@ -377,66 +376,46 @@ class DenseLayer(Layer):
                 bias_done = True
             else:
                 dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
-        if self.b is not None and not bias_done and not (isinstance(grad, PreAct) and grad.bias_done):
+        if self.b is not None and not bias_done:
             K.colsum(dS, out=self.b.grad)
-        handle = None
-        A = kwargs.get('A') if self._uses_graph(kwargs) else None
-        comm = kwargs.get('comm')
-        if A is not None and comm is not None:
-            A_bwd = A.bwd
-            if getattr(A, 'head_dense', None) is not None:
-                raise ValueError("a graph operand with a split transpose (dense head panel) cannot be exchanged: build "
-                                 "it with SparseOperand.from_scipy(..., dense_head=False)")
-            hint = kwargs.get('A_bwd_rows_hint')
-            if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
-                A_bwd = hint[1]
-            g = comm.stage_operand(dS, self.num_units, tag='bwd')
-            handle = comm.graph_spmm_begin(A_bwd, g, None, 0, self.num_units, tag='bwd')
-        return dS, handle
+        return dS
+
+    def _transpose_operand(self, A, grad, kwargs):
+        """A^T for the backward product.  Structural zeros: when the incoming gradient is known to be zero outside a
+        set of rows (the CE gradient lives on the training rows only), the caller may pass A^T with the other
+        COLUMNS removed (`A_bwd_rows_hint`)."""
+        hint = kwargs.get('A_bwd_rows_hint')
+        if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
+            return hint[1]
+        return A.bwd
+
+    def _backward_pre(self, grad, tape, kwargs):
+        """-> (dS, handle): the pre-activation gradient and the started exchange of it (partitioned graph)."""
+        dS = self._pre_activation_grad(grad, tape, kwargs)
+        A, comm = kwargs['A'], kwargs['comm']
+        if getattr(A, 'head_dense', None) is not None:
+            raise ValueError("a graph operand with a split transpose (dense head panel) cannot be exchanged: build "
+                             "it with SparseOperand.from_scipy(..., dense_head=False)")
+        g = comm.stage_operand(dS, self.num_units, tag='bwd')
+        return dS, comm.graph_spmm_begin(self._transpose_operand(A, grad, kwargs), g, None, 0, self.num_units, tag='bwd')
 
     def backward(self, grad, tape, into, need_input_grad=True, **kwargs):
         K = backend.active()
-        s = tape[self]
-        x, y = s['x'], s['y']
+        x = tape[self]['x']
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
         if A is not None and kwargs.get('comm') is not None:
             dS, handle = self._pending.pop(('bwd', id(tape)), None) or self._backward_pre(grad, tape, kwargs)
             dZ = kwargs['comm'].graph_spmm_end(handle)
             return self._backward_post(x, dZ, into, need_input_grad, kwargs)
-        bias_done = False
-        if isinstance(grad, PreAct):
-            dS = grad.m
-        elif self.nonlinearity is _nl.softmax:
-            raise NotImplementedError("softmax output expects the fused CE gradient (PreAct)")
-        elif self.nonlinearity.act == 0:
-            dS = grad
+        dS = self._pre_activation_grad(grad, tape, kwargs)
+        if A is None:
+            dZ = dS
         else:
-            uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
-            km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
-            g_in = grad.m if isinstance(grad, Masked) else grad
-            out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None
-            if self.b is not None and hasattr(K, 'act_bwd_colsum'):
-                # activation gradient and bias gradient (its column sums) in one pass
-                dS = K.act_bwd_colsum(g_in, y, self.nonlinearity.act, self.b.grad, out=out, keep_mask=km, scale=sc)
-                bias_done = True
-            else:
-                dS = K.act_bwd(g_in, y, self.nonlinearity.act, out=out, keep_mask=km, scale=sc)
-        if self.b is not None and not bias_done and not (isinstance(grad, PreAct) and grad.bias_done):
-            K.colsum(dS, out=self.b.grad)
-        A = kwargs.get('A') if self._uses_graph(kwargs) else None
-        if A is not None:
-            A_bwd = A.bwd
-            # structural zeros: when the incoming gradient is known to be zero outside a set of rows (the CE
-            # gradient lives on the training rows only), the caller may pass A^T with the other COLUMNS removed
-            hint = kwargs.get('A_bwd_rows_hint')
-            if hint is not None and isinstance(grad, PreAct) and hint[0] is self:
-                A_bwd = hint[1]
+            A_bwd = self._transpose_operand(A, grad, kwargs)
             if A_bwd is A.bwd and getattr(A, 'head_dense', None) is not None:
                 dZ = K.spmm_t(A, dS)          # an operand whose transpose is split (dense head panel + CSR tail)
             else:
                 dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
-        else:
-            dZ = dS
         return self._backward_post(x, dZ, into, need_input_grad, kwargs)
 
     def _backward_post(self, x, dZ, into, need_input_grad, kwargs):
