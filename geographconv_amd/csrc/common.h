@@ -76,6 +76,7 @@ __device__ __forceinline__ float apply_act(float x) {
 // by a kernel that accumulates into the same buffer was observed to race on ROCm 7.2 when the graph is
 // launched on an idle device (tests/test_e2e_gpu.py::test_hip_graph_...); kernel -> kernel edges are safe.
 int zero_fill_async(void* ptr, size_t bytes, hipStream_t st);        // core.hip; bytes % 4 == 0
+int zero_rows_async(float* ptr, int64_t rows, int64_t cols, int64_t ld, hipStream_t st);   // ptr[r*ld + c] = 0, c < cols
 
 // elementwise.hip: out[col] = sum over parts of P[part * stride + col], fixed tree (deterministic)
 int colsum_final_launch(int nparts, int F, const float* P, int64_t stride, float* out, hipStream_t st);

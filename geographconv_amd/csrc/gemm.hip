@@ -158,21 +158,32 @@ struct GemmCfg {
     static_assert(kWaveM % 16 == 0 && kWaveN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA");
 };
 
+// One launch multiplies up to two SEGMENTS (gcnmodel.py:281-286: the highway block's conv branch and gate read the
+// same input; their backward adds two products into the same dH):
+//   n_nseg = 2  "dual":  C[q] = act_q(op(A[0]) . B[q] + bias[q]), q = 0, 1 -- the A tile is staged for both weights by the
+//               same XCD (shared through its L2), tile column nt belongs to segment nt / nt_per_seg;
+//   n_kseg = 2  "k-concatenated":  C[0] = A[0].op(B[0]) + A[1].op(B[1]) [+ C[0]] -- one accumulator, one pass over C.
+// Never both; split-K (transA) only with n_kseg = 1.
 struct GemmArgs {
-    int64_t M, N, K;
-    const float* A; int64_t lda;
-    const float* B; int64_t ldb;
-    float* C; int64_t ldc;
-    const float* bias;
+    int64_t M;
+    const float* A[2]; int64_t lda[2];
+    const float* B[2]; int64_t ldb[2];
+    float* C[2]; int64_t ldc[2];
+    const float* bias[2];
+    int64_t N[2];              // output columns of N segment q
+    int64_t K[2];              // reduction length of K segment q
+    int act_on[2];             // apply the kernel's ACT to N segment q (0 = linear)
     int accumulate;
     int64_t kchunk;
-    int n_mt, n_nt, n_split, xcd_order;
+    int n_mt, n_nt, nt_per_seg, n_split, xcd_order, n_kseg, nk0;
+    int64_t slab_seg_w;        // MODE 1: column offset of N segment 1 inside a slab row
 };
 
 // Tile coordinates are wave-uniform (functions of blockIdx and loop counters); readfirstlane keeps them in
 // SGPRs so that everything derived from them (buffer descriptors, loop control) is scalar code.
 struct TileCoord {
-    int mt, nt, z, nk;      // nk == 0: past the end of this block's list
+    int mt, nt, z, nk;      // nk == 0: past the end of this block's list;  nt = tile column INSIDE its segment
+    int seg;                // N segment
 };
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -197,11 +208,18 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmArgs& a, int p, int G
     }
     TileCoord t;
     t.mt = uni(mt);
-    t.nt = uni(nt);
+    t.seg = uni(nt / a.nt_per_seg);
+    t.nt = uni(nt % a.nt_per_seg);
     t.z = uni(z);
-    const int64_t kbeg = (int64_t)t.z * a.kchunk;
-    const int64_t kend = min(a.K, kbeg + a.kchunk);
-    int nk = (t.mt < a.n_mt) ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+    int nk;
+    if (a.n_kseg == 2) {
+        nk = a.nk0 + (int)((a.K[1] + BK - 1) / BK);
+    } else {
+        const int64_t kbeg = (int64_t)t.z * a.kchunk;
+        const int64_t kend = min(a.K[0], kbeg + a.kchunk);
+        nk = (int)((kend - kbeg + BK - 1) / BK);
+    }
+    if (t.mt >= a.n_mt) nk = 0;
     t.nk = uni(nk < 0 ? 0 : nk);
     return t;
 }
@@ -236,17 +254,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
     // two register sets: while stage s is multiplied, stage s+1 waits in one set to be written to LDS and
     // the global loads of stage s+2 land in the other (two stages of HBM latency tolerance)
     float4 ra0[Cfg::kAIters], rb0[Cfg::kBIters], ra1[Cfg::kAIters], rb1[Cfg::kBIters];
+    // reduction window of stage kt of tile t: K segment, first k, end of the window (all wave-uniform)
+    struct KWin { int ks; int64_t k0, kend; };
+    auto kwin = [&](const TileCoord& t, int kt) -> KWin {
+        KWin w;
+        if (a.n_kseg == 2) {
+            w.ks = uni(kt >= a.nk0 ? 1 : 0);
+            w.k0 = (int64_t)(w.ks ? kt - a.nk0 : kt) * BK;
+            w.kend = w.ks ? a.K[1] : a.K[0];
+        } else {
+            const int64_t kbeg = (int64_t)t.z * a.kchunk;
+            w.ks = 0;
+            w.k0 = kbeg + (int64_t)kt * BK;
+            w.kend = min(a.K[0], kbeg + a.kchunk);
+        }
+        return w;
+    };
     auto gload = [&](float4 (&ra)[Cfg::kAIters], float4 (&rb)[Cfg::kBIters], const TileCoord& t, int kt) {
-        const int64_t kbeg = (int64_t)t.z * a.kchunk;
+        const KWin w = kwin(t, kt);
         // past the end of the list (nk == 0): kend = k0 makes every descriptor empty
-        const int64_t k0 = kbeg + (int64_t)kt * BK;
-        const int64_t kend = t.nk > 0 ? min(a.K, kbeg + a.kchunk) : k0;
+        const int64_t k0 = w.k0;
+        const int64_t kend = t.nk > 0 ? w.kend : k0;
         const int64_t m0 = (int64_t)t.mt * BM, n0 = (int64_t)t.nt * BN;
-        const int64_t Mlim = t.nk > 0 ? a.M : 0, Nlim = t.nk > 0 ? a.N : 0;
-        if constexpr (AT) gload_kstrided<BM, NTH>(ra, a.A, a.lda, m0, Mlim, k0, kend);
-        else gload_kcontig<BM, NTH>(ra, a.A, a.lda, m0, Mlim, k0, kend);
-        if constexpr (BT) gload_kcontig<BN, NTH>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
-        else gload_kstrided<BN, NTH>(rb, a.B, a.ldb, n0, Nlim, k0, kend);
+        const int sb = w.ks | t.seg;             // which B (at most one of the two indices is non-zero)
+        const float* Ap = w.ks ? a.A[1] : a.A[0];
+        const int64_t lda = w.ks ? a.lda[1] : a.lda[0];
+        const float* Bp = sb ? a.B[1] : a.B[0];
+        const int64_t ldb = sb ? a.ldb[1] : a.ldb[0];
+        const int64_t Mlim = t.nk > 0 ? a.M : 0, Nlim = t.nk > 0 ? (t.seg ? a.N[1] : a.N[0]) : 0;
+        if constexpr (AT) gload_kstrided<BM, NTH>(ra, Ap, lda, m0, Mlim, k0, kend);
+        else gload_kcontig<BM, NTH>(ra, Ap, lda, m0, Mlim, k0, kend);
+        if constexpr (BT) gload_kcontig<BN, NTH>(rb, Bp, ldb, n0, Nlim, k0, kend);
+        else gload_kstrided<BN, NTH>(rb, Bp, ldb, n0, Nlim, k0, kend);
     };
     auto sstore = [&](int buf, const float4 (&ra)[Cfg::kAIters], const float4 (&rb)[Cfg::kBIters]) {
         float* As = smem + buf * Cfg::kStageFloats;
@@ -280,9 +319,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
         advance_load();
         const float* As = smem + cur * Cfg::kStageFloats;
         const float* Bs = As + Cfg::kAFloats;
-        const int64_t ckbeg = (int64_t)ct.z * a.kchunk;
-        const int64_t ckend = min(a.K, ckbeg + a.kchunk);
-        const int64_t k_stage = ckbeg + (int64_t)ckt * BK;
+        const KWin cw = kwin(ct, ckt);
+        const int64_t ckend = cw.kend;
+        const int64_t k_stage = cw.k0;
         if (PROBE & 16) __builtin_amdgcn_s_setprio(1);       // experiment: MFMA section at raised wave priority
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
@@ -328,8 +367,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
             // epilogue of this tile.  With the swapped operands the accumulator of lane (li, lg) holds
             // C[row = li][col = 4*lg + r], r = 0..3, of each 16x16 sub-tile: one float4 per sub-tile.
             // Columns in [N, roundup4(N)) are pad columns and are written as zeros (geogcn.h convention).
-            float* Cout = a.C;
-            if constexpr (MODE == 1) Cout = a.C + (int64_t)ct.z * a.M * a.ldc;
+            float* Cout = ct.seg ? a.C[1] : a.C[0];
+            int64_t ldc = ct.seg ? a.ldc[1] : a.ldc[0];
+            const float* bias = ct.seg ? a.bias[1] : a.bias[0];
+            const int64_t Nseg = ct.seg ? a.N[1] : a.N[0];
+            const bool act_on = (ct.seg ? a.act_on[1] : a.act_on[0]) != 0;
+            if constexpr (MODE == 1) {
+                Cout = a.C[0] + (int64_t)ct.z * a.M * a.ldc[0] + (ct.seg ? a.slab_seg_w : 0);
+                ldc = a.ldc[0];
+            }
             const int64_t m0 = (int64_t)ct.mt * BM, n0 = (int64_t)ct.nt * BN;
             float bcol[Cfg::NR][4];
 #pragma unroll
@@ -339,14 +385,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
                 for (int r = 0; r < 4; ++r) {
                     bcol[jn][r] = 0.f;
                     if constexpr (MODE == 0) {
-                        if (a.bias && col0 + r < a.N) bcol[jn][r] = a.bias[col0 + r];
+                        if (bias && col0 + r < Nseg) bcol[jn][r] = bias[col0 + r];
                     }
                 }
             }
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
                 const int64_t row = m0 + wm * Cfg::kWaveM + i * 16 + li;
-                float* crow = Cout + row * a.ldc;
+                float* crow = Cout + row * ldc;
                 const bool row_ok = row < a.M;
                 // all loads of the epilogue (bias above, old C when accumulating) are issued as independent
                 // batches before their first use -- no load/wait/store chains
@@ -357,7 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
                         for (int jn = 0; jn < Cfg::NR; ++jn) {
                             const int64_t col0 = n0 + wn * Cfg::kWaveN + jn * 16 + lg * 4;
                             oldv[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (row_ok && col0 < a.N) oldv[jn] = *reinterpret_cast<const float4*>(crow + col0);
+                            if (row_ok && col0 < Nseg) oldv[jn] = *reinterpret_cast<const float4*>(crow + col0);
                         }
                     }
                 }
@@ -368,15 +414,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         x[r] = acc[i][jn][r];
-                        if constexpr (MODE == 0) x[r] = apply_act<ACT>(x[r] + bcol[jn][r]);
+                        if constexpr (MODE == 0) {
+                            x[r] += bcol[jn][r];
+                            if (ACT == GEOGCN_ACT_NONE || act_on) x[r] = apply_act<ACT>(x[r]);
+                        }
                     }
                     if constexpr (MODE == 0) {
                         if (a.accumulate) { x[0] += oldv[jn].x; x[1] += oldv[jn].y; x[2] += oldv[jn].z; x[3] += oldv[jn].w; }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (col0 + r >= a.N) x[r] = 0.f;
-                    if ((PROBE & 2) ? (x[0] == 123.456f) : (row_ok && col0 < a.N))
+                        if (col0 + r >= Nseg) x[r] = 0.f;
+                    if ((PROBE & 2) ? (x[0] == 123.456f) : (row_ok && col0 < Nseg))
                         *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
                     acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -438,10 +487,24 @@ struct SplitPlan {
     int grid;
 };
 
+// host-side description of one launch (segments as in GemmArgs)
+struct GemmCall {
+    int64_t M;
+    int n_nseg, n_kseg;
+    const float* A[2]; int64_t lda[2];
+    const float* B[2]; int64_t ldb[2];
+    float* C[2]; int64_t ldc[2];
+    const float* bias[2];
+    int64_t N[2], K[2];
+    int act[2];
+    int accumulate;
+    int64_t maxN() const { return n_nseg == 2 ? std::max(N[0], N[1]) : N[0]; }
+};
+
 // grid = resident persistent blocks; transA additionally slices K so that (tiles x slices) fills the grid
 template <int BM, int BN, bool AT, bool BT, int WM = 2, int WN = 2>
-SplitPlan plan_grid(int64_t M, int64_t N, int64_t K) {
-    const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
+SplitPlan plan_grid(int64_t M, int64_t n_nt, int64_t K) {
+    const int64_t tiles = cdiv(M, BM) * n_nt;
     const int G = kNumCU * GemmCfg<BM, BN, AT, BT, WM, WN>::kBlocksPerCU;
     SplitPlan sp{1, cdiv(K, BK) * BK, 0};
     if (AT) {
@@ -459,14 +522,27 @@ SplitPlan plan_grid(int64_t M, int64_t N, int64_t K) {
 }
 
 template <int BM, int BN, bool AT, bool BT, int WM = 2, int WN = 2>
-int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
-                hipStream_t st) {
+int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     using Cfg = GemmCfg<BM, BN, AT, BT, WM, WN>;
-    const SplitPlan sp = plan_grid<BM, BN, AT, BT, WM, WN>(M, N, K);
-    GemmArgs a{M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, sp.kchunk, (int)cdiv(M, BM), (int)cdiv(N, BN),
-               sp.nsplit, 0};
+    const int nt_per_seg = (int)cdiv(c.maxN(), BN);
+    const int n_nt = nt_per_seg * c.n_nseg;
+    const SplitPlan sp = plan_grid<BM, BN, AT, BT, WM, WN>(c.M, n_nt, c.K[0]);
+    GemmArgs a{};
+    a.M = c.M;
+    for (int q = 0; q < 2; ++q) {
+        a.A[q] = c.A[q]; a.lda[q] = c.lda[q]; a.B[q] = c.B[q]; a.ldb[q] = c.ldb[q]; a.C[q] = c.C[q]; a.ldc[q] = c.ldc[q];
+        a.bias[q] = c.bias[q]; a.N[q] = c.N[q]; a.K[q] = c.K[q]; a.act_on[q] = c.act[q] != GEOGCN_ACT_NONE;
+    }
+    a.accumulate = c.accumulate;
+    a.kchunk = sp.kchunk;
+    a.n_mt = (int)cdiv(c.M, BM);
+    a.n_nt = n_nt;
+    a.nt_per_seg = nt_per_seg;
+    a.n_split = sp.nsplit;
+    a.n_kseg = c.n_kseg;
+    a.nk0 = (int)cdiv(c.K[0], BK);
     a.xcd_order = (a.n_mt >= 4 * kNumXCD) ? 1 : 0;
+    const int act = c.act[0] != GEOGCN_ACT_NONE ? c.act[0] : c.act[1];     // (the entry points check that they agree)
     const dim3 grid((unsigned)sp.grid);
 #define GEOGCN_GEMM_LAUNCH(ACT, MODE)                                                                    \
     do {                                                                                                  \
@@ -487,18 +563,26 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
         else GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 0);
         return 0;
     }
-    // split-K slabs into the workspace, then the ordered combine
-    const int64_t ldw = (N + 3) & ~(int64_t)3;      // slabs are stored as float4s
-    const size_t need = (size_t)sp.nsplit * (size_t)M * (size_t)ldw * sizeof(float);
+    // split-K slabs into the workspace, then the ordered combine (per N segment)
+    GEOGCN_REQUIRE(c.n_kseg == 1, GEOGCN_E_ARG, "gemm_f32: split-K with two K segments");
+    const int64_t seg_w = (c.maxN() + 3) & ~(int64_t)3;      // slabs are stored as float4s
+    const int64_t ldw = seg_w * c.n_nseg;
+    const size_t need = (size_t)sp.nsplit * (size_t)c.M * (size_t)ldw * sizeof(float);
     GEOGCN_REQUIRE(ws && ws_bytes >= need, GEOGCN_E_ARG, "gemm_f32: split-K workspace too small (%zu < %zu)",
                    ws_bytes, need);
     float* W = (float*)ws;
-    a.C = W;
-    a.ldc = ldw;
-    a.bias = nullptr;
+    a.C[0] = W;
+    a.ldc[0] = ldw;
+    a.slab_seg_w = seg_w;
+    a.bias[0] = a.bias[1] = nullptr;
     a.accumulate = 0;
     GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1);
-    return splitk_reduce_launch(M, N, sp.nsplit, W, ldw, C, ldc, bias, act, accumulate, st);
+    for (int q = 0; q < c.n_nseg; ++q) {
+        const int rc = splitk_reduce_launch(c.M, c.N[q], sp.nsplit, W + q * seg_w, ldw, c.C[q], c.ldc[q], c.bias[q],
+                                            c.act[q], c.accumulate, st);
+        if (rc) return rc;
+    }
+    return 0;
 #undef GEOGCN_GEMM_LAUNCH
 }
 
@@ -527,15 +611,11 @@ inline int wide_bn(int64_t N) {
 }
 
 template <bool AT, bool BT>
-int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-                   int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws,
-                   size_t ws_bytes, hipStream_t st) {
-#define GEOGCN_T(BM_, BN_)                                                                                   \
-    if (bm == BM_ && bn == BN_)                                                                              \
-        return launch_gemm<BM_, BN_, AT, BT>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
-#define GEOGCN_W(BM_, BN_)                                                                                   \
-    if (bm == BM_ && bn == BN_)                                                                              \
-        return launch_gemm<BM_, BN_, AT, BT, 2, 4>(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
+int dispatch_tiles(int bm, int bn, const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
+#define GEOGCN_T(BM_, BN_) \
+    if (bm == BM_ && bn == BN_) return launch_gemm<BM_, BN_, AT, BT>(c, ws, ws_bytes, st);
+#define GEOGCN_W(BM_, BN_) \
+    if (bm == BM_ && bn == BN_) return launch_gemm<BM_, BN_, AT, BT, 2, 4>(c, ws, ws_bytes, st);
     GEOGCN_T(128, 128)
     GEOGCN_T(128, 160)
     if constexpr (!AT) {
@@ -559,11 +639,44 @@ int dispatch_tiles(int bm, int bn, int64_t M, int64_t N, int64_t K, const float*
     return GEOGCN_E_ARG;
 }
 
-template <int BM, int BN, int WM = 2, int WN = 2>
-size_t splitk_ws_bytes(int64_t M, int64_t N, int64_t K) {
-    const SplitPlan sp = plan_grid<BM, BN, true, false, WM, WN>(M, N, K);
-    return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)((N + 3) & ~(int64_t)3) * sizeof(float);
+// tile shape of a call: (bm, bn)
+inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int n_nseg, int& bm, int& bn) {
+    const int wbn = transA ? wide_bn(maxN) : 0;
+    bn = wbn ? wbn : pick_tile(maxN);
+    if (transA) {
+        bm = pick_tile(M);
+        return;
+    }
+    // short operands: with 128-row tiles fewer tiles than CUs -> 64-row tiles (M = 9,475: 150 -> 298 tiles)
+    const bool few = cdiv(M, 128) * cdiv(maxN, bn) * n_nseg < kNumCU;
+    bm = few ? 64 : ((transB && bn == 160) ? 96 : 128);
 }
+
+int run_call(bool transA, bool transB, const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
+    int bm, bn;
+    choose_tiles(transA, transB, c.M, c.maxN(), c.n_nseg, bm, bn);
+    if (transA) return dispatch_tiles<true, false>(bm, bn, c, ws, ws_bytes, st);
+    if (transB) return dispatch_tiles<false, true>(bm, bn, c, ws, ws_bytes, st);
+    return dispatch_tiles<false, false>(bm, bn, c, ws, ws_bytes, st);
+}
+
+template <int BM, int BN, int WM = 2, int WN = 2>
+size_t splitk_ws_bytes(int64_t M, int64_t maxN, int n_nseg, int64_t K) {
+    const SplitPlan sp = plan_grid<BM, BN, true, false, WM, WN>(M, cdiv(maxN, BN) * n_nseg, K);
+    return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)(((maxN + 3) & ~(int64_t)3) * n_nseg) * sizeof(float);
+}
+
+size_t transA_ws_bytes(int64_t M, int64_t maxN, int n_nseg, int64_t K) {
+    const int bm = pick_tile(M), bn = pick_tile(maxN), wbn = wide_bn(maxN);
+    if (wbn == 320) return bm == 160 ? splitk_ws_bytes<160, 320, 2, 4>(M, maxN, n_nseg, K) : splitk_ws_bytes<128, 320, 2, 4>(M, maxN, n_nseg, K);
+    if (wbn == 256) return bm == 160 ? splitk_ws_bytes<160, 256, 2, 4>(M, maxN, n_nseg, K) : splitk_ws_bytes<128, 256, 2, 4>(M, maxN, n_nseg, K);
+    if (bm == 128 && bn == 128) return splitk_ws_bytes<128, 128>(M, maxN, n_nseg, K);
+    if (bm == 128 && bn == 160) return splitk_ws_bytes<128, 160>(M, maxN, n_nseg, K);
+    if (bm == 160 && bn == 128) return splitk_ws_bytes<160, 128>(M, maxN, n_nseg, K);
+    return splitk_ws_bytes<160, 160>(M, maxN, n_nseg, K);
+}
+
+bool ld_ok(const void* p, int64_t ld) { return ld % 4 == 0 && aligned16(p); }
 
 }  // namespace
 }  // namespace geogcn
@@ -581,13 +694,12 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
         const size_t h = gemm_bf16_tn_workspace_bytes(M, N, K);      // 0: shape left to the fp32 kernel
         if (h) return h;
     }
-    const int bm = pick_tile(M), bn = pick_tile(N), wbn = wide_bn(N);
-    if (wbn == 320) return bm == 160 ? splitk_ws_bytes<160, 320, 2, 4>(M, N, K) : splitk_ws_bytes<128, 320, 2, 4>(M, N, K);
-    if (wbn == 256) return bm == 160 ? splitk_ws_bytes<160, 256, 2, 4>(M, N, K) : splitk_ws_bytes<128, 256, 2, 4>(M, N, K);
-    if (bm == 128 && bn == 128) return splitk_ws_bytes<128, 128>(M, N, K);
-    if (bm == 128 && bn == 160) return splitk_ws_bytes<128, 160>(M, N, K);
-    if (bm == 160 && bn == 128) return splitk_ws_bytes<160, 128>(M, N, K);
-    return splitk_ws_bytes<160, 160>(M, N, K);
+    return transA_ws_bytes(M, N, 1, K);
+}
+
+size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K) {
+    if (!transA || M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0) return 0;
+    return transA_ws_bytes(M, std::max(N0, N1), 2, K);
 }
 
 static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
@@ -615,26 +727,25 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
         GEOGCN_REQUIRE(ldc % 8 == 0 && ldc >= ((N + 7) & ~(int64_t)7), GEOGCN_E_ALIGN,
                        "%s: a bf16 C needs ldc %% 8 == 0 and >= roundup8(N) (ldc=%lld)", fn, (long long)ldc);
     }
-    if (!transA && precision != GEOGCN_GEMM_F32 && K > 0)
+    if (K == 0) {
+        // an empty reduction (a rank that owns no rows: dW = H^T.dZ over zero nodes): the product is the zero matrix
+        if (accumulate) return 0;
+        GEOGCN_REQUIRE(!bias && act == GEOGCN_ACT_NONE, GEOGCN_E_ARG, "%s: K = 0 with a bias / activation", fn);
+        return zero_rows_async((float*)Cv, M, (N + 3) & ~(int64_t)3, ldc, st);
+    }
+    if (!transA && precision != GEOGCN_GEMM_F32)
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
                                   ws_bytes, st);
     float* C = (float*)Cv;
-    if (transA && precision == GEOGCN_GEMM_BF16 && K > 0) {
+    if (transA && precision == GEOGCN_GEMM_BF16) {
         const int rc = gemm_bf16_tn_dispatch(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
         if (rc != 1) return rc;          // 1 = shape not handled by the bf16 kernel: exact fp32 below
     }
-    const int wbn = transA ? wide_bn(N) : 0;
-    const int bn = wbn ? wbn : pick_tile(N);
-    if (transA)
-        return dispatch_tiles<true, false>(pick_tile(M), bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
-                                           ws_bytes, st);
-    // short operands: with 128-row tiles fewer tiles than CUs -> 64-row tiles (M = 9,475: 150 -> 298 tiles)
-    const bool few = cdiv(M, 128) * cdiv(N, bn) < kNumCU;
-    if (transB)
-        return dispatch_tiles<false, true>(few ? 64 : ((bn == 160) ? 96 : 128), bn, M, N, K, A, lda, B, ldb, C, ldc, bias,
-                                           act, accumulate, ws, ws_bytes, st);
-    return dispatch_tiles<false, false>(few ? 64 : 128, bn, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws,
-                                        ws_bytes, st);
+    GemmCall c{};
+    c.M = M; c.n_nseg = 1; c.n_kseg = 1;
+    c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = C; c.ldc[0] = ldc; c.bias[0] = bias;
+    c.N[0] = N; c.K[0] = K; c.act[0] = act; c.act[1] = GEOGCN_ACT_NONE; c.accumulate = accumulate;
+    return run_call(transA != 0, transB != 0, c, ws, ws_bytes, st);
 }
 
 int geogcn_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
@@ -649,6 +760,65 @@ int geogcn_gemm_f32_bf16c(int32_t transB, int64_t M, int64_t N, int64_t K, const
                           size_t ws_bytes, void* stream) {
     return gemm_entry("gemm_f32_bf16c", 0, transB, M, N, K, A, lda, B, ldb, C, ldc, 1, bias, act, 0, GEOGCN_GEMM_BF16, ws,
                       ws_bytes, stream);
+}
+
+// (C0, C1) = (act0(op(A).B0 + bias0), act1(op(A).B1 + bias1)) in one launch, exact fp32
+int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda,
+                         const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
+                         float* C1, int64_t ldc1, const float* bias0, int32_t act0, const float* bias1, int32_t act1,
+                         void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "gemm_dual_f32";
+    GEOGCN_REQUIRE(M >= 0 && N0 >= 0 && N1 >= 0 && K >= 0, GEOGCN_E_SIZE, "%s: negative size", fn);
+    if (M == 0 || (N0 == 0 && N1 == 0)) return 0;
+    GEOGCN_REQUIRE(N0 > 0 && N1 > 0, GEOGCN_E_SIZE, "%s: both products need columns (N0=%lld N1=%lld)", fn, (long long)N0,
+                   (long long)N1);
+    GEOGCN_REQUIRE(C0 && C1 && (K == 0 || (A && B0 && B1)), GEOGCN_E_NULL, "%s: null pointer", fn);
+    GEOGCN_REQUIRE(act0 >= GEOGCN_ACT_NONE && act0 <= GEOGCN_ACT_SIGMOID && act1 >= GEOGCN_ACT_NONE && act1 <= GEOGCN_ACT_SIGMOID,
+                   GEOGCN_E_ARG, "%s: unknown act", fn);
+    GEOGCN_REQUIRE(act0 == GEOGCN_ACT_NONE || act1 == GEOGCN_ACT_NONE || act0 == act1, GEOGCN_E_ARG,
+                   "%s: two different non-linear epilogues (%d, %d) in one launch are not supported", fn, act0, act1);
+    const int64_t a_cols = transA ? M : K;
+    GEOGCN_REQUIRE(lda >= a_cols && ldb0 >= N0 && ldb1 >= N1 && ldc0 >= N0 && ldc1 >= N1, GEOGCN_E_SIZE,
+                   "%s: leading dimension too small", fn);
+    GEOGCN_REQUIRE(ld_ok(A, lda) && ld_ok(B0, ldb0) && ld_ok(B1, ldb1) && ld_ok(C0, ldc0) && ld_ok(C1, ldc1), GEOGCN_E_ALIGN,
+                   "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 0) {
+        GEOGCN_REQUIRE(!bias0 && !bias1 && act0 == GEOGCN_ACT_NONE && act1 == GEOGCN_ACT_NONE, GEOGCN_E_ARG,
+                       "%s: K = 0 with a bias / activation", fn);
+        const int rc = zero_rows_async(C0, M, (N0 + 3) & ~(int64_t)3, ldc0, st);
+        return rc ? rc : zero_rows_async(C1, M, (N1 + 3) & ~(int64_t)3, ldc1, st);
+    }
+    GemmCall c{};
+    c.M = M; c.n_nseg = 2; c.n_kseg = 1;
+    c.A[0] = A; c.lda[0] = lda;
+    c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
+    c.C[0] = C0; c.ldc[0] = ldc0; c.C[1] = C1; c.ldc[1] = ldc1;
+    c.bias[0] = bias0; c.bias[1] = bias1;
+    c.N[0] = N0; c.N[1] = N1; c.K[0] = K; c.act[0] = act0; c.act[1] = act1;
+    return run_call(transA != 0, false, c, ws, ws_bytes, st);
+}
+
+// C = A0.op(B0) + A1.op(B1) [+ C]: one accumulator over both reductions, exact fp32
+int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                         const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                         float* C, int64_t ldc, int32_t accumulate, void* stream) {
+    const char* fn = "gemm_kcat_f32";
+    GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    if (M == 0 || N == 0) return 0;
+    GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C, GEOGCN_E_NULL, "%s: null pointer", fn);
+    const int64_t b0_cols = transB ? K0 : N, b1_cols = transB ? K1 : N;
+    GEOGCN_REQUIRE(lda0 >= K0 && lda1 >= K1 && ldb0 >= b0_cols && ldb1 >= b1_cols && ldc >= N, GEOGCN_E_SIZE,
+                   "%s: leading dimension too small", fn);
+    GEOGCN_REQUIRE(ld_ok(A0, lda0) && ld_ok(A1, lda1) && ld_ok(B0, ldb0) && ld_ok(B1, ldb1) && ld_ok(C, ldc), GEOGCN_E_ALIGN,
+                   "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
+    GemmCall c{};
+    c.M = M; c.n_nseg = 1; c.n_kseg = 2;
+    c.A[0] = A0; c.lda[0] = lda0; c.A[1] = A1; c.lda[1] = lda1;
+    c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
+    c.C[0] = C; c.ldc[0] = ldc;
+    c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate;
+    return run_call(false, transB != 0, c, nullptr, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -280,6 +280,7 @@ def highway_dense(incoming, gconv=False, Wh=_init.GlorotUniform(), bh=_init.Cons
         l_h = DenseLayer(incoming, num_units=num_inputs, W=Wh, b=bh, nonlinearity=nonlinearity)
     l_t = DenseLayer(incoming, num_units=num_inputs, W=Wt, b=bt, nonlinearity=NL.sigmoid)
     l_h.highway_gate = l_t           # lets the convolution fuse the gating mix into its SpMM epilogue
+    l_t.highway_conv = l_h           # lets the gate's launch multiply by [Wh | Wt] (both read `incoming`)
     return MultiplicativeGatingLayer(gate=l_t, input1=l_h, input2=incoming), l_t
 
 

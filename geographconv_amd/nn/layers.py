@@ -225,6 +225,12 @@ def _fuse_highway(fp32_operand):
     return mode == 'all' or (mode == 'f32' and fp32_operand)
 
 
+def _fuse_gemms():
+    """GEOGCN_FUSE_GEMMS = 1 (default) | 0: the highway block's two weights in one launch (A/B switch)."""
+    import os
+    return os.environ.get('GEOGCN_FUSE_GEMMS', '1') != '0'
+
+
 def _accumulate(dst, src):
     backend.active().add_inplace(src, dst)
     return dst
@@ -281,7 +287,15 @@ class DenseLayer(Layer):
         prec = kwargs.get('gemm_precision')     # None = backend default ('f32': exact fp32 MFMA)
         saved = {'x': input}
         if A is None:
-            if isinstance(input, K.DMat):
+            conv = self._fusable_sibling(input, tape, kwargs)
+            if conv is not None:
+                # highway block (gcnmodel.py:281-286): this gate and the conv branch read the same input -- one launch
+                # multiplies it by [Wh | Wt]: Z = H.Wh raw into the SpMM operand's pitch, T = sigmoid(H.Wt + bt) here
+                zf = K.DMat.empty(input.n, conv.num_units, input.device, ld=K.gather_ld(conv.num_units))
+                _, y = K.gemm_dual(input, conv.W.data, self.W.data, out0=zf, bias1=bias, act1=act)
+                tape[('fused_z', conv)] = (input, zf)
+                saved['fused_with'] = conv
+            elif isinstance(input, K.DMat):
                 y = K.gemm(input, self.W.data, bias=bias, act=act, precision=prec)   # bias + act fused
             else:
                 y = K.spmm(input.fwd, self.W.data, bias=bias, act=act)    # sparse input: X.W0
@@ -296,8 +310,12 @@ class DenseLayer(Layer):
                     zf = K.HMat(n_in, self.num_units, y_device(input))
                     self._matmul(input, zf, prec)
                 else:
-                    zf = K.DMat.empty(n_in, self.num_units, y_device(input), ld=K.gather_ld(self.num_units))
-                    self._matmul(input, zf, prec)
+                    pre = tape.pop(('fused_z', self), None) if tape is not None else None
+                    if pre is not None and pre[0] is input:
+                        zf = pre[1]                 # the gate's launch already multiplied by this layer's W
+                    else:
+                        zf = K.DMat.empty(n_in, self.num_units, y_device(input), ld=K.gather_ld(self.num_units))
+                        self._matmul(input, zf, prec)
                     if K.bf16_gather(prec):
                         zf = K.cast_bf16(zf)
                 gate = getattr(self, 'highway_gate', None)
@@ -305,8 +323,7 @@ class DenseLayer(Layer):
                 # (fp32 operand only: on the bf16 operand the epilogue's T / H loads cost more than the separate pass:
                 #  1.82 ms fused against 1.10 + 0.41 ms)
                 if (T is not None and self.nonlinearity is _nl.tanh and bias is not None and isinstance(input, K.DMat)
-                        and _fuse_highway(isinstance(zf, K.DMat)) and tape[gate]['x'] is input and T.ld == input.ld
-                        and hasattr(K, 'spmm_highway')):
+                        and _fuse_highway(isinstance(zf, K.DMat)) and tape[gate]['x'] is input and T.ld == input.ld):
                     # highway block: the gating mix T*Hc + (1-T)*H rides in the SpMM's epilogue (the gate was
                     # evaluated just before this layer); MultiplicativeGatingLayer picks the result up
                     y, saved['highway_out'] = K.spmm_highway(A.fwd, zf, bias, T, input)
@@ -327,6 +344,19 @@ class DenseLayer(Layer):
         if tape is not None:
             tape[self] = saved
         return y
+
+    def _fusable_sibling(self, input, tape, kwargs):
+        """The highway block's conv branch, when its H.W can ride in this gate's launch: one GPU, exact-fp32 products,
+        a graph convolution (whose Z stays linear) with a plain dense product, evaluated with a tape."""
+        K = backend.active()
+        conv = getattr(self, 'highway_conv', None)
+        if (conv is None or tape is None or kwargs.get('comm') is not None or kwargs.get('A') is None
+                or not isinstance(input, K.DMat) or conv.input_layer is not self.input_layer
+                or (kwargs.get('gemm_precision') or K.GEMM_PRECISION) != 'f32' or not _fuse_gemms()
+                or not conv._uses_graph(kwargs) or type(conv)._matmul is not DenseLayer._matmul
+                or conv.W.data is None or conv.W.shape[0] != self.W.shape[0]):
+            return None
+        return conv
 
     # ---- two-phase evaluation (multi-GPU): start the exchange of the SpMM operand early, finish later --------
     def _exchange_begin_fwd(self, input, A, comm, bias, act, prec):
@@ -370,7 +400,7 @@ class DenseLayer(Layer):
             km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
             g_in = grad.m if isinstance(grad, Masked) else grad
             out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None
-            if self.b is not None and hasattr(K, 'act_bwd_colsum'):
+            if self.b is not None:
                 # activation gradient and bias gradient (its column sums) in one pass
                 dS = K.act_bwd_colsum(g_in, y, self.nonlinearity.act, self.b.grad, out=out, keep_mask=km, scale=sc)
                 bias_done = True
@@ -416,12 +446,29 @@ class DenseLayer(Layer):
                 dZ = K.spmm_t(A, dS)          # an operand whose transpose is split (dense head panel + CSR tail)
             else:
                 dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
-        return self._backward_post(x, dZ, into, need_input_grad, kwargs)
+        return self._backward_post(x, dZ, into, need_input_grad, kwargs, tape)
 
-    def _backward_post(self, x, dZ, into, need_input_grad, kwargs):
+    def _backward_post(self, x, dZ, into, need_input_grad, kwargs, tape=None):
         K = backend.active()
         if isinstance(x, K.DMat):
             prec = kwargs.get('gemm_precision')
+            gate = getattr(self, 'highway_gate', None)
+            if (tape is not None and gate is not None and tape.get(gate, {}).get('fused_with') is self
+                    and not tape[gate].get('bwd_done')):
+                # the gate comes next in the reverse sweep and reads the same H: it multiplies H^T by [dZ | dU] and
+                # [dZ | dU] by [Wh | Wt]^T in one launch each
+                tape[('fused_dz', gate)] = dZ
+                return [into[0]]
+            fused = tape.pop(('fused_dz', self), None) if tape is not None else None
+            if fused is not None:
+                conv = tape[self]['fused_with']
+                K.gemm_dual(x, fused, dZ, out0=conv.W.grad, out1=self.W.grad, transA=True)     # dWh, dWt = H^T.[dZ | dU]
+                tape[self]['bwd_done'] = True
+                if not need_input_grad:
+                    return [None]
+                # dH = dZ.Wh^T + dU.Wt^T [+ the carry gradient]: one accumulator, one pass over dH
+                return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
+                                    accumulate=into[0] is not None)]
             K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ
             if not need_input_grad:
                 return [None]
@@ -490,7 +537,7 @@ class DropoutLayer(Layer):
         mask = tape[self]['mask']
         below = self.input_layer
         if (mask is not None and into[0] is None and isinstance(below, DenseLayer) and not isinstance(grad, (PreAct, Masked))
-                and below.nonlinearity.act not in (None, 0) and below.nonlinearity.fusable and hasattr(K, 'act_bwd')):
+                and below.nonlinearity.act not in (None, 0) and below.nonlinearity.fusable):
             # the layer below applies mask and 1/(1-p) inside its activation-gradient kernel
             return [Masked(grad, mask, 1.0 / (1.0 - self.p))]
         g = grad if mask is None else K.dropout_apply(grad, mask, self.p)

@@ -311,6 +311,43 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     return out
 
 
+def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None, transA=False, bias0=None, act0=ACT_NONE,
+              bias1=None, act1=ACT_NONE):
+    """(out0, out1) = (act0(op(A) . B0 + bias0), act1(op(A) . B1 + bias1)) in ONE launch (exact fp32): the highway block's
+    conv branch and gate read the same input (reference gcnmodel.py:281-286)."""
+    lib = _ffi.lib()
+    M = A.F if transA else A.n
+    K = A.n if transA else A.F
+    if B0.n != K or B1.n != K:
+        raise ValueError("gemm_dual: inner dimensions differ (%d vs %d, %d)" % (K, B0.n, B1.n))
+    out0 = DMat.empty(M, B0.F, A.device) if out0 is None else out0
+    out1 = DMat.empty(M, B1.F, A.device) if out1 is None else out1
+    dev = A.device
+    ws = _gemm_ws.get(dev)
+    if ws is None:
+        ws = _gemm_ws[dev] = Workspace(dev)
+    w = ws.get(lib.geogcn_gemm_dual_workspace_bytes(int(transA), M, B0.F, B1.F, K))
+    check(lib.geogcn_gemm_dual_f32(int(transA), M, B0.F, B1.F, K, _p(A.t), A.ld, _p(B0.t), B0.ld, _p(B1.t), B1.ld,
+                                   _p(out0.t), out0.ld, _p(out1.t), out1.ld, _p(bias0), int(act0), _p(bias1), int(act1),
+                                   _p(w), w.numel(), _stream()), 'gemm_dual_f32')
+    return out0, out1
+
+
+def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False):
+    """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
+    dH = dZ . Wh^T + dU . Wt^T of the highway block."""
+    N = B0.n if transB else B0.F
+    if (B1.n if transB else B1.F) != N or A0.n != A1.n or (B0.F if transB else B0.n) != A0.F or (B1.F if transB else B1.n) != A1.F:
+        raise ValueError("gemm_kcat: shapes do not match")
+    if out is None:
+        if accumulate:
+            raise ValueError("gemm_kcat: accumulate needs an existing output")
+        out = DMat.empty(A0.n, N, A0.device)
+    check(_ffi.lib().geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
+                                          _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _stream()), 'gemm_kcat_f32')
+    return out
+
+
 def bias_act(X: DMat, bias, act, out: DMat = None):
     out = X.like() if out is None else out
     check(_ffi.lib().geogcn_bias_act_f32(X.n, X.F, _p(X.t), X.ld, _p(bias), act, _p(out.t), out.ld,

@@ -151,6 +151,26 @@ int geogcn_gemm_f32_bf16c(int32_t transB, int64_t M, int64_t N, int64_t K, const
                           const float* B, int64_t ldb, uint16_t* C, int64_t ldc, const float* bias,
                           int32_t act, void* ws, size_t ws_bytes, void* stream);
 
+/* Highway block, both weights in one launch (gcnmodel.py:281-286: the conv branch l_h and the gate l_t take the same
+ * `incoming`).  Exact fp32 MFMA, same arithmetic per element as two geogcn_gemm_f32 calls:
+ *   (C0, C1) = (act0(op(A) . B0 + bias0), act1(op(A) . B1 + bias1))       op(A) = A (transA = 0) or A^T (transA = 1)
+ * transA = 0: the forward pair Z = H.Wh (raw, into the SpMM operand's pitch) and T = sigmoid(H.Wt + bt) -- every A
+ * tile is multiplied by both weights inside one XCD (second read from L2).  transA = 1: dWh = H^T.dZ and
+ * dWt = H^T.dU, one pass over H (split-K into `ws`, geogcn_gemm_dual_workspace_bytes; slabs combined in fixed order).
+ * B0 is K x N0 (ldb0), B1 is K x N1 (ldb1).  If both act0 and act1 are non-linear they must be equal.          */
+size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K);
+int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda,
+                         const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
+                         float* C1, int64_t ldc1, const float* bias0, int32_t act0, const float* bias1, int32_t act1,
+                         void* ws, size_t ws_bytes, void* stream);
+/* Two products into one accumulator (what autodiff derives for the input of the highway block: dH = dZ.Wh^T + dU.Wt^T
+ * [+ the carry gradient already in C]):  C[M x N] = A0 . op(B0) + A1 . op(B1) [+ C].  A0 is M x K0, A1 is M x K1;
+ * transB = 1: B0 is N x K0, B1 is N x K1 (the weights as stored); transB = 0: B0 is K0 x N, B1 is K1 x N.
+ * One pass over C instead of two accumulating calls.                                                        */
+int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                         const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                         float* C, int64_t ldc, int32_t accumulate, void* stream);
+
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */
 int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const float* bias,

@@ -86,6 +86,30 @@ def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, ac
     return out
 
 
+GEMM_PRECISION = 'f32'
+
+
+def gemm_dual(A, B0, B1, out0=None, out1=None, transA=False, bias0=None, act0=ACT_NONE, bias1=None, act1=ACT_NONE):
+    return (gemm(A, B0, out=out0, transA=transA, bias=bias0, act=act0),
+            gemm(A, B1, out=out1, transA=transA, bias=bias1, act=act1))
+
+
+def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False):
+    out = gemm(A0, B0, out=out, transB=transB, accumulate=accumulate)
+    return gemm(A1, B1, out=out, transB=transB, accumulate=True)
+
+
+def spmm_highway(A, B, bias, T, H, Hc=None, Hout=None):
+    Hc = spmm(A, B, out=Hc, bias=bias, act=ACT_TANH, F=H.F)
+    return Hc, highway_fwd(T, Hc, H, out=Hout)
+
+
+def act_bwd_colsum(G, Y, act, db, out=None, keep_mask=None, scale=1.0):
+    out = act_bwd(G, Y, act, out=out, keep_mask=keep_mask, scale=scale)
+    db.numpy()[:G.F] = _v(out).sum(axis=0)
+    return out
+
+
 def bias_act(X, bias, act, out=None):
     out = DMat(X.n, X.F, X.device) if out is None else out
     r = _v(X) + (0 if bias is None else bias.numpy()[:X.F])

@@ -82,6 +82,25 @@ def test_cmu_train_step_matches_oracle(cmu):
             assert np.abs(q - r).max() <= 2e-3 * 0.02 + 1e-7, (step, i, np.abs(q - r).max())
 
 
+def test_fused_highway_gemms_match_the_separate_launches(cmu, monkeypatch):
+    """The highway block multiplies its input by [Wh | Wt] in one launch, H^T by [dZ | dU] in one, and forms
+    dH = dZ.Wh^T + dU.Wt^T in one contraction (reference gcnmodel.py:281-286: both branches read `incoming`).  Against
+    the same step with GEOGCN_FUSE_GEMMS=0: forward bitwise equal (same fma chains); gradients equal up to the one
+    changed association in dH (two accumulating passes -> one) and the dual launch's split-K slicing."""
+    c = cmu
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('GEOGCN_FUSE_GEMMS', mode)
+        clf = _clf(c)
+        clf.inject_dropout_mask(c['mask'])
+        out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+        outs[mode] = (out[:4], np.asarray(out[4]), clf.get_grads())
+    assert outs['1'][0] == outs['0'][0]
+    assert np.array_equal(outs['1'][1], outs['0'][1])
+    for i, (a, b) in enumerate(zip(outs['1'][2], outs['0'][2])):
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max() + 1e-12, (i, np.abs(a - b).max(), np.abs(b).max())
+
+
 def test_cmu_plain_gcn_and_regularisation(cmu):
     c = cmu
     hid = [300, 200, 100]

@@ -314,6 +314,86 @@ def test_gemm_tn_bf16_products(dev, R, M, N):
     assert np.allclose(dC.numpy(), got.numpy() + C0, rtol=0, atol=1e-5 + 1e-6 * np.abs(got.numpy()).max())
 
 
+@pytest.mark.parametrize("M,N0,N1,K", [(1000, 300, 300, 300), (4100, 600, 600, 600), (777, 129, 300, 129), (333, 64, 16, 40),
+                                      (70000, 300, 300, 300)])
+def test_gemm_dual_forward_equals_two_calls_bitwise(dev, M, N0, N1, K):
+    """geogcn_gemm_dual_f32 (the highway block's [Wh | Wt] in one launch): every element goes through the same fp32 fma
+    chain as in two geogcn_gemm_f32 calls -- the results are bitwise those, whatever pitch the outputs use."""
+    from geographconv_amd import ops
+    dA = ops.DMat.from_numpy(_rand((M, K), 1), dev)
+    dB0, dB1 = ops.DMat.from_numpy(_rand((K, N0), 2), dev), ops.DMat.from_numpy(_rand((K, N1), 3), dev)
+    b1 = torch.from_numpy(np.pad(_rand((N1,), 4), (0, ops.pad4(N1) - N1))).to(dev)
+    z = ops.DMat.empty(M, N0, dev, ld=ops.gather_ld(N0))
+    z.t.fill_(7.0)
+    z_ref = ops.gemm(dA, dB0)
+    t_ref = ops.gemm(dA, dB1, bias=b1, act=ops.ACT_SIGMOID)
+    z2, t2 = ops.gemm_dual(dA, dB0, dB1, out0=z, bias1=b1, act1=ops.ACT_SIGMOID)
+    assert z2 is z
+    assert torch.equal(z.t[:, :ops.pad4(N0)], z_ref.t[:, :ops.pad4(N0)])      # pad columns up to roundup4 written as zeros
+    assert torch.equal(t2.t, t_ref.t)
+    # both linear, with and without biases
+    b0 = torch.from_numpy(np.pad(_rand((N0,), 5), (0, ops.pad4(N0) - N0))).to(dev)
+    c0, c1 = ops.gemm_dual(dA, dB0, dB1, bias0=b0, act0=ops.ACT_TANH, act1=ops.ACT_TANH)
+    assert torch.equal(c0.t, ops.gemm(dA, dB0, bias=b0, act=ops.ACT_TANH).t)
+    assert torch.equal(c1.t, ops.gemm(dA, dB1, act=ops.ACT_TANH).t)
+    with pytest.raises(Exception):
+        ops.gemm_dual(dA, dB0, dB1, act0=ops.ACT_TANH, act1=ops.ACT_SIGMOID)
+
+
+@pytest.mark.parametrize("R,M,N0,N1", [(5000, 300, 300, 300), (4097, 300, 256, 300), (3333, 600, 600, 600), (20000, 64, 8, 40),
+                                      (0, 300, 300, 300)])
+def test_gemm_dual_transposed_equals_two_calls_bitwise(dev, R, M, N0, N1):
+    """(dWh, dWt) = H^T . [dZ | dU] in one pass over H: same split-K slices and the same ordered slab combine as two
+    calls => bitwise equal, deterministic; an empty reduction (a rank without rows) gives zeros."""
+    from geographconv_amd import ops
+    dA = ops.DMat.from_numpy(_rand((R, M), 1), dev) if R else ops.DMat(0, M, dev)
+    dB0 = ops.DMat.from_numpy(_rand((R, N0), 2), dev) if R else ops.DMat(0, N0, dev)
+    dB1 = ops.DMat.from_numpy(_rand((R, N1), 3), dev) if R else ops.DMat(0, N1, dev)
+    o0, o1 = ops.DMat(M, N0, dev), ops.DMat(M, N1, dev)
+    o0.t.fill_(3.0)
+    o1.t.fill_(3.0)
+    ops.gemm_dual(dA, dB0, dB1, out0=o0, out1=o1, transA=True)
+    if R == 0:
+        assert torch.all(o0.t[:, :N0] == 0) and torch.all(o1.t[:, :N1] == 0)
+        return
+    r0, r1 = ops.gemm(dA, dB0, transA=True), ops.gemm(dA, dB1, transA=True)
+    # the split-K plan of the dual launch covers twice the tiles: slices may differ from the single call's, so
+    # compare within the fp32 envelope, and bitwise against a second dual launch
+    A, B0, B1 = dA.numpy().astype(np.float64), dB0.numpy().astype(np.float64), dB1.numpy().astype(np.float64)
+    for got, B in ((o0, B0), (o1, B1)):
+        ref = A.T @ B
+        assert np.all(np.abs(got.numpy() - ref) <= 3e-6 * (np.abs(A).T @ np.abs(B)) + 1e-5)
+    assert np.allclose(o0.numpy(), r0.numpy(), rtol=0, atol=1e-4) and np.allclose(o1.numpy(), r1.numpy(), rtol=0, atol=1e-4)
+    p0, p1 = ops.gemm_dual(dA, dB0, dB1, transA=True)
+    assert torch.equal(p0.t, o0.t) and torch.equal(p1.t, o1.t)
+    assert torch.all(o0.t[:, N0:] == 0) and torch.all(o1.t[:, N1:] == 0)
+
+
+@pytest.mark.parametrize("M,N,K0,K1", [(1000, 300, 300, 300), (4100, 600, 600, 600), (777, 300, 129, 300), (333, 16, 40, 64),
+                                      (70000, 300, 300, 300)])
+def test_gemm_kcat_two_products_one_accumulator(dev, M, N, K0, K1):
+    """dH = dZ . Wh^T + dU . Wt^T [+ carry] as ONE contraction over K0 + K1 (geogcn_gemm_kcat_f32)."""
+    from geographconv_amd import ops
+    A0, A1 = _rand((M, K0), 1), _rand((M, K1), 2)
+    B0, B1 = _rand((N, K0), 3), _rand((N, K1), 4)           # weights as stored: n_in x n_out = N x K
+    C0 = _rand((M, N), 5)
+    dA0, dA1 = ops.DMat.from_numpy(A0, dev), ops.DMat.from_numpy(A1, dev)
+    dB0, dB1 = ops.DMat.from_numpy(B0, dev), ops.DMat.from_numpy(B1, dev)
+    ref = A0.astype(np.float64) @ B0.astype(np.float64).T + A1.astype(np.float64) @ B1.astype(np.float64).T
+    tol = 2e-6 * (np.abs(A0) @ np.abs(B0).T + np.abs(A1) @ np.abs(B1).T) + 1e-6
+    got = ops.gemm_kcat(dA0, dB0, dA1, dB1, transB=True)
+    assert np.all(np.abs(got.numpy() - ref) <= tol)
+    assert torch.all(got.t[:, N:] == 0)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm_kcat(dA0, dB0, dA1, dB1, out=dC, transB=True, accumulate=True)
+    assert np.all(np.abs(dC.numpy() - (ref + C0)) <= tol + 1e-6)
+    assert torch.equal(ops.gemm_kcat(dA0, dB0, dA1, dB1, transB=True).t, got.t)           # deterministic
+    # NN form
+    dB0n, dB1n = ops.DMat.from_numpy(np.ascontiguousarray(B0.T), dev), ops.DMat.from_numpy(np.ascontiguousarray(B1.T), dev)
+    got = ops.gemm_kcat(dA0, dB0n, dA1, dB1n)
+    assert np.all(np.abs(got.numpy() - ref) <= tol)
+
+
 def test_gemm_asymmetric_detects_transposes(dev):
     """A = I check with an asymmetric B (guide rule: symmetric inputs hide row/col swaps)."""
     from geographconv_amd import ops
