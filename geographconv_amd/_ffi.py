@@ -28,6 +28,12 @@ SIGNATURES = {
     'geogcn_spmm_workspace_bytes': (c_sz, [c_ptr, c_i32]),
     'geogcn_spmm_csr_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                     c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_spmm_csr_acc_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                        c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_xt_plan_create': (c_i32, [c_i32, c_i32, c_ptr, c_ptr, c_i32, C.POINTER(c_ptr)]),
+    'geogcn_xt_plan_destroy': (None, [c_ptr]),
+    'geogcn_xt_workspace_bytes': (c_sz, [c_ptr]),
+    'geogcn_xt_dot_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_sz, c_ptr]),
     'geogcn_spmm_csr_bf16b': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                       c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_cast_bf16_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),

@@ -191,6 +191,8 @@ struct HwArgs {
     const float* H;
     float* Hout;
     int64_t ld;          // common pitch of T, H, Hout
+    const float* init;   // nullable: the accumulators start from init[row][:] (pitch ld_init) instead of zero --
+    int64_t ld_init;     // C = act(C0 + A.B + bias): a product that continues one already in C (X.W0: dense head + tail)
 };
 __device__ __forceinline__ float4 highway_mix(const float4 t, const float4 hc, const float4 h) {
     return make_float4(t.x * hc.x + (1.0f - t.x) * h.x, t.y * hc.y + (1.0f - t.y) * h.y,
@@ -234,6 +236,14 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     const int e = rowptr[row + 1];
     if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks
     const int h = rowsplit ? rowsplit[row] : e;
+    if (hw.init) {
+        const float4* irow = reinterpret_cast<const float4*>(hw.init + (int64_t)row * hw.ld_init);
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int q = f4_index<G, BF>(lane16, k);
+            if (q < nF4) acc[k] = irow[q];
+        }
+    }
     group_accumulate<K4, 0, G, BF>(s, h, lane16, nF4, colidx, val, B, ldb, acc);
     group_accumulate<K4, NTT, G, BF>(h, e, lane16, nF4, colidx, val, B, ldb, acc);
     float4* out = reinterpret_cast<float4*>(C + (int64_t)row * ldc);
@@ -286,6 +296,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(
         __syncthreads();
         if (cg == 0 && col < Fpad) {
             acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            if (hw.init) acc += hw.init[(int64_t)row * hw.ld_init + col];
             float o = 0.f;
             if (col < F) {
                 if (bias) acc += bias[col];
@@ -426,7 +437,7 @@ template <int BF>
 int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
                   const int32_t* rowptr, const int32_t* colidx, const float* val, const void* B, int64_t ldb,
                   float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* ws, size_t ws_bytes,
-                  void* stream, const HwArgs hw = HwArgs{nullptr, nullptr, nullptr, 0}) {
+                  void* stream, const HwArgs hw = HwArgs{nullptr, nullptr, nullptr, 0, nullptr, 0}) {
     GEOGCN_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && F >= 0, GEOGCN_E_SIZE,
                    "%s: negative size", fn);
     if (n_rows == 0 || F == 0) return 0;
@@ -480,7 +491,7 @@ int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, 
     const bool vec_ok = (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
                         ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && F4 <= 16 * 16;      // F <= 1024
     if (!vec_ok) {
-        GEOGCN_REQUIRE(!hw.T, GEOGCN_E_ALIGN, "%s: the highway epilogue needs float4-addressable operands", fn);
+        GEOGCN_REQUIRE(!hw.T && !hw.init, GEOGCN_E_ALIGN, "%s: the highway / accumulate forms need float4-addressable operands", fn);
         const dim3 grid((unsigned)cdiv(n_rows, kBlock / kWave));
 #define GEOGCN_SC(ACT)                                                                              \
     hipLaunchKernelGGL((spmm_scalar_kernel<ACT>), grid, dim3(kBlock), 0, st, n_rows, rowptr, colidx, \
@@ -679,12 +690,22 @@ int geogcn_spmm_csr_highway_f32(const geogcn_spmm_plan* plan, int32_t n_rows, in
     GEOGCN_REQUIRE(ld % 4 == 0 && ld >= (int64_t)((F + 3) / 4) * 4 && aligned16(T) && aligned16(H) && aligned16(Hout),
                    GEOGCN_E_ALIGN, "spmm_csr_highway_f32: T, H, Hc, Hout need 16-byte bases and a pitch %% 4 == 0 (ld=%lld)",
                    (long long)ld);
-    const HwArgs hw{T, H, Hout, ld};
+    const HwArgs hw{T, H, Hout, ld, nullptr, 0};
     if (b_bf16)
         return spmm_csr_impl<1>("spmm_csr_highway_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, Hc, ld, F,
                                 bias, GEOGCN_ACT_TANH, ws, ws_bytes, stream, hw);
     return spmm_csr_impl<0>("spmm_csr_highway_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, Hc, ld, F,
                             bias, GEOGCN_ACT_TANH, ws, ws_bytes, stream, hw);
+}
+
+// C = act(C + A.B + bias): the accumulators start from the row already in C
+int geogcn_spmm_csr_acc_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                            const int32_t* rowptr, const int32_t* colidx, const float* val, const float* B, int64_t ldb,
+                            float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* ws, size_t ws_bytes,
+                            void* stream) {
+    const HwArgs hw{nullptr, nullptr, nullptr, 0, C, ldc};
+    return spmm_csr_impl<0>("spmm_csr_acc_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, C, ldc, F, bias,
+                            act, ws, ws_bytes, stream, hw);
 }
 
 int geogcn_spmm_csr_bf16b(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,

@@ -298,7 +298,7 @@ class DenseLayer(Layer):
             elif isinstance(input, K.DMat):
                 y = K.gemm(input, self.W.data, bias=bias, act=act, precision=prec)   # bias + act fused
             else:
-                y = K.spmm(input.fwd, self.W.data, bias=bias, act=act)    # sparse input: X.W0
+                y = K.spmm_x(input, self.W.data, bias=bias, act=act)      # sparse input: X.W0
         else:
             comm = kwargs.get('comm')
             if comm is None:
@@ -396,7 +396,8 @@ class DenseLayer(Layer):
         elif self.nonlinearity.act == 0:
             dS = grad
         else:
-            uses_graph = self._uses_graph(kwargs) and kwargs.get('A') is not None
+            # (dS is gathered row-wise by the next product -- A^T . dS, or X^T . dS0 under a sparse input: line-aligned pitch)
+            uses_graph = (self._uses_graph(kwargs) and kwargs.get('A') is not None) or not isinstance(tape[self]['x'], K.DMat)
             km, sc = (grad.keep_mask, grad.scale) if isinstance(grad, Masked) else (None, 1.0)
             g_in = grad.m if isinstance(grad, Masked) else grad
             out = K.DMat.empty(g_in.n, g_in.F, g_in.device, ld=K.gather_ld(g_in.F)) if uses_graph else None

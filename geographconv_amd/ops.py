@@ -210,6 +210,7 @@ class CSR:
                 rowsplit = np.ascontiguousarray(indptr[:-1] + hub_per_row, dtype=np.int32)
                 self.n_hubs = k
         self.rowptr_host = indptr
+        self.colidx_host = indices          # (host copy: plan builders walk the structure, e.g. geogcn_xt_plan_create)
         self.rowptr = torch.from_numpy(indptr).to(device)
         self.colidx = torch.from_numpy(indices).to(device)
         self.val = torch.from_numpy(data).to(device)
@@ -233,18 +234,23 @@ class CSR:
             pass
 
 
-def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None):
+def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None, accumulate=False):
     """out = act(A . B + bias)  -- S.structured_dot (reference gcnmodel.py:39,130,153).  B is a DMat, or an
-    HMat (bf16 gathered operand, fp32 accumulation) in the bf16 configuration."""
+    HMat (bf16 gathered operand, fp32 accumulation) in the bf16 configuration.  accumulate: out = act(out + A . B + bias)."""
     lib = _ffi.lib()
     F = B.F if F is None else F
     if B.n != A.shape[1]:
         raise ValueError("spmm: A is %s but B has %d rows" % (A.shape, B.n))
     if out is None:
+        if accumulate:
+            raise ValueError("spmm: accumulate needs an existing output")
         out = DMat.empty(A.shape[0], F, B.device)
     need = lib.geogcn_spmm_workspace_bytes(A._plan, F)
     ws = A._ws.get(need)
+    if accumulate and isinstance(B, HMat):
+        raise ValueError("spmm: the accumulate form takes an fp32 operand")
     fn, name = ((lib.geogcn_spmm_csr_bf16b, 'spmm_csr_bf16b') if isinstance(B, HMat)
+                else (lib.geogcn_spmm_csr_acc_f32, 'spmm_csr_acc_f32') if accumulate
                 else (lib.geogcn_spmm_csr_f32, 'spmm_csr_f32'))
     check(fn(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), _p(B.t), B.ld,
              _p(out.t), out.ld, F, _p(bias), act, _p(ws), ws.numel(), _stream()), name)
@@ -544,20 +550,43 @@ DENSE_HEAD_DENSITY = 0.035
 DENSE_HEAD_MAX_COLS = 512
 
 
+# A bag-of-words X is multiplied in two parts when its column distribution is Zipfian: the columns denser than
+# DENSE_HEAD_DENSITY as a dense N x K panel on the MFMA pipe, the long tail as CSR.  The transposed tail product goes
+# through the document-blocked kernel (geogcn_xt_dot_f32) from XT_MIN_NNZ stored tail entries on (below that dS0 sits
+# in the L2 / Infinity Cache anyway and the plain row gather is as fast).
+XT_MIN_NNZ = int(os.environ.get('GEOGCN_XT_MIN_NNZ', 1_000_000))
+# forward X.W0: the tail's W0 rows are gathered in column slabs of this many floats so that the slab (n_tail_words x
+# slab x 4 bytes) stays inside one XCD's 4 MB L2; 0 = one pass over all columns
+X_FWD_SLAB = int(os.environ.get('GEOGCN_X_FWD_SLAB', 0))
+
+
 class SparseOperand:
     """A constant sparse matrix as the path uses it: ``fwd`` multiplies it (A . B) and ``bwd``
     multiplies its transpose (A^T . G, the StructuredDot gradient).  For the normalised adjacency
     of an unweighted graph A^T == A exactly in fp32 (checked here, not assumed), so
     one CSR serves both directions; otherwise CSR(A^T) is built once on the host.
 
-    For a bag-of-words X (Zipfian columns) the transpose product X^T . G is split: the few columns
-    denser than DENSE_HEAD_DENSITY become a dense N x K panel multiplied by the split-K MFMA GEMM,
-    the long tail stays a CSR gather (`bwd` then holds only the tail rows of X^T)."""
+    For a bag-of-words X (Zipfian columns) both products are split: the few columns denser than
+    DENSE_HEAD_DENSITY form a dense N x K panel (``head_dense``) multiplied on the MFMA pipe -- X^T . G by the
+    split-K GEMM, X . W by a GEMM against the K gathered rows of W -- and the long tail stays sparse:
+    ``bwd`` holds the tail rows of X^T (head rows empty), ``fwd_tail`` the tail columns of X."""
 
-    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool, head_idx=None, head_dense=None):
+    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool, head_idx=None, head_dense=None, fwd_tail: CSR = None):
         self.fwd, self.bwd, self.symmetric = fwd, bwd, symmetric
-        self.head_idx, self.head_dense = head_idx, head_dense
+        self.head_idx, self.head_dense, self.fwd_tail = head_idx, head_dense, fwd_tail
         self.shape = fwd.shape
+        self._xt_plans = {}
+
+    def xt_plan(self, F):
+        """Plan of the document-blocked X^T . G kernel for width F (built on first use; None when the tail is small)."""
+        if self.bwd is None or self.symmetric or self.bwd.nnz < XT_MIN_NNZ:
+            return None
+        base = getattr(self.bwd, '_base', self.bwd)           # value-dropout variants share the structure's plans
+        plans = base._xt_plans if hasattr(base, '_xt_plans') else self._xt_plans
+        plan = plans.get(int(F))
+        if plan is None:
+            plan = plans[int(F)] = XtPlan(base, F)
+        return plan
 
     @staticmethod
     def from_scipy(m, device, need_transpose=True, long_row_nnz=None, chunk_nnz=None, dense_head=True,
@@ -575,7 +604,7 @@ class SparseOperand:
                    and np.array_equal(mt.data, m.data))
         if sym:
             return SparseOperand(fwd, fwd, True)
-        head_idx = head_dense = None
+        head_idx = head_dense = fwd_tail = None
         if dense_head and m.shape[0] > 0:
             col_nnz = np.diff(mt.indptr)
             cand = np.nonzero(col_nnz >= DENSE_HEAD_DENSITY * m.shape[0])[0]
@@ -593,8 +622,37 @@ class SparseOperand:
                 mt = sps.csr_matrix(mt)
                 mt.eliminate_zeros()
                 mt.sort_indices()
+                # the same tail, row-major: X with the head columns removed (stored order = column order, as in X)
+                sel = keep[m.indices]
+                row_of = np.repeat(np.arange(m.shape[0], dtype=np.int64), np.diff(m.indptr))
+                indptr = np.concatenate([[0], np.cumsum(np.bincount(row_of[sel], minlength=m.shape[0]))]).astype(np.int32)
+                tail = sps.csr_matrix((m.data[sel], m.indices[sel], indptr), shape=m.shape)
+                # (rows of X are short: no row splitting, so the accumulate form starts every row from the GEMM's value)
+                fwd_tail = CSR(tail, device, long_row_nnz=1 << 30, chunk_nnz=128)
         bwd = CSR(mt, device, long_row_nnz, chunk_nnz, hub_row_bytes=hub_row_bytes if head_dense is None else None)
-        return SparseOperand(fwd, bwd, False, head_idx, head_dense)
+        bwd._xt_plans = {}
+        return SparseOperand(fwd, bwd, False, head_idx, head_dense, fwd_tail)
+
+
+class XtPlan:
+    """geogcn_xt_plan of one CSR(X^T) structure and output width (include/geogcn.h)."""
+
+    def __init__(self, csr_t: CSR, F: int):
+        self._h = C.c_void_p(0)
+        lib = _ffi.lib()
+        check(lib.geogcn_xt_plan_create(csr_t.shape[0], csr_t.shape[1], csr_t.rowptr_host.ctypes.data_as(C.c_void_p),
+                                        csr_t.colidx_host.ctypes.data_as(C.c_void_p), int(F), C.byref(self._h)),
+              'xt_plan_create')
+        self.F = int(F)
+        self.ws_bytes = int(lib.geogcn_xt_workspace_bytes(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().geogcn_xt_plan_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
 
 
 class _CSRValues:
@@ -604,8 +662,8 @@ class _CSRValues:
     def __init__(self, base: CSR, val: torch.Tensor):
         self._base = base
         self.val = val
-        for k in ('shape', 'nnz', 'rowptr', 'colidx', 'rowptr_host', 'device', '_plan', '_ws', 'n_long_rows', 'n_chunks',
-                  'n_hubs'):
+        for k in ('shape', 'nnz', 'rowptr', 'colidx', 'rowptr_host', 'colidx_host', 'device', '_plan', '_ws', 'n_long_rows',
+                  'n_chunks', 'n_hubs'):
             setattr(self, k, getattr(base, k))
 
 
@@ -633,16 +691,62 @@ def sparse_dropout(x: SparseOperand, p, seed, call):
         head = DMat(x.head_dense.n, x.head_dense.F, x.head_dense.device, ld=x.head_dense.ld)
         check(lib.geogcn_dropout_panel_f32(head.n, head.F, _p(x.head_dense.t), head.ld, _p(x.head_idx), V, float(p), int(seed),
                                            int(call), _p(head.t), _stream()), 'dropout_panel_f32')
-    return SparseOperand(fwd, bwd, False, x.head_idx, head)
+    return SparseOperand(fwd, bwd, False, x.head_idx, head, None if x.fwd_tail is None else csr(x.fwd_tail, False))
 
 
 def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff)."""
-    out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)
+    plan = x.xt_plan(G.F)
+    if plan is not None:
+        # tail rows through the document-blocked kernel (every row written; head rows as zeros)
+        if out is None:
+            out = DMat.empty(x.bwd.shape[0], G.F, G.device)
+        w = _ws_for(G.device).get(plan.ws_bytes)
+        check(_ffi.lib().geogcn_xt_dot_f32(plan._h, _p(x.bwd.colidx), _p(x.bwd.val), _p(G.t), G.ld, _p(out.t), out.ld,
+                                           _p(w), w.numel(), _stream()), 'xt_dot_f32')
+    else:
+        out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)
     if x.head_dense is not None:
         head = gemm(x.head_dense, G, transA=True)  # K x F on the MFMA pipe, deterministic split-K
         scatter_rows(head, x.head_idx, out)
     return out
+
+
+def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE):
+    """out = act(x . W + bias) for a sparse input x (S.structured_dot(X, W0), reference gcnmodel.py:39-42).  With a
+    dense head panel: the K hot vocabulary rows of W are gathered into a K x F matrix and multiplied by the panel on the
+    MFMA pipe (raw product), then the CSR tail continues each row from that value (bias and activation in its epilogue)."""
+    if x.head_dense is None or x.fwd_tail is None or not X_SPLIT_FWD:
+        return spmm(x.fwd, W, out=out, bias=bias, act=act)
+    K = x.head_dense.F
+    Wh = DMat(K, W.F, W.device)
+    gather_rows(W, x.head_idx, out=Wh.t)
+    out = gemm(x.head_dense, Wh, out=out, precision='f32')
+    if X_FWD_SLAB and W.F > X_FWD_SLAB:
+        # column slabs: the tail's slab of W (n_words x slab x 4 B) stays inside one XCD's L2 across the sweep
+        for c0 in range(0, W.F, X_FWD_SLAB):
+            c1 = min(W.F, c0 + X_FWD_SLAB)
+            _spmm_cols(x.fwd_tail, W, out, bias, act, c0, c1)
+        return out
+    return spmm(x.fwd_tail, W, out=out, bias=bias, act=act, accumulate=True)
+
+
+def _spmm_cols(A: CSR, B: DMat, out: DMat, bias, act, c0, c1):
+    """out[:, c0:c1] = act(out[:, c0:c1] + A . B[:, c0:c1] + bias[c0:c1]) -- a column window of the accumulate form
+    (c0 % 4 == 0: the window starts on a float4)."""
+    lib = _ffi.lib()
+    F = c1 - c0
+    ws = A._ws.get(lib.geogcn_spmm_workspace_bytes(A._plan, F))
+    bptr = C.c_void_p(B.t.data_ptr() + 4 * c0)
+    optr = C.c_void_p(out.t.data_ptr() + 4 * c0)
+    biasp = C.c_void_p(bias.data_ptr() + 4 * c0) if bias is not None else C.c_void_p(0)
+    check(lib.geogcn_spmm_csr_acc_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), bptr, B.ld,
+                                      optr, out.ld, F, biasp, act, _p(ws), ws.numel(), _stream()), 'spmm_csr_acc_f32')
+    return out
+
+
+# GEOGCN_X_SPLIT_FWD = 1 (default) | 0: X . W0 as dense head panel + CSR tail (A/B switch)
+X_SPLIT_FWD = os.environ.get('GEOGCN_X_SPLIT_FWD', '1') != '0'
 
 
 class SpmmTimer:

@@ -71,6 +71,30 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
                         const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
                         const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
 
+/* C = act(C + A_csr . B + bias): the accumulators start from the row already in C (a product that continues one begun
+ * by another kernel -- X.W0 as dense head panel on the MFMA pipe + CSR tail, gcnmodel.py:39).  Same kernel, same order
+ * (C's value first, then the stored nonzeros in index order).  Needs float4-addressable operands (GEOGCN_E_ALIGN).  */
+int geogcn_spmm_csr_acc_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                            const int32_t* rowptr, const int32_t* colidx, const float* val, const float* B, int64_t ldb,
+                            float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* dW[n_words x F] = X^T . G  -- the gradient of S.structured_dot(X, W0) w.r.t. W0 (autodiff of gcnmodel.py:39) for a
+ * bag-of-words X whose transpose is given as CSR (rows = vocabulary, columns = documents, sorted).  Instead of gathering
+ * rows of the N x F matrix G at random (every row fetched ~nnz/N times from beyond the L2), the documents are
+ * partitioned over 8 groups of workgroups (one per XCD) that sweep their range in L2-sized blocks while each 16-lane
+ * group accumulates a fixed set of vocabulary rows in LDS; the 8 partial results per row are added in fixed order.
+ * Deterministic, no atomics.  The plan (host-built once per X^T and F: row-to-workgroup assignment balanced by
+ * nonzeros, per-range entry points) is independent of the VALUES, so value dropout on X re-uses it.
+ * Every row of dW is written (rows without nonzeros as zeros; pad columns [F, roundup4(F)) as zeros).           */
+typedef struct geogcn_xt_plan geogcn_xt_plan;
+int    geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr_t_host, const int32_t* docidx_t_host,
+                             int32_t F, geogcn_xt_plan** out);
+void   geogcn_xt_plan_destroy(geogcn_xt_plan* plan);
+size_t geogcn_xt_workspace_bytes(const geogcn_xt_plan* plan);
+int    geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const float* val_t, const float* G, int64_t ldg,
+                         float* dW, int64_t ldw, void* ws, size_t ws_bytes, void* stream);
+
 /* Reduced-precision variant for the bf16 configuration (BASELINE config 5, `-gemm-precision bf16`; no
  * reference counterpart -- the reference is fp32 throughout): the GATHERED operand B is stored as
  * bfloat16 (raw uint16 bit patterns, row pitch ldb ELEMENTS), everything else -- CSR values, products,

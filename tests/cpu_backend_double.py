@@ -70,6 +70,10 @@ def spmm_t(x, G, out=None):
     return spmm(x.bwd, G, out=out)
 
 
+def spmm_x(x, W, out=None, bias=None, act=ACT_NONE):
+    return spmm(x.fwd, W, out=out, bias=bias, act=act)
+
+
 def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None):
     a = _v(A).T if transA else _v(A)
     b = _v(B).T if transB else _v(B)

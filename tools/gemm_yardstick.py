@@ -74,3 +74,22 @@ for name, fn in [
     t = timed(fn)
     print("%-30s %.3f ms (%.1f TF)" % (name, t, flops / t / 1e9))
 
+
+# fused highway launches (geogcn_gemm_dual_f32 / geogcn_gemm_kcat_f32) next to the pairs of calls they replace
+W2 = ops.DMat.from_numpy((rng.randn(F, F) * 0.05).astype(np.float32), dev)
+U = ops.DMat.from_numpy(rng.randn(N, F).astype(np.float32), dev)
+T = ops.DMat.empty(N, F, dev)
+bt = torch.full((ops.pad4(F),), -4.0, device=dev)
+dW2 = ops.DMat.empty(F, F, dev)
+for name, fn, nprod in [
+    ('fwd pair  Z=H.Wh ; T=sig(H.Wt+bt)', lambda: (ops.gemm(H, W, out=Z320), ops.gemm(H, W2, out=T, bias=bt, act=ops.ACT_SIGMOID)), 2),
+    ('fwd dual  [Wh|Wt] one launch', lambda: ops.gemm_dual(H, W, W2, out0=Z320, out1=T, bias1=bt, act1=ops.ACT_SIGMOID), 2),
+    ('dW pair   H^T.dZ ; H^T.dU', lambda: (ops.gemm(H, Z, out=dW, transA=True), ops.gemm(H, U, out=dW2, transA=True)), 2),
+    ('dW dual   H^T.[dZ|dU] one launch', lambda: ops.gemm_dual(H, Z, U, out0=dW, out1=dW2, transA=True), 2),
+    ('dH pair   += dZ.Wh^T ; += dU.Wt^T', lambda: (ops.gemm(Z, W, out=T, transB=True, accumulate=True),
+                                                  ops.gemm(U, W2, out=T, transB=True, accumulate=True)), 2),
+    ('dH kcat   += [dZ|dU].[Wh|Wt]^T', lambda: ops.gemm_kcat(Z, W, U, W2, out=T, transB=True, accumulate=True), 2),
+]:
+    T.t.zero_()
+    t = timed(fn)
+    print("%-38s %.3f ms (%.1f TF)" % (name, t, nprod * flops / t / 1e9))
