@@ -523,7 +523,13 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
                            int64_t ld, float* dS, int64_t ld_dS, float* dU, float* dHcarry, float* dbS, float* dbU,
                            void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "highway_bwd_f32: negative size");
-    if (n == 0 || F == 0) return 0;
+    if (F == 0) return 0;
+    if (n == 0) {
+        // a rank that owns no rows: its share of the bias gradients is the zero vector (not last step's values)
+        if (dbS) { const int rc = zero_fill_async(dbS, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream); if (rc) return rc; }
+        if (dbU) { const int rc = zero_fill_async(dbU, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream); if (rc) return rc; }
+        return 0;
+    }
     CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU, dHcarry);
     GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= ld, GEOGCN_E_ALIGN, "highway_bwd_f32: ld_dS=%lld must be a multiple of 4, >= ld",
                    (long long)ld_dS);
@@ -731,7 +737,8 @@ int geogcn_act_bwd_colsum_f32(int64_t n, int32_t F, const float* G, const float*
                               size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "act_bwd_colsum_f32: negative size");
     GEOGCN_REQUIRE(db, GEOGCN_E_NULL, "act_bwd_colsum_f32: null db");
-    if (n == 0 || F == 0) return 0;
+    if (F == 0) return 0;
+    if (n == 0) return zero_fill_async(db, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream);      // empty row share: db = 0
     const int64_t F4 = (F + 3) / 4;
     const bool fused = (act == GEOGCN_ACT_TANH || act == GEOGCN_ACT_SIGMOID || act == GEOGCN_ACT_NONE) && ld == F4 * 4 &&
                        F4 <= TPB;

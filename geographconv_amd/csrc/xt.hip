@@ -7,7 +7,8 @@
 // are partitioned instead of streamed at random:
 //   * the grid is 8 "virtual XCDs" x `slots` workgroups (block b runs on XCD b % 8 -- a speed assumption only,
 //     nothing below depends on it for correctness);  virtual XCD x owns the contiguous document range
-//     [doc_lo[x], doc_lo[x+1]) and sweeps it in blocks of kDocBlock rows (~2.5 MB of dS0: L2 sized);
+//     [doc_lo[x], doc_lo[x+1]) and sweeps it in blocks of `doc_block` rows (1024 rows = 1.3 MB of dS0: a third of
+//     the XCD's L2, so that sweepers one or two blocks apart still share it);
 //   * the vocabulary rows are dealt out to `slots * n_batches` bins, balanced by nonzeros AND by count;  in
 //     batch r, slot c accumulates the rows of bin (r, c): every 16-lane group owns a fixed subset of the bin's
 //     rows (row j -> group j % 16) and keeps one LDS accumulator row per owned word.  For each document
@@ -29,13 +30,21 @@ namespace geogcn {
 namespace {
 
 constexpr int kGroup = 16;
-constexpr int kBlock = 256;
-constexpr int kGroupsPerBlock = kBlock / kGroup;
-constexpr int kDocBlock = 2048;
-// LDS accumulator rows per workgroup and workgroups per virtual XCD: narrow rows (K4 <= 6, <= 128 VGPRs) run four
-// workgroups per CU (more gathers in flight), wide ones two
-constexpr int lds_budget(int K4) { return (K4 <= 6 ? 36 : 72) * 1024; }
-constexpr int slots_for(int K4) { return K4 <= 6 ? 128 : 64; }
+constexpr int kBlock = 256;              // combine kernel
+// The sweep kernel runs ONE workgroup per CU (32 per virtual XCD): the fewer independent sweepers an XCD has, the
+// closer together they stay inside the L2 window.  Narrow rows (K4 <= 6: <= 128 VGPRs) use 1024 threads = 64 groups,
+// wide ones 512 threads.  Inside a workgroup the groups are held together by a barrier per document block.
+constexpr int kSlots = 32;
+constexpr int wg_threads(int K4) { return K4 <= 6 ? 1024 : 512; }
+constexpr int kLdsBudget = 150 * 1024;
+inline int doc_block_rows() {
+    static const int v = [] {
+        const char* e = getenv("GEOGCN_XT_DOC_BLOCK");
+        const int b = e ? atoi(e) : 0;
+        return b > 0 ? b : 1024;
+    }();
+    return v;
+}
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -59,13 +68,20 @@ struct XtArgs {
     const int* bin_words;       // vocabulary row of position p
     const int* wptr;            // [9][n_words]: first nonzero of word w with doc >= doc_lo[x]
     const int* doc_lo;          // [9]
-    int n_words, slots, n_batches, cap;
+    int n_words, slots, n_batches, cap, doc_block;
     float* partial; int64_t ldp;        // [8][n_pos][ldp]
     int64_t n_pos;
+    // soft per-XCD rendezvous (nullable): arrive[(x * n_batches + r) * max_blocks + blk] counts the workgroups of
+    // virtual XCD x that have ENTERED block blk of batch r.  A workgroup enters block blk + 2 only once all of them
+    // have entered block blk -- with a bounded wait: results never depend on it, it only keeps the sweepers inside
+    // a two-block window of dS0 so that the window stays in the XCD's L2.
+    unsigned* arrive;
+    int max_blocks, spin_limit;
 };
 
 template <int K4>
-__global__ __launch_bounds__(kBlock, (K4 <= 6) ? 4 : 2) void xt_tail_kernel(const XtArgs a) {
+__global__ __launch_bounds__(wg_threads(K4), 1) void xt_tail_kernel(const XtArgs a) {
+    constexpr int kGroupsPerBlock = wg_threads(K4) / kGroup;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* acc_lds = reinterpret_cast<float4*>(smem_raw);                       // [cap][K4 * 16]
     int* cur = reinterpret_cast<int*>(smem_raw + (size_t)a.cap * K4 * kGroup * sizeof(float4));      // [cap]
@@ -88,8 +104,23 @@ __global__ __launch_bounds__(kBlock, (K4 <= 6) ? 4 : 2) void xt_tail_kernel(cons
 #pragma unroll
             for (int k = 0; k < K4; ++k) acc_lds[(j * K4 + k) * kGroup + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int b0 = d0; b0 < d1; b0 += kDocBlock) {
-            const int be = min(d1, b0 + kDocBlock);
+        __syncthreads();
+        int blk = 0;
+        for (int b0 = d0; b0 < d1; b0 += a.doc_block, ++blk) {
+            const int be = min(d1, b0 + a.doc_block);
+            if (a.arrive) {
+                if (threadIdx.x == 0) {
+                    unsigned* base = a.arrive + ((int64_t)x * a.n_batches + r) * a.max_blocks;
+                    __hip_atomic_fetch_add(base + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (blk >= 2) {
+                        int spins = 0;
+                        while (__hip_atomic_load(base + blk - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.slots &&
+                               ++spins < a.spin_limit)
+                            __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
+            __syncthreads();          // the groups of a workgroup move through the document blocks together
             for (int j = g; j < nw; j += kGroupsPerBlock) {
                 int s = cur[j];
                 const int e = endp[j];
@@ -198,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void xt_combine_kernel(int n_words, int F, 
 
 struct geogcn_xt_plan {
     int32_t n_words = 0, n_docs = 0, F = 0, K4 = 0;
-    int32_t slots = 0, n_batches = 0, cap = 0;
+    int32_t slots = 0, n_batches = 0, cap = 0, doc_block = 0, max_blocks = 0;
     int64_t n_pos = 0, nnz = 0;
     int* d_bin_start = nullptr;
     int* d_bin_words = nullptr;
@@ -223,7 +254,8 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
     plan->K4 = (int)cdiv(cdiv(F, 4), kGroup);
     plan->nnz = rowptr_t_host[n_words];
     const int row_bytes = plan->K4 * kGroup * (int)sizeof(float4);
-    plan->cap = std::max(1, (lds_budget(plan->K4) - 1024) / (row_bytes + 8));
+    plan->cap = std::max(1, (kLdsBudget - 1024) / (row_bytes + 8));
+    plan->doc_block = doc_block_rows();
     // words with nonzeros, heaviest first
     std::vector<int> words;
     for (int w = 0; w < n_words; ++w) {
@@ -234,7 +266,7 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
         return rowptr_t_host[p + 1] - rowptr_t_host[p] > rowptr_t_host[q + 1] - rowptr_t_host[q];
     });
     const int64_t nw = (int64_t)words.size();
-    plan->slots = slots_for(plan->K4);                   // x 8 virtual XCDs = 512 / 1024 workgroups = two / four per CU
+    plan->slots = kSlots;                                // x 8 virtual XCDs = 256 workgroups = one per CU
     plan->n_batches = (int)std::max<int64_t>(1, cdiv(nw, (int64_t)plan->slots * plan->cap));
     const int n_bins = plan->slots * plan->n_batches;
     // snake deal over the bins: equal counts (+-1) and near-equal nonzeros per bin
@@ -257,9 +289,12 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
     plan->n_pos = (int64_t)bin_words.size();
     // document ranges of the 8 virtual XCDs (multiples of the block size except the last) + per-word entry points
     std::vector<int> doc_lo(kNumXCD + 1);
-    const int64_t blocks = cdiv(n_docs, kDocBlock);
-    for (int x = 0; x <= kNumXCD; ++x) doc_lo[x] = (int)std::min<int64_t>(n_docs, (blocks * x / kNumXCD) * kDocBlock);
+    const int64_t blocks = cdiv(n_docs, plan->doc_block);
+    for (int x = 0; x <= kNumXCD; ++x) doc_lo[x] = (int)std::min<int64_t>(n_docs, (blocks * x / kNumXCD) * plan->doc_block);
     doc_lo[kNumXCD] = n_docs;
+    plan->max_blocks = 1;
+    for (int x = 0; x < kNumXCD; ++x)
+        plan->max_blocks = std::max<int>(plan->max_blocks, (int)cdiv(doc_lo[x + 1] - doc_lo[x], plan->doc_block));
     std::vector<int> wptr((size_t)(kNumXCD + 1) * std::max(1, n_words), 0);
     for (int w = 0; w < n_words; ++w) {
         const int32_t* b = docidx_t_host + rowptr_t_host[w];
@@ -294,9 +329,13 @@ void geogcn_xt_plan_destroy(geogcn_xt_plan* plan) {
     delete plan;
 }
 
+static size_t xt_arrive_bytes(const geogcn_xt_plan* plan) {
+    return (((size_t)kNumXCD * plan->n_batches * plan->max_blocks * sizeof(unsigned)) + 255) & ~(size_t)255;
+}
+
 size_t geogcn_xt_workspace_bytes(const geogcn_xt_plan* plan) {
     if (!plan || plan->n_pos == 0) return 0;
-    return (size_t)kNumXCD * (size_t)plan->n_pos * (size_t)(plan->K4 * kGroup * 4) * sizeof(float);
+    return xt_arrive_bytes(plan) + (size_t)kNumXCD * (size_t)plan->n_pos * (size_t)(plan->K4 * kGroup * 4) * sizeof(float);
 }
 
 int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const float* val_t, const float* G, int64_t ldg,
@@ -306,15 +345,26 @@ int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const
     const int F = plan->F, F4 = (F + 3) / 4;
     GEOGCN_REQUIRE(ldw % 4 == 0 && ldw >= (int64_t)F4 * 4 && aligned16(dW), GEOGCN_E_ALIGN, "xt_dot_f32: bad dW pitch / base");
     hipStream_t st = (hipStream_t)stream;
+    float* partial = nullptr;
     if (plan->n_pos > 0) {
         GEOGCN_REQUIRE(docidx_t && val_t && G, GEOGCN_E_NULL, "xt_dot_f32: null pointer");
         GEOGCN_REQUIRE(ldg % 4 == 0 && ldg >= (int64_t)F4 * 4 && aligned16(G), GEOGCN_E_ALIGN, "xt_dot_f32: bad G pitch / base");
         const size_t need = geogcn_xt_workspace_bytes(plan);
         GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "xt_dot_f32: workspace too small (%zu < %zu)",
                        ws_bytes, need);
+        static const int rendezvous = [] {
+            const char* e = getenv("GEOGCN_XT_RENDEZVOUS");       // 0 = free-running sweepers (A/B switch)
+            return (e && e[0] == '0') ? 0 : 1;
+        }();
+        unsigned* arrive = rendezvous ? (unsigned*)ws : nullptr;
+        if (arrive) {
+            const int zrc = zero_fill_async(arrive, xt_arrive_bytes(plan), st);
+            if (zrc) return zrc;
+        }
+        partial = (float*)((char*)ws + xt_arrive_bytes(plan));
         XtArgs a{docidx_t, val_t, G, ldg, F, plan->d_bin_start, plan->d_bin_words, plan->d_wptr, plan->d_doc_lo,
-                 plan->n_words, plan->slots, plan->n_batches, plan->cap, (float*)ws, (int64_t)plan->K4 * kGroup * 4,
-                 plan->n_pos};
+                 plan->n_words, plan->slots, plan->n_batches, plan->cap, plan->doc_block, partial,
+                 (int64_t)plan->K4 * kGroup * 4, plan->n_pos, arrive, plan->max_blocks, 4000};
         const size_t lds = (size_t)plan->cap * plan->K4 * kGroup * sizeof(float4) + (size_t)plan->cap * 2 * sizeof(int);
         const dim3 grid((unsigned)(kNumXCD * plan->slots));
         switch (plan->K4) {
@@ -323,10 +373,10 @@ int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const
         auto kern = xt_tail_kernel<K>;                                                                            \
         static bool attr_done = false;                                                                            \
         if (!attr_done) {                                                                                         \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_done = true;                                                                                     \
         }                                                                                                         \
-        hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, st, a);                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(wg_threads(K)), lds, st, a);                                          \
     } break;
             GEOGCN_XT(1) GEOGCN_XT(2) GEOGCN_XT(3) GEOGCN_XT(4) GEOGCN_XT(5) GEOGCN_XT(6) GEOGCN_XT(7) GEOGCN_XT(8)
             GEOGCN_XT(9) GEOGCN_XT(10) GEOGCN_XT(11) GEOGCN_XT(12) GEOGCN_XT(13) GEOGCN_XT(14) GEOGCN_XT(15) GEOGCN_XT(16)
@@ -340,7 +390,7 @@ int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const
     const int64_t total = (int64_t)plan->n_words * F4;
     const unsigned cgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, kBlock), (int64_t)kNumCU * 8));
     hipLaunchKernelGGL(xt_combine_kernel, dim3(cgrid), dim3(kBlock), 0, st, plan->n_words, F, F4, plan->d_pos_of_word,
-                       (const float*)ws, (int64_t)plan->K4 * kGroup * 4, plan->n_pos, dW, ldw);
+                       partial, (int64_t)plan->K4 * kGroup * 4, plan->n_pos, dW, ldw);
     GEOGCN_LAUNCH_CHECK("xt_combine_kernel");
     return 0;
 }

@@ -43,32 +43,35 @@ def load_obj(filename, serializer=pickle):
             return serializer.load(fin, encoding='latin1')
 
 
+EARTH_RADIUS_KM = 6371.0088          # mean earth radius used by the `haversine` package the reference imports (gcnmain.py:20)
+
+
+def haversine_km(lat1, lon1, lat2, lon2):
+    """Great-circle distances in km, elementwise over arrays of degrees."""
+    lat1, lon1, lat2, lon2 = (np.radians(np.asarray(v, dtype=np.float64)) for v in (lat1, lon1, lat2, lon2))
+    h = np.sin((lat2 - lat1) * 0.5) ** 2 + np.cos(lat1) * np.cos(lat2) * np.sin((lon2 - lon1) * 0.5) ** 2
+    return 2.0 * EARTH_RADIUS_KM * np.arcsin(np.sqrt(h))
+
+
 def haversine(p1, p2):
-    """Great-circle distance in km (the `haversine` package the reference imports, gcnmain.py:20;
-    mean earth radius 6371.0088 km)."""
-    lat1, lon1 = np.radians(p1[0]), np.radians(p1[1])
-    lat2, lon2 = np.radians(p2[0]), np.radians(p2[1])
-    d = np.sin((lat2 - lat1) * 0.5) ** 2 + np.cos(lat1) * np.cos(lat2) * np.sin((lon2 - lon1) * 0.5) ** 2
-    return float(2 * 6371.0088 * np.arcsin(np.sqrt(d)))
+    """Scalar form with the signature of the package function: haversine((lat, lon), (lat, lon)) -> km."""
+    return float(haversine_km(p1[0], p1[1], p2[0], p2[1]))
 
 
 def geo_eval(y_true, y_pred, U_eval, classLatMedian, classLonMedian, userLocation):
-    """Mean / median error km and Acc@161 (reference gcnmain.py:43-63)."""
-    assert len(y_pred) == len(U_eval), "#preds: %d, #users: %d" % (len(y_pred), len(U_eval))
-    distances, latlon_pred, latlon_true = [], [], []
-    for i in range(0, len(y_pred)):
-        user = U_eval[i]
-        location = userLocation[user].split(',')
-        lat, lon = float(location[0]), float(location[1])
-        latlon_true.append([lat, lon])
-        prediction = str(y_pred[i])
-        lat_pred, lon_pred = classLatMedian[prediction], classLonMedian[prediction]
-        latlon_pred.append([lat_pred, lon_pred])
-        distances.append(haversine((lat, lon), (lat_pred, lon_pred)))
-    acc_at_161 = 100 * len([d for d in distances if d < 161]) / float(len(distances))
-    logging.info("Mean: " + str(int(np.mean(distances))) + " Median: " + str(int(np.median(distances))) +
-                 " Acc@161: " + str(int(acc_at_161)))
-    return np.mean(distances), np.median(distances), acc_at_161, distances, latlon_true, latlon_pred
+    """Geolocation metrics of a set of predictions (what reference gcnmain.py:43-63 reports): distance between each
+    user's true coordinates ('lat,lon' strings in userLocation) and the median coordinates of the predicted class;
+    -> (mean km, median km, Acc@161, distances, [[lat, lon]] true, [[lat, lon]] predicted) and the same log line."""
+    n = len(y_pred)
+    assert n == len(U_eval), "#preds: %d, #users: %d" % (n, len(U_eval))
+    true = np.array([userLocation[u].split(',')[:2] for u in U_eval], dtype=np.float64).reshape(n, 2)
+    labels = [str(c) for c in y_pred]
+    pred = np.array([(classLatMedian[c], classLonMedian[c]) for c in labels], dtype=np.float64).reshape(n, 2)
+    km = haversine_km(true[:, 0], true[:, 1], pred[:, 0], pred[:, 1])
+    mean, median = np.mean(km), np.median(km)
+    acc_at_161 = 100 * float(np.count_nonzero(km < 161)) / float(n)
+    logging.info("Mean: " + str(int(mean)) + " Median: " + str(int(median)) + " Acc@161: " + str(int(acc_at_161)))
+    return mean, median, acc_at_161, km.tolist(), true.tolist(), pred.tolist()
 
 
 def synthetic_data(shape_name):
@@ -120,115 +123,138 @@ def setup_distributed(args):
     return torch.device('cuda', local), 'dist'
 
 
+class Splits:
+    """The 13-tuple of dump.pkl (reference gcnmain.py:153,170) as the training loop wants it: one stacked float32 CSR X,
+    one int32 label vector, float32 CSR A, and the row ranges of the train / dev / test users inside them."""
+
+    def __init__(self, data, dtype='float32', dtypeint='int32'):
+        (A, X_train, Y_train, X_dev, Y_dev, X_test, Y_test, self.U_train, self.U_dev, self.U_test,
+         self.classLatMedian, self.classLonMedian, self.userLocation) = data
+        self.dtypeint = dtypeint
+        parts_x, parts_y = [X_train, X_dev, X_test], (Y_train, Y_dev, Y_test)
+        self.X = sps.vstack(parts_x).tocsr().astype(dtype)
+        stack = np.hstack if np.ndim(Y_train) == 1 else np.vstack
+        self.Y = stack(parts_y).astype(dtypeint)
+        self.A = sps.csr_matrix(A).astype(dtype)
+        self.Y_dev, self.Y_test = Y_dev, Y_test
+        n_tr, n_dev, n_te = (m.shape[0] for m in parts_x)
+        self.n_train = n_tr
+        self.all_train = np.arange(0, n_tr).astype(dtypeint)
+        self.dev_indices = np.arange(n_tr, n_tr + n_dev).astype(dtypeint)
+        self.test_indices = np.arange(n_tr + n_dev, n_tr + n_dev + n_te).astype(dtypeint)
+        self.input_size = self.X.shape[1]
+        self.output_size = int(np.max(self.Y) + 1)
+
+    def draw_training_subset(self, fraction):
+        """`-lblfraction`: a random subset of the training users, drawn from the global numpy stream exactly as the
+        reference draws it (gcnmain.py:206-207: one np.random.choice without replacement per fraction)."""
+        size = min(int(fraction * self.X.shape[0]), self.all_train.shape[0])
+        return np.random.choice(self.all_train, size=size, replace=False).astype(self.dtypeint)
+
+    def evaluate(self, clf, which):
+        """predict + geo_eval on the dev or test users -> geo_eval's tuple."""
+        idx, y, users = ((self.dev_indices, self.Y_dev, self.U_dev) if which == 'dev'
+                         else (self.test_indices, self.Y_test, self.U_test))
+        logging.info('%s results:' % which)
+        y_pred, _ = clf.predict(self.X, self.A, idx)
+        return geo_eval(y, y_pred, users, self.classLatMedian, self.classLonMedian, self.userLocation)
+
+
+def run_fraction(clf, ds, fraction, args, batch_size, verbose, rank0):
+    """One `-lblfraction` round: train (or load) on a fresh subset, report dev / test metrics, write the pickles the
+    reference writes (model file if -save, dev distances always)."""
+    logging.info('***********percentile %f ******************' % fraction)
+    model_file = './data/model-{}-{}.pkl'.format(ds.A.shape[0], fraction)
+    train_indices = ds.draw_training_subset(fraction)
+    logging.info('{} training samples'.format(train_indices.shape[0]))
+    if args.load:
+        clf.load(load_obj, model_file)
+        return train_indices, None
+    if clf.fitted:
+        clf.reset()             # parameters back to their initial values; Adam's state lives on, as in the reference
+    clf.fit(ds.X, ds.A, ds.Y, train_indices=train_indices, val_indices=ds.dev_indices, n_epochs=args.epochs,
+            batch_size=batch_size, max_down=args.maxdown, verbose=verbose and rank0, seed=model_args.seed)
+    if args.save and rank0:
+        os.makedirs(os.path.dirname(model_file), exist_ok=True)
+        clf.save(dump_obj, model_file)
+    dev = ds.evaluate(clf, 'dev')
+    if rank0:
+        with open('gcn_{}_percent_pred_{}.pkl'.format(fraction, ds.output_size), 'wb') as fout:
+            pickle.dump(dev[3:], fout)                  # (distances, latlon_true, latlon_pred)
+    test = ds.evaluate(clf, 'test')
+    return train_indices, {'fraction': fraction, 'dev': dev[:3], 'test': test[:3]}
+
+
 def main(data, args, **kwargs):
-    batch_size = kwargs.get('batch', 500)
-    hidden_size = kwargs.get('hidden', [100])
-    dropout = kwargs.get('dropout', 0.0)
-    regul = kwargs.get('regularization', 1e-6)
-    dtype = 'float32'
-    dtypeint = 'int32'
-    A, X_train, Y_train, X_dev, Y_dev, X_test, Y_test, U_train, U_dev, U_test, classLatMedian, classLonMedian, userLocation = data
     logging.info('stacking training, dev and test features and creating indices...')
-    X = sps.vstack([X_train, X_dev, X_test]).tocsr()
-    if len(Y_train.shape) == 1:
-        Y = np.hstack((Y_train, Y_dev, Y_test))
-    else:
-        Y = np.vstack((Y_train, Y_dev, Y_test))
-    Y = Y.astype(dtypeint)
-    X = X.astype(dtype)
-    A = sps.csr_matrix(A).astype(dtype)
+    ds = Splits(data)
     if args.vis:
         raise NotImplementedError("-vis (t-SNE plots, gcnmain.py:180-183) is outside the hot path")
-    input_size = X.shape[1]
-    output_size = int(np.max(Y) + 1)
-    verbose = not args.silent
-    fractions = args.lblfraction
-    all_train_indices = np.asarray(range(0, X_train.shape[0])).astype(dtypeint)
     logging.info('running mlp with graph conv...')
     device, mode = setup_distributed(args)
     comm = None
     if mode == 'dist':
         from .dist import TorchDistComm
-        comm = TorchDistComm(X.shape[0], device)
+        comm = TorchDistComm(ds.X.shape[0], device)
     rank0 = comm is None or comm.rank == 0
-    clf = GraphConv(input_size=input_size, output_size=output_size, hid_size_list=hidden_size, regul_coef=regul,
-                    drop_out=dropout, batchnorm=args.batchnorm, highway=model_args.highway, device=device, comm=comm,
+    clf = GraphConv(input_size=ds.input_size, output_size=ds.output_size, hid_size_list=kwargs.get('hidden', [100]),
+                    regul_coef=kwargs.get('regularization', 1e-6), drop_out=kwargs.get('dropout', 0.0),
+                    batchnorm=args.batchnorm, highway=model_args.highway, device=device, comm=comm,
                     gemm_precision=getattr(args, 'gemm_precision', None))
-    clf.build_model(A, use_text=args.notxt, use_labels=args.lp, seed=model_args.seed)
-
-    results = []
-    for percentile in fractions:
-        logging.info('***********percentile %f ******************' % percentile)
-        model_file = './data/model-{}-{}.pkl'.format(A.shape[0], percentile)
-        selection_size = min(int(percentile * X.shape[0]), all_train_indices.shape[0])
-        train_indices = np.random.choice(all_train_indices, size=selection_size, replace=False).astype(dtypeint)
-        logging.info('{} training samples'.format(train_indices.shape[0]))
-        dev_indices = np.asarray(range(X_train.shape[0], X_train.shape[0] + X_dev.shape[0])).astype(dtypeint)
-        test_indices = np.asarray(range(X_train.shape[0] + X_dev.shape[0],
-                                        X_train.shape[0] + X_dev.shape[0] + X_test.shape[0])).astype(dtypeint)
-        if args.load:
-            clf.load(load_obj, model_file)
-        else:
-            if clf.fitted:
-                clf.reset()
-            clf.fit(X, A, Y, train_indices=train_indices, val_indices=dev_indices, n_epochs=args.epochs,
-                    batch_size=batch_size, max_down=args.maxdown, verbose=verbose and rank0, seed=model_args.seed)
-            if args.save and rank0:
-                os.makedirs(os.path.dirname(model_file), exist_ok=True)
-                clf.save(dump_obj, model_file)
-            logging.info('dev results:')
-            y_pred, _ = clf.predict(X, A, dev_indices)
-            mean, median, acc, distances, latlon_true, latlon_pred = geo_eval(Y_dev, y_pred, U_dev, classLatMedian,
-                                                                              classLonMedian, userLocation)
-            if rank0:
-                with open('gcn_{}_percent_pred_{}.pkl'.format(percentile, output_size), 'wb') as fout:
-                    pickle.dump((distances, latlon_true, latlon_pred), fout)
-            logging.info('test results:')
-            y_pred, _ = clf.predict(X, A, test_indices)
-            t = geo_eval(Y_test, y_pred, U_test, classLatMedian, classLonMedian, userLocation)
-            results.append({'fraction': percentile, 'dev': (mean, median, acc), 'test': t[:3]})
+    clf.build_model(ds.A, use_text=args.notxt, use_labels=args.lp, seed=model_args.seed)
+    results, train_indices = [], None
+    for fraction in args.lblfraction:
+        train_indices, res = run_fraction(clf, ds, fraction, args, kwargs.get('batch', 500), not args.silent, rank0)
+        if res is not None:
+            results.append(res)
     if args.feature_report:
-        # gcnmain.py:234-246: probe the trained model with one-hot "documents" (X = I over the vocabulary) on an
-        # identity graph and list, per class, the words it is most confident about
-        vocab_file = os.path.join(args.dir, 'vocab.pkl')
-        if os.path.exists(vocab_file):
-            vocab = load_obj(vocab_file)
-        elif getattr(model_args, 'synthetic', None):
-            vocab = {'w%d' % i: i for i in range(X.shape[1])}
-        else:
-            logging.error('vocab file {} not found'.format(vocab_file))
-            return clf, results
-        logging.info('{} vocab loaded from file'.format(len(vocab)))
-        from collections import Counter
-        train_vocab = set(term for term, count in Counter(X[train_indices].nonzero()[1]).items() if count >= 10)
-        dev_vocab = set(np.nonzero(np.asarray(X[dev_indices].sum(axis=0)).ravel())[0])
-        X_onehot = sps.identity(len(vocab), dtype=dtype, format='csr')
-        A_onehot = X_onehot
-        if rank0 and comm is None:
-            feature_report(clf, vocab, X_onehot, A_onehot, classLatMedian, classLonMedian, train_vocab, dev_vocab,
-                           topk=200, dtypeint=dtypeint)
-        else:
-            logging.warning('-feature_report runs on a single GPU only')
+        report_features(clf, ds, train_indices, args, single_gpu=rank0 and comm is None)
     return clf, results
+
+
+def report_features(clf, ds, train_indices, args, single_gpu):
+    """`-feature_report` (reference gcnmain.py:234-246): probe the trained model with one one-hot "document" per
+    vocabulary entry on an identity graph."""
+    vocab_file = os.path.join(args.dir, 'vocab.pkl')
+    if os.path.exists(vocab_file):
+        vocab = load_obj(vocab_file)
+    elif getattr(model_args, 'synthetic', None):
+        vocab = {'w%d' % i: i for i in range(ds.X.shape[1])}
+    else:
+        logging.error('vocab file {} not found'.format(vocab_file))
+        return
+    logging.info('{} vocab loaded from file'.format(len(vocab)))
+    if not single_gpu:
+        logging.warning('-feature_report runs on a single GPU only')
+        return
+    # words seen >= 10 times among the training users are excluded from the report; dev vocabulary as the reference passes it
+    seen = np.bincount(ds.X[train_indices].indices, minlength=ds.X.shape[1])
+    train_vocab = set(np.nonzero(seen >= 10)[0].tolist())
+    dev_vocab = set(np.unique(ds.X[ds.dev_indices].indices).tolist())
+    eye = sps.identity(len(vocab), dtype='float32', format='csr')
+    feature_report(clf, vocab, eye, eye, ds.classLatMedian, ds.classLonMedian, train_vocab, dev_vocab, topk=200,
+                   dtypeint=ds.dtypeint)
 
 
 def feature_report(model, vocab, X, A, classLatMedian, classLonMedian, train_vocab=set(), dev_vocab=set(), topk=20,
                    dtypeint='int32', filename='important_features.txt'):
-    """Top-k most indicative vocabulary entries per class (reference gcnmain.py:249-261, python-3 idioms)."""
+    """Per class, the `topk` vocabulary entries whose one-hot document the model assigns to that class with the highest
+    probability, skipping `train_vocab` (reference gcnmain.py:249-261; same output file format)."""
     import codecs
-    eval_indices = np.asarray(range(X.shape[0])).astype(dtypeint)
-    preds, probs = model.predict(X, A, eval_indices)
-    id2v = {v: k for k, v in vocab.items()}
+    _, probs = model.predict(X, A, np.arange(X.shape[0]).astype(dtypeint))
+    word_of = {i: w for w, i in vocab.items()}
     logging.info('{} train vocab are being excluded!'.format(len(train_vocab)))
-    feature_importance = np.argsort(-probs, axis=0)
+    ranking = np.argsort(-probs, axis=0)                       # column c: vocabulary ids by decreasing P(class c)
+    allowed = np.ones(probs.shape[0], dtype=bool)
+    allowed[[i for i in train_vocab if i < len(allowed)]] = False
     with codecs.open(filename, 'w', encoding='utf-8') as fout:
-        for lbl in range(probs.shape[1]):
-            important_vocab = ' '.join([id2v[idx] for idx in feature_importance[:, lbl].reshape(-1).tolist()
-                                        if idx not in train_vocab][0:topk])
-            lat, lon = classLatMedian[str(lbl)], classLonMedian[str(lbl)]
-            fout.write(u'location: {},{} \nimportant features: {} \n\n'.format(lat, lon, important_vocab))
+        for c in range(probs.shape[1]):
+            order = ranking[:, c]
+            words = ' '.join(word_of[int(i)] for i in order[allowed[order]][:topk])
+            fout.write(u'location: {},{} \nimportant features: {} \n\n'.format(classLatMedian[str(c)], classLonMedian[str(c)],
+                                                                              words))
     logging.info('important features are written to {}'.format(filename))
-    return feature_importance
+    return ranking
 
 
 def parse_args(argv):

@@ -54,8 +54,9 @@ class _TargetRows:
     with `use_target_indices` the layer returns only the rows named by the `target_indices` kwarg of get_output.
     The reference gathers BEFORE the nonlinearity; the nonlinearities here act per row (elementwise or softmax),
     so gathering the finished rows is the same thing and keeps bias + activation fused in the producing kernel.
-    The backward scatters the incoming gradient into a zero matrix of all rows (rows named twice: last one
-    wins -- the reference's index vectors are unique, gcnmain.py:207)."""
+    The backward is what Theano's AdvancedIncSubtensor1 does for the gather's gradient: the incoming rows are ADDED into
+    a zero matrix of all rows, so a row named k times receives the sum of its k gradients.  It runs as S^T . grad with
+    the 0/1 selection matrix S on the SpMM kernel -- sequential adds in index-vector order, deterministic, no atomics."""
 
     def _target(self, kwargs):
         return kwargs.get('target_indices') if getattr(self, 'use_target_indices', False) else None
@@ -82,9 +83,10 @@ class _TargetRows:
         if s.get('target_idx') is not None:
             if isinstance(grad, L.PreAct):
                 raise NotImplementedError("a fused pre-activation gradient cannot pass through a row gather")
-            full = K.DMat(s['n_full'], grad.F, grad.device)          # zeros
-            K.scatter_rows(grad, s['target_idx'], full)
-            grad = full
+            idx = s['target_idx'].cpu().numpy().astype(np.int64)
+            sel_t = sps.csr_matrix((np.ones(len(idx), dtype=np.float32), (idx, np.arange(len(idx)))),
+                                   shape=(s['n_full'], len(idx)))              # S^T: row = node, column = position in idx
+            grad = K.spmm(K.CSR(sel_t, grad.device), grad)
         return super().backward(grad, tape, into, **kwargs)
 
 
@@ -299,19 +301,75 @@ def np_softmax(x):
 
 class LazyArray:
     """The N x C probability matrix f_train hands back every epoch (reference gcnmodel.py:410,430
-    -- fit() discards it).  Stays on the device until somebody looks."""
+    -- fit() discards it).  Stays on the device until somebody looks.
 
-    def __init__(self, fetch, shape):
+    Row-partitioned runs: every rank holds only ITS rows, and assembling the matrix is a collective.  Hiding a
+    collective inside ``__array__`` deadlocks as soon as one rank looks and another does not, so a sharded result
+    refuses the implicit conversion: call ``GraphConv.gather_output(out)`` on ALL ranks, or ``out.local()`` for
+    this rank's rows.  A result of a captured (hipGraph) step lives in the capture's static buffer: reading it
+    after a later step has overwritten that buffer raises instead of returning the newer values."""
+
+    def __init__(self, fetch, shape, sharded=False, still_valid=None):
         self._fetch, self.shape, self._v = fetch, shape, None
+        self.sharded, self._still_valid = sharded, still_valid
 
-    def get(self):
+    def _check_fresh(self):
+        if self._v is None and self._still_valid is not None and not self._still_valid():
+            raise RuntimeError("this f_train output belongs to an earlier captured step whose device buffer has been "
+                               "overwritten by a later step; read it before calling f_train again")
+
+    def local(self):
+        """This rank's rows (all rows on one GPU)."""
         if self._v is None:
+            self._check_fresh()
             self._v = self._fetch()
         return self._v
+
+    def get(self):
+        if self.sharded:
+            raise RuntimeError("f_train's output matrix is row-partitioned across the ranks: fetch it with "
+                               "GraphConv.gather_output(out) on ALL ranks (a collective), or out.local() for this rank's rows")
+        return self.local()
 
     def __array__(self, dtype=None, copy=None):
         v = self.get()
         return v if dtype is None else v.astype(dtype)
+
+
+def _content_key(a):
+    """Identity of a host index / label vector by CONTENT (shape, dtype, 64-bit hash of the bytes): editing the vector
+    in place, or a new vector that reuses a freed one's address, can never hit a stale device copy."""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        h = xxhash.xxh3_64_intdigest(memoryview(a).cast('B'))
+    except ImportError:
+        import zlib
+        h = zlib.crc32(memoryview(a).cast('B'))
+    return (a.shape, a.dtype.str, h)
+
+
+class _DevLossWatch:
+    """The reference's stopping rule (gcnmodel.py:434-447): keep the parameters of the epoch with the lowest dev loss;
+    stop once the loss has failed to improve more than `max_down` epochs in a row AND more than 2 * max_down epochs
+    have run."""
+
+    def __init__(self, max_down):
+        self.max_down = max_down
+        self.best_loss, self.best_acc, self.n_down, self.snapshot = sys.maxsize, 0.0, 0, None
+
+    def update(self, loss, acc):
+        """-> True when this epoch is the new best (strictly lower loss; a NaN never is)."""
+        if loss < self.best_loss:
+            self.best_loss, self.best_acc, self.n_down = loss, acc, 0
+            return True
+        self.n_down += 1
+        return False
+
+    def exhausted(self, epoch):
+        return self.n_down > self.max_down and epoch > 2 * self.max_down
 
 
 # --------------------------------------------------------------------------------------------
@@ -351,6 +409,7 @@ class GraphConv():
         # GEOGCN_HIP_GRAPH=1); single GPU only; the inputs of f_train must stay the same objects between calls.
         self.hip_graph = (os.environ.get('GEOGCN_HIP_GRAPH', '0') == '1') if hip_graph is None else bool(hip_graph)
         self._hg = None
+        self._step_serial = 0             # f_train calls so far (freshness of outputs that live in a captured step's buffers)
         self._adam_state_dev = None
         self.stream_overlap = os.environ.get('GEOGCN_STREAM_OVERLAP', '0') == '1'      # measured: no net gain, off
         self._overlap_comm = None
@@ -455,7 +514,7 @@ class GraphConv():
     def _train_columns_operand(self, g, A, train_indices):
         """CSR of A^T restricted to the columns in `train_indices` (cached per graph and index set)."""
         idx = np.asarray(train_indices)
-        key = (idx.ctypes.data, len(idx), int(idx.sum()))
+        key = _content_key(idx)
         hit = g.get('A_tr')
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -472,24 +531,38 @@ class GraphConv():
         return csr
 
     def _device_indices(self, comm, idx, y=None):
-        """Index / label vectors on the device (local share when distributed) + the global count."""
+        """Index / label vectors on the device (local share when distributed) + the global count.  Cached by content."""
         import torch
         idx = np.asarray(idx)
         ya = None if y is None else np.asarray(y)
-        key = (idx.ctypes.data, len(idx), int(idx.sum()), None if ya is None else (ya.ctypes.data, int(ya.sum())))
+        key = (_content_key(idx), _content_key(ya))
         hit = self._idx_cache.get(key)
-        if hit is not None and np.array_equal(hit[3], idx[:16]):
-            return hit[:3]
+        if hit is not None:
+            return hit
         if idx.size and (idx.min() < 0 or idx.max() >= comm.part.N):
             raise IndexError("index out of bounds for %d nodes" % comm.part.N)
+        if ya is not None:
+            if len(ya) != len(idx):
+                raise ValueError("%d labels for %d indices" % (len(ya), len(idx)))
+            if ya.size and (ya.min() < 0 or ya.max() >= self.output_size):
+                # (Theano raises on an out-of-range label in the cross-entropy's advanced indexing)
+                raise IndexError("label out of range for %d classes" % self.output_size)
         loc, yloc, _ = comm.part.split_indices(idx, y)
         t_idx = torch.from_numpy(np.ascontiguousarray(loc, dtype=np.int32)).to(self.device)
         t_y = None if y is None else torch.from_numpy(np.ascontiguousarray(yloc, dtype=np.int32)).to(self.device)
         out = (t_idx, t_y, len(idx))
         if len(self._idx_cache) > 8:
             self._idx_cache.clear()
-        self._idx_cache[key] = out + (idx[:16].copy(),)
+        self._idx_cache[key] = out
         return out
+
+    def invalidate_inputs(self):
+        """Forget the device copies of X / A and of the index vectors.  X and A are cached by object identity (a
+        reference is held, so the identity cannot be recycled) and must be treated as immutable while cached: call this
+        after editing X.data / A.data in place (e.g. re-normalising A)."""
+        self._graph_cache = {}
+        self._idx_cache = {}
+        self._hg = None
 
     # -- f_train (reference gcnmodel.py:375-389, 406-410) ----------------------------------------
     def inject_dropout_mask(self, mask):
@@ -502,6 +575,7 @@ class GraphConv():
         dev_acc, output(N x C)]; dev metrics come from the same dropout-ON pass (gcnmodel.py:378)."""
         g = self._device_graph(X, A)
         comm = g['comm']
+        self._step_serial += 1
         if self.hip_graph and not self._dist(comm) and self._injected_mask is None and self.device.type == 'cuda':
             P, n_tr, n_dv = self._train_step_graphed(g, X, y_train, y_dev, A, train_indices, dev_indices)
         else:
@@ -568,10 +642,8 @@ class GraphConv():
         replay it.  Step and dropout-stream counters live on the device, so each replay is a new step."""
         import torch
 
-        def ident(a):
-            a = np.asarray(a)
-            return (a.ctypes.data, a.shape, int(a[:16].sum()) if a.size else 0)
-        key = (id(X), id(A), ident(y_train), ident(y_dev), ident(train_indices), ident(dev_indices))
+        key = (id(X), id(A), _content_key(y_train), _content_key(y_dev), _content_key(train_indices),
+               _content_key(dev_indices))
         hg = self._hg
         if hg is None or hg['key'] != key:
             hg = self._hg = {'key': key, 'eager': 0, 'graph': None}
@@ -594,21 +666,41 @@ class GraphConv():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, 'captured')
-        hg.update(graph=graph, P=P, n_tr=n_tr, n_dv=n_dv, dropouts=drops)
+        # (the capture refers to the device index vectors: hold them, the content-keyed cache may drop its entries)
+        keep = (self._device_indices(g['comm'], train_indices, y_train), self._device_indices(g['comm'], dev_indices, y_dev))
+        hg.update(graph=graph, P=P, n_tr=n_tr, n_dv=n_dv, dropouts=drops, keep=keep)
         graph.replay()          # capture records, it does not run: this replay IS the step just counted
         return P, n_tr, n_dv
 
     def _lazy_output(self, P, comm):
-        def fetch():
-            if self._dist(comm):
-                return comm.all_gather_rows(P).numpy()[:comm.part.N]
-            return P.numpy()
-        return LazyArray(fetch, (comm.part.N, P.F))
+        N = comm.part.N
+        if self._dist(comm):
+            la = LazyArray(lambda: P.numpy(), (N, P.F), sharded=True)
+            la._P, la._comm = P, comm
+            return la
+        if self._hg is not None and self._hg.get('graph') is not None and P is self._hg.get('P'):
+            serial = self._step_serial
+            return LazyArray(lambda: P.numpy(), (N, P.F), still_valid=lambda: self._step_serial == serial)
+        return LazyArray(lambda: P.numpy(), (N, P.F))
+
+    def gather_output(self, out):
+        """The full N x C matrix behind an f_train output.  COLLECTIVE when the graph is row-partitioned: every rank
+        must call it (each gets the whole matrix); on one GPU it is just the device-to-host copy."""
+        if not isinstance(out, LazyArray):
+            return np.asarray(out)
+        if not out.sharded:
+            return out.get()
+        return self._gather_rows(out._P, out._comm)
+
+    def _gather_rows(self, M, comm):
+        """Row-partitioned DMat -> full numpy matrix on every rank (collective)."""
+        return comm.all_gather_rows(M).numpy()[:comm.part.N]
 
     # -- f_val (reference gcnmodel.py:392-394, 411) ------------------------------------------------
     def f_val(self, X, A, test_indices):
+        """Deterministic forward -> (argmax, probabilities) of the indexed rows.  Row-partitioned runs: a collective
+        (every rank calls predict and gets the same answer)."""
         K = backend.active()
-        import torch
         g = self._device_graph(X, A)
         comm = g['comm']
         kw = dict(A=g['A'], deterministic=True, comm=self._layer_comm(comm),
@@ -618,8 +710,7 @@ class GraphConv():
         amax = tape[self.l_out]['argmax']
         idx = np.asarray(test_indices)
         if self._dist(comm):
-            full = self._lazy_output(P, comm).get()
-            rows = full[idx]
+            rows = self._gather_rows(P, comm)[idx]
             return rows.argmax(-1).astype(np.int64), rows
         t_idx, _, _ = self._device_indices(comm, idx)
         rows = K.gather_rows(P, t_idx).cpu().numpy()
@@ -633,44 +724,35 @@ class GraphConv():
             kw = dict(A=g['A'], deterministic=True, comm=self._layer_comm(comm),
                       gemm_precision=self.gemm_precision)
             T = L.get_output(layer, {self.l_in: g['X']}, **kw)
+            if self._dist(comm):
+                return self._gather_rows(T, comm)          # collective: get_gates is called on every rank
             return T.numpy()
         return f_gate
 
     # -- training loop (reference gcnmodel.py:418-450) -------------------------------------------
     def fit(self, X, H, Y, train_indices, val_indices, n_epochs=10000, batch_size=1000, max_down=10,
             pseudolikelihood_thresh=0.2, verbose=True, seed=77):
+        """Full-batch training with early stopping on the dev loss of the dropout-ON pass (reference gcnmodel.py:418-450:
+        one f_train per epoch over the whole graph; `batch_size` and `pseudolikelihood_thresh` are accepted and unused
+        there too).  The best parameters are snapshotted ON THE DEVICE (one copy of the flat arena) instead of being
+        read back every improving epoch, and restored at the end."""
         np.random.seed(seed)
         logging.info('training for {} epochs with batch size {}'.format(n_epochs, batch_size))
-        best_params = None
-        best_val_loss = sys.maxsize
-        best_val_acc = 0.0
-        n_validation_down = 0
-        report_k_epoch = 1
-
-        X_train, y_train = X, Y[train_indices]
-        y_dev = Y[val_indices]
-        for n in range(n_epochs):
-            l_train, acc_train, l_val, acc_val, all_probs = self.f_train(X_train, y_train, y_dev, H, train_indices,
-                                                                         val_indices)
-            l_train, acc_train = l_train.item(), acc_train.item()
-            l_val, acc_val = l_val.item(), acc_val.item()
-
-            if l_val < best_val_loss:
-                best_val_loss = l_val
-                best_val_acc = acc_val
-                best_params = self.store.p.clone()      # device snapshot (reference: get_all_param_values)
-                n_validation_down = 0
-            else:
-                n_validation_down += 1
+        watch = _DevLossWatch(max_down)
+        y_train, y_dev = Y[train_indices], Y[val_indices]
+        for epoch in range(n_epochs):
+            out = self.f_train(X, y_train, y_dev, H, train_indices, val_indices)
+            l_train, acc_train, l_val, acc_val = (v.item() for v in out[:4])
+            if watch.update(l_val, acc_val):
+                watch.snapshot = self.store.p.clone()
             if verbose:
-                if n % report_k_epoch == 0:
-                    logging.info('epoch {} train loss {:.2f} train acc {:.2f} val loss {:.2f} val acc {:.2f} best val acc {:.2f} maxdown {}'.format(
-                        n, l_train, acc_train, l_val, acc_val, best_val_acc, n_validation_down))
-            if n_validation_down > max_down and n > 2 * report_k_epoch * max_down:
+                logging.info('epoch {} train loss {:.2f} train acc {:.2f} val loss {:.2f} val acc {:.2f} best val acc {:.2f} maxdown {}'.format(
+                    epoch, l_train, acc_train, l_val, acc_val, watch.best_acc, watch.n_down))
+            if watch.exhausted(epoch):
                 logging.info('validation results went down. early stopping ...')
                 break
-        if best_params is not None:
-            self.store.p.copy_(best_params)
+        if watch.snapshot is not None:
+            self.store.p.copy_(watch.snapshot)
         self.best_params = L.get_all_param_values(self.l_out)
         self.fitted = True
 

@@ -576,6 +576,7 @@ class SparseOperand:
         self.head_idx, self.head_dense, self.fwd_tail = head_idx, head_dense, fwd_tail
         self.shape = fwd.shape
         self._xt_plans = {}
+        self._hot = {}            # HotCSR per LDS capacity (forward X . W0 with the hot rows of W0 in LDS)
 
     def xt_plan(self, F):
         """Plan of the document-blocked X^T . G kernel for width F (built on first use; None when the tail is small)."""
@@ -712,11 +713,62 @@ def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     return out
 
 
+class HotCSR:
+    """CSR(X) prepared for geogcn_spmm_csr_hot_f32: the `n_hot` most frequent columns are served from LDS; every row is
+    reordered [hot | cold] and a hot entry's column index is its LDS slot (include/geogcn.h)."""
+
+    def __init__(self, csr: CSR, values_host: np.ndarray, n_hot: int):
+        indptr, indices = csr.rowptr_host, csr.colidx_host
+        counts = np.bincount(indices, minlength=csr.shape[1])
+        n_hot = int(min(n_hot, np.count_nonzero(counts)))
+        hot = np.sort(np.argsort(-counts, kind='stable')[:n_hot]).astype(np.int32)
+        slot_of = np.full(csr.shape[1], -1, dtype=np.int32)
+        slot_of[hot] = np.arange(n_hot, dtype=np.int32)
+        slot = slot_of[indices]
+        is_hot = slot >= 0
+        row_of = np.repeat(np.arange(csr.shape[0], dtype=np.int64), np.diff(indptr))
+        order = np.lexsort((indices, ~is_hot, row_of))                 # row, hot first, ascending column inside a part
+        col2 = np.where(is_hot, slot, indices)[order].astype(np.int32)
+        hot_per_row = np.bincount(row_of[is_hot], minlength=csr.shape[0]).astype(np.int32)
+        dev = csr.device
+        self.shape, self.nnz, self.n_hot = csr.shape, csr.nnz, n_hot
+        self.hot_fraction = float(is_hot.mean()) if len(indices) else 0.0
+        self.rowptr = csr.rowptr
+        self.rowsplit = torch.from_numpy(np.ascontiguousarray(indptr[:-1] + hot_per_row, dtype=np.int32)).to(dev)
+        self.colidx = torch.from_numpy(np.ascontiguousarray(col2)).to(dev)
+        self.val = torch.from_numpy(np.ascontiguousarray(values_host[order], dtype=np.float32)).to(dev)
+        self.hot_rows = torch.from_numpy(hot).to(dev)
+
+
+def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE):
+    """out = act(A . B + bias), hot rows of B from LDS (geogcn_spmm_csr_hot_f32)."""
+    if B.n != A.shape[1]:
+        raise ValueError("spmm_hot: A is %s but B has %d rows" % (A.shape, B.n))
+    out = DMat.empty(A.shape[0], B.F, B.device) if out is None else out
+    check(_ffi.lib().geogcn_spmm_csr_hot_f32(A.shape[0], _p(A.rowptr), _p(A.rowsplit), _p(A.colidx), _p(A.val), _p(B.t), B.ld,
+                                             _p(A.hot_rows), A.n_hot, _p(out.t), out.ld, B.F, _p(bias), act, _stream()),
+          'spmm_csr_hot_f32')
+    return out
+
+
+# How X . W0 is formed (GEOGCN_X_FWD): 'hot' = hot rows of W0 from LDS (default from HOT_MIN_NNZ stored entries on),
+# 'split' = dense head panel GEMM + CSR tail, 'plain' = one CSR gather kernel
+X_FWD_MODE = os.environ.get('GEOGCN_X_FWD', 'hot')
+HOT_MIN_NNZ = int(os.environ.get('GEOGCN_HOT_MIN_NNZ', 2_000_000))
+
+
 def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE):
     """out = act(x . W + bias) for a sparse input x (S.structured_dot(X, W0), reference gcnmodel.py:39-42).  With a
     dense head panel: the K hot vocabulary rows of W are gathered into a K x F matrix and multiplied by the panel on the
     MFMA pipe (raw product), then the CSR tail continues each row from that value (bias and activation in its epilogue)."""
-    if x.head_dense is None or x.fwd_tail is None or not X_SPLIT_FWD:
+    if X_FWD_MODE == 'hot' and isinstance(x.fwd, CSR) and x.fwd.nnz >= HOT_MIN_NNZ and not x.symmetric:
+        cap = int(_ffi.lib().geogcn_spmm_hot_capacity(W.F))
+        if cap > 0:
+            hot = x._hot.get(cap)
+            if hot is None:
+                hot = x._hot[cap] = HotCSR(x.fwd, x.fwd.val.cpu().numpy(), cap)
+            return spmm_hot(hot, W, out=out, bias=bias, act=act)
+    if x.head_dense is None or x.fwd_tail is None or X_FWD_MODE != 'split':
         return spmm(x.fwd, W, out=out, bias=bias, act=act)
     K = x.head_dense.F
     Wh = DMat(K, W.F, W.device)
@@ -743,10 +795,6 @@ def _spmm_cols(A: CSR, B: DMat, out: DMat, bias, act, c0, c1):
     check(lib.geogcn_spmm_csr_acc_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), bptr, B.ld,
                                       optr, out.ld, F, biasp, act, _p(ws), ws.numel(), _stream()), 'spmm_csr_acc_f32')
     return out
-
-
-# GEOGCN_X_SPLIT_FWD = 1 (default) | 0: X . W0 as dense head panel + CSR tail (A/B switch)
-X_SPLIT_FWD = os.environ.get('GEOGCN_X_SPLIT_FWD', '1') != '0'
 
 
 class SpmmTimer:

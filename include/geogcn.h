@@ -79,6 +79,18 @@ int geogcn_spmm_csr_acc_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_
                             float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* C = act(A_csr . B + bias) with the HOT rows of B staged in LDS -- S.structured_dot(X, W0), gcnmodel.py:39-42, for a
+ * bag-of-words X whose columns are Zipfian (the ~120 most frequent vocabulary entries hold more than half of the stored
+ * nonzeros at the TwitterUS shape): one persistent workgroup per CU copies the n_hot rows B[hot_rows[s]] into its LDS
+ * once and serves the hot nonzeros from there; only the cold ones are gathered from L2 / HBM.  The caller prepares the
+ * structure: every row is ordered [hot | cold] (each part in ascending column order), rowsplit[r] is the boundary, and
+ * colidx of a HOT entry holds its LDS slot s (0 <= s < n_hot) instead of the column.  n_hot <= geogcn_spmm_hot_capacity(F)
+ * (0 = this width is not supported: use geogcn_spmm_csr_f32).  Accumulation is sequential in the stored order.     */
+int32_t geogcn_spmm_hot_capacity(int32_t F);
+int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
+                            int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream);
+
 /* dW[n_words x F] = X^T . G  -- the gradient of S.structured_dot(X, W0) w.r.t. W0 (autodiff of gcnmodel.py:39) for a
  * bag-of-words X whose transpose is given as CSR (rows = vocabulary, columns = documents, sorted).  Instead of gathering
  * rows of the N x F matrix G at random (every row fetched ~nnz/N times from beyond the L2), the documents are
@@ -124,7 +136,7 @@ int geogcn_spmm_csr_highway_f32(const geogcn_spmm_plan* plan, int32_t n_rows, in
 /* profiling aid (bench.py's roofline leg): a pool of hipEvent pairs owned by the library.  While a
  * timer is attached, every geogcn_spmm_csr_f32 / _bf16b call (not the fused _highway one) whose F equals `only_F` and whose nnz equals
  * `only_nnz` (0 = any) records one
- * (begin, end) pair immediately around its main row kernel (spmm_rows_kernel) on the call's stream,
+ * (begin, end) pair around the whole product (spmm_rows_kernel + the long rows' combine kernel) on the call's stream,
  * until the pool is full.  geogcn_timer_read_ms synchronises the recorded events and returns the
  * per-launch durations.  Detach with geogcn_timer_attach_spmm(NULL, 0, 0).                          */
 typedef struct geogcn_timer geogcn_timer;

@@ -74,7 +74,7 @@ def _worker(rank, world, port, q, exchange):
             res = []
             for step in range(2):
                 o = clf.f_train(X, z['Y'][z['tr']], z['Y'][z['dev']], A, z['tr'], z['dev'])
-                res.append(([float(v) for v in o[:4]], np.asarray(o[4]), clf.get_grads(),
+                res.append(([float(v) for v in o[:4]], clf.gather_output(o[4]), clf.get_grads(),
                             L.get_all_param_values(clf.l_out)))
             pred, probs = clf.predict(X, A, z['te'])
             out[name] = (res, pred, probs, dict(L.DenseLayer.early_starts))
@@ -154,7 +154,7 @@ def _asym_worker(rank, world, port, q, exchange):
         comm = TorchDistComm(cfg['N'], torch.device('cpu'), exchange=exchange)
         clf = make_clf(cfg, params, device=torch.device('cpu'), comm=comm)
         o = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
-        res = ([float(v) for v in o[:4]], np.asarray(o[4]), clf.get_grads())     # (fetching P is a collective: all ranks)
+        res = ([float(v) for v in o[:4]], clf.gather_output(o[4]), clf.get_grads())     # (a collective: all ranks)
         if rank == 0:
             q.put(res)
     finally:

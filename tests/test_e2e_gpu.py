@@ -246,6 +246,18 @@ def test_layer_zoo_variants_match_oracle(cmu):
     p6 = L.get_all_params(l6)
     assert np.abs(p6[0]._store.read_grad(p6[0]) - ref.T @ dZ).max() <= 2e-4 * np.abs(ref.T @ dZ).max()
     assert np.abs(p6[1]._store.read_grad(p6[1]) - (Gfull * (1 - full * full)).sum(0)).max() <= 1e-4
+    # an index vector that names rows more than once: the gradients of the copies ADD (AdvancedIncSubtensor1)
+    idx_d = np.concatenate([idx[:50], idx[:20], idx[10:15], idx[:1]]).astype(np.int32)
+    tape = {}
+    y6 = L.get_output(l6, {d_in: H}, tape=tape, target_indices=idx_d)
+    assert np.abs(y6.numpy() - full[idx_d]).max() < 2e-5
+    G6 = rng.randn(len(idx_d), 32).astype(np.float32)
+    L.backward(l6, ops.DMat.from_numpy(G6, dev), tape)
+    Gfull = np.zeros_like(full)
+    np.add.at(Gfull, idx_d, G6)
+    dZ = O.spmm_t(c['A'], Gfull * (1 - full * full))
+    assert np.abs(p6[0]._store.read_grad(p6[0]) - ref.T @ dZ).max() <= 2e-4 * np.abs(ref.T @ dZ).max()
+    assert np.abs(p6[1]._store.read_grad(p6[1]) - (Gfull * (1 - full * full)).sum(0)).max() <= 1e-4
     l7 = M.ConvolutionDenseLayer2(d_in, use_target_indices=True, num_units=32, W=W2, b=b2, nonlinearity=NL.tanh)
     L.ParamStore(L.get_all_params(l7), dev)
     assert np.abs(L.get_output(l7, {d_in: H}, A=A, target_indices=idx).numpy() - full[idx]).max() < 2e-5
@@ -334,8 +346,17 @@ def test_hip_graph_replay_equals_eager_steps(cmu):
         assert np.abs(q - r).max() <= 2e-3 * 0.05 + 1e-7
         assert np.mean(np.abs(q - r)) <= 1e-7
     print("CMU step: eager %.3f ms, hipGraph replay %.3f ms" % (dte * 1e3, dtg * 1e3))
-    # changing an input object falls back to eager steps and a new capture
+    # an output of a captured step lives in the capture's buffer: reading it after a later step raises
+    o1 = clfg.f_train(c['X'], ytr, ydv, c['A'], c['tr'], c['dev'])
+    o2 = clfg.f_train(c['X'], ytr, ydv, c['A'], c['tr'], c['dev'])
+    with pytest.raises(RuntimeError):
+        np.asarray(o1[4])
+    assert np.isfinite(np.asarray(o2[4])).all()
+    # inputs are recognised by CONTENT: an equal copy replays the capture, changed labels fall back to eager + re-capture
+    out = clfg.f_train(c['X'], c['Y'][c['tr']].copy(), c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+    assert clfg._hg['graph'] is not None and np.isfinite(out[0])
     ytr2 = c['Y'][c['tr']].copy()
+    ytr2[:5] = (ytr2[:5] + 1) % c['C']
     out = clfg.f_train(c['X'], ytr2, c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
     assert clfg._hg['graph'] is None and np.isfinite(out[0])
 

@@ -495,6 +495,39 @@ def test_spmm_x_dense_head_plus_tail(dev, n_docs, n_words, mean, F, slab, monkey
     assert np.all(np.abs(dC.numpy() - ref) <= 3e-6 * (np.abs(C0) + np.asarray(abs(A).astype(np.float64) @ np.abs(W))) + 1e-6)
 
 
+@pytest.mark.parametrize("n_docs,n_words,mean,F,n_hot", [(30000, 2000, 40, 300, None), (9000, 700, 25, 129, None), (5000, 300, 12, 64, 7),
+                                                        (4000, 600, 30, 384, None), (3000, 50, 6, 5, 0), (2500, 90, 6, 20, 1000)])
+def test_spmm_hot_rows_in_lds(dev, n_docs, n_words, mean, F, n_hot):
+    """geogcn_spmm_csr_hot_f32 (X . W0 with the hot rows of W0 in LDS): against the fp64 product and the plain gather
+    kernel; the [hot | cold] reordering only changes the summation order; bitwise reproducible; every n_hot from 0 to
+    "all columns" is valid."""
+    from geographconv_amd import _ffi, ops
+    X = sps.csr_matrix(_bow(n_docs, n_words, mean, seed=3))
+    X.data[::5] *= -1.0
+    csr = ops.CSR(X, dev)
+    cap = int(_ffi.lib().geogcn_spmm_hot_capacity(F))
+    assert cap > 0
+    hot = ops.HotCSR(csr, X.data, cap if n_hot is None else min(n_hot, cap))
+    W = _rand((n_words, F), 4, 0.1)
+    b = _rand((F,), 5, 0.1)
+    dWm = ops.DMat.from_numpy(W, dev)
+    db = torch.from_numpy(np.pad(b, (0, ops.pad4(F) - F))).to(dev)
+    got = ops.DMat(n_docs, F, dev)
+    got.t.fill_(9.0)
+    ops.spmm_hot(hot, dWm, out=got, bias=db, act=ops.ACT_TANH)
+    ref = np.tanh(X.astype(np.float64) @ W.astype(np.float64) + b)
+    tol = 3e-6 * np.asarray(abs(X).astype(np.float64) @ np.abs(W)) + 1e-6
+    assert np.all(np.abs(got.numpy() - ref) <= tol)
+    assert torch.all(got.t[:, F:] == 0)
+    assert torch.equal(ops.spmm_hot(hot, dWm, bias=db, act=ops.ACT_TANH).t, got.t)
+    plain = ops.spmm(csr, dWm, bias=db, act=ops.ACT_TANH)
+    assert np.all(np.abs(plain.numpy() - got.numpy()) <= 2 * tol)
+    if n_hot == 0:
+        assert hot.hot_fraction == 0.0
+        assert torch.equal(ops.spmm_hot(hot, dWm).t, ops.spmm(csr, dWm).t)        # no hot part: the same order, bitwise
+    assert int(_ffi.lib().geogcn_spmm_hot_capacity(2000)) == 0
+
+
 def test_gemm_asymmetric_detects_transposes(dev):
     """A = I check with an asymmetric B (guide rule: symmetric inputs hide row/col swaps)."""
     from geographconv_amd import ops

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--shape', default='twus')
+    ap.add_argument('--only', default='all', choices=['all', 'fwd', 'xt'])
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     s = synth.SHAPES[args.shape]
@@ -39,18 +40,21 @@ def main():
     def show(name, ms, alg):
         print('%-52s %.3f ms   alg %.0f GB/s (%.1f %% of 8 TB/s)' % (name, ms, alg / ms / 1e6, alg / ms / 1e6 / 80), flush=True)
 
-    show('X.W0   one CSR gather kernel', timeit(lambda: ops.spmm(x.fwd, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
-    for slab in (0, 64, 128):
-        ops.X_FWD_SLAB = slab
-        show('X.W0   dense head GEMM + tail (slab %d)' % slab,
-             timeit(lambda: ops.spmm_x(x, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
-    ops.X_FWD_SLAB = 0
-    Wh = ops.DMat(x.head_dense.F, F, dev)
-    show('   head GEMM alone  N x %d x %d' % (x.head_dense.F, F), timeit(lambda: ops.gemm(x.head_dense, Wh, out=out), args.reps)[0], alg_fwd)
-    show('   tail accumulate alone', timeit(lambda: ops.spmm(x.fwd_tail, W, out=out, bias=b, act=1, accumulate=True), args.reps)[0], alg_fwd)
-    for c in (64, 128):
-        show('   tail, one %d-column slab' % c, timeit(lambda: ops._spmm_cols(x.fwd_tail, W, out, b, 1, 0, c), args.reps)[0], alg_fwd)
-
+    if args.only in ('all', 'fwd'):
+      cap = int(__import__('geographconv_amd._ffi', fromlist=['lib']).lib().geogcn_spmm_hot_capacity(F))
+      hot = ops.HotCSR(x.fwd, X.data, cap)
+      print('hot rows in LDS: %d -> %.1f %% of the stored entries' % (hot.n_hot, 100 * hot.hot_fraction))
+      show('X.W0   hot rows of W0 in LDS (%d rows)' % hot.n_hot, timeit(lambda: ops.spmm_hot(hot, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
+      for nh in (32, 64):
+          h2 = ops.HotCSR(x.fwd, X.data, nh)
+          show('X.W0   hot rows of W0 in LDS (%d rows, %.0f %%)' % (nh, 100 * h2.hot_fraction),
+               timeit(lambda: ops.spmm_hot(h2, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
+      ops.X_FWD_MODE = 'split'
+      show('X.W0   one CSR gather kernel', timeit(lambda: ops.spmm(x.fwd, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
+      show('X.W0   dense head GEMM + tail', timeit(lambda: ops.spmm_x(x, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
+    if args.only == 'fwd':
+        return
+    print('doc block %s rows, rendezvous %s' % (os.environ.get('GEOGCN_XT_DOC_BLOCK', '1024'), os.environ.get('GEOGCN_XT_RENDEZVOUS', '1')))
     for name, g in (('ld 320', G), ('ld 300', G300)):
         ops.XT_MIN_NNZ = 0
         show('X^T.dS0  head GEMM + document-blocked tail (%s)' % name, timeit(lambda: ops.spmm_t(x, g, out=dW), args.reps)[0], alg_bwd)
