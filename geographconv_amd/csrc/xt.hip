@@ -52,7 +52,7 @@ inline double unit_cap() {
     static const double v = [] {
         const char* e = getenv("GEOGCN_XT_UNIT_CAP");
         const double c = e ? atof(e) : 0.0;
-        return c > 0.0 ? c : 1.0;
+        return c > 0.0 ? c : 2.0;
     }();
     return v;
 }
@@ -86,7 +86,7 @@ struct XtArgs {
     // virtual XCD x that have ENTERED block blk of batch r.  A workgroup enters block blk + 2 only once all of them
     // have entered block blk -- with a bounded wait: results never depend on it.
     unsigned* arrive;
-    int max_blocks, spin_limit;
+    int max_blocks, spin_limit, prefetch;
 };
 
 template <int K4>
@@ -117,6 +117,20 @@ __global__ __launch_bounds__(wg_threads(K4), 1) void xt_tail_kernel(const XtArgs
 #pragma unroll
             for (int k = 0; k < K4; ++k) acc[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // the next <= 16 entries of every unit are always loaded one step ahead (at the end of the previous block)
+        int doc[U];
+        float v[U];
+        auto load_entries = [&](int u) {
+            const int p = cur[u] + lane;
+            doc[u] = 0x7fffffff;
+            v[u] = 0.f;
+            if (p < endp[u]) {
+                doc[u] = a.docidx[p];
+                v[u] = a.val[p];
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_entries(u);
         int blk = 0;
         for (int b0 = d0; b0 < d1; b0 += a.doc_block, ++blk) {
             const int be = min(d1, b0 + a.doc_block);
@@ -133,18 +147,19 @@ __global__ __launch_bounds__(wg_threads(K4), 1) void xt_tail_kernel(const XtArgs
                 }
             }
             __syncthreads();          // the groups of a workgroup move through the document blocks together
-            // next <= 16 entries of every unit first: independent loads, both in flight before either is consumed
-            int doc[U];
-            float v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int p = cur[u] + lane;
-                doc[u] = 0x7fffffff;
-                v[u] = 0.f;
-                if (p < endp[u]) {
-                    doc[u] = a.docidx[p];
-                    v[u] = a.val[p];
-                }
+            // L2 prefetch of the NEXT block: this workgroup touches one dword of every 128-byte line of its 1/32 slice
+            // of the block's rows (the other 31 workgroups of the XCD touch theirs), so that by the time the sweep
+            // gets there the gathers hit L2 instead of waiting ~2 us each for HBM.  The value is consumed (discarded)
+            // at the end of this step: the load stays in flight under the gathers.
+            float pf = 0.f;
+            if (a.prefetch) {
+                const int n0 = be, n1 = min(d1, be + a.doc_block);
+                const int per = (n1 - n0 + kSlots - 1) / kSlots;
+                const int lines_per_row = (int)((a.ldg * 4 + 127) / 128);
+                const int i = threadIdx.x;
+                const int row = n0 + c * per + i / lines_per_row;
+                if (i < per * lines_per_row && row < min(n1, n0 + (c + 1) * per))
+                    pf = a.G[(int64_t)row * a.ldg + (i % lines_per_row) * 32];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -191,16 +206,11 @@ __global__ __launch_bounds__(wg_threads(K4), 1) void xt_tail_kernel(const XtArgs
                         }
                     }
                     cur[u] += cnt;
+                    load_entries(u);              // the next 16 (for this block if the batch was full, else for the next)
                     if (cnt < kGroup) break;
-                    const int p = cur[u] + lane;          // a full batch inside the block: the next 16
-                    doc[u] = 0x7fffffff;
-                    v[u] = 0.f;
-                    if (p < endp[u]) {
-                        doc[u] = a.docidx[p];
-                        v[u] = a.val[p];
-                    }
                 }
             }
+            asm volatile("" ::"v"(pf));
         }
         // this batch's accumulators -> partial[x][slot]
 #pragma unroll
@@ -286,7 +296,8 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
     std::vector<Unit> units;
     int n_batches = (int)std::max<int64_t>(1, cdiv((int64_t)words.size(), slots_per_batch));
     for (int it = 0; it < 8; ++it) {
-        // (unit_cap = how many average group shares one unit may weigh: 1 = best balance, more batches)
+        // (unit_cap = how many average group shares one unit may weigh: 1 = best balance but 4 batches at the TwitterUS
+        //  shape, 2 = 3 batches: measured 1.50 against 1.59 ms)
         const double share = unit_cap() * std::max(16.0, (double)plan->nnz / ((double)n_batches * kSlots * plan->groups));
         units.clear();
         for (int w : words) {
@@ -396,6 +407,13 @@ int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const
             const char* e = getenv("GEOGCN_XT_RENDEZVOUS");       // 1 = soft per-XCD rendezvous (experiment switch)
             return (e && e[0] == '1') ? 1 : 0;
         }();
+        static const int prefetch = [] {
+            // 1 = every workgroup touches its slice of the NEXT block's lines while the current block is swept.
+            // Measured (profiles/r02_xt_sweep.txt): slower -- 1.84-1.96 ms against 1.50-1.54 -- the touching wave itself
+            // waits ~2 us for HBM at the end of the step; off
+            const char* e = getenv("GEOGCN_XT_PREFETCH");
+            return (e && e[0] == '1') ? 1 : 0;
+        }();
         unsigned* arrive = rendezvous ? (unsigned*)ws : nullptr;
         if (arrive) {
             const int zrc = zero_fill_async(arrive, xt_arrive_bytes(plan), st);
@@ -403,7 +421,8 @@ int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const
         }
         partial = (float*)((char*)ws + xt_arrive_bytes(plan));
         XtArgs a{docidx_t, val_t, G, ldg, F, plan->d_unit_word, plan->d_unit_part, plan->d_wptr, plan->d_doc_lo,
-                 plan->n_words, plan->n_batches, plan->doc_block, partial, ldp, plan->n_slots, arrive, plan->max_blocks, 4000};
+                 plan->n_words, plan->n_batches, plan->doc_block, partial, ldp, plan->n_slots, arrive, plan->max_blocks, 4000,
+                 prefetch};
         const dim3 grid((unsigned)(kNumXCD * kSlots));
         switch (plan->K4) {
 #define GEOGCN_XT(K)                                                                \
