@@ -51,6 +51,8 @@ SIGNATURES = {
                                 c_i64, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_f32_bf16c': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                                       c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_gemm_panels_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32,
+                                       c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_dual_workspace_bytes': (c_sz, [c_i32, c_i64, c_i64, c_i64, c_i64]),
     'geogcn_gemm_dual_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                      c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),

@@ -93,6 +93,6 @@ int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K);
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
-                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w = 0, int64_t panel_R = 0);
 
 }  // namespace geogcn

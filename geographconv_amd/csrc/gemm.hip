@@ -177,6 +177,11 @@ struct GemmArgs {
     int64_t kchunk;
     int n_mt, n_nt, nt_per_seg, n_split, xcd_order, n_kseg, nk0;
     int64_t slab_seg_w;        // MODE 1: column offset of N segment 1 inside a slab row
+    // MODE 0, N segment 0 only: C laid out as feature panels [N / panel_w][panel_R][panel_w] instead of row-major
+    // (element (i, j) at ((j / panel_w) * panel_R + i) * panel_w + j % panel_w): the send buffer of the multi-GPU
+    // repartition all-to-all, written straight from the accumulators.  0 = row-major.
+    int panel_w;
+    int64_t panel_R;
 };
 
 // Tile coordinates are wave-uniform (functions of blockIdx and loop counters); readfirstlane keeps them in
@@ -425,8 +430,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (col0 + r >= Nseg) x[r] = 0.f;
-                    if ((PROBE & 2) ? (x[0] == 123.456f) : (row_ok && col0 < Nseg))
-                        *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
+                    if ((PROBE & 2) ? (x[0] == 123.456f) : (row_ok && col0 < Nseg)) {
+                        float* dst = crow + col0;
+                        if (MODE == 0 && a.panel_w) {
+                            const int64_t q = col0 / a.panel_w;
+                            dst = Cout + (q * a.panel_R + row) * a.panel_w + (col0 - q * a.panel_w);
+                        }
+                        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+                    }
                     acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -498,6 +509,8 @@ struct GemmCall {
     int64_t N[2], K[2];
     int act[2];
     int accumulate;
+    int panel_w = 0;
+    int64_t panel_R = 0;
     int64_t maxN() const { return n_nseg == 2 ? std::max(N[0], N[1]) : N[0]; }
 };
 
@@ -534,6 +547,8 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
         a.bias[q] = c.bias[q]; a.N[q] = c.N[q]; a.K[q] = c.K[q]; a.act_on[q] = c.act[q] != GEOGCN_ACT_NONE;
     }
     a.accumulate = c.accumulate;
+    a.panel_w = c.panel_w;
+    a.panel_R = c.panel_R;
     a.kchunk = sp.kchunk;
     a.n_mt = (int)cdiv(c.M, BM);
     a.n_nt = n_nt;
@@ -704,7 +719,8 @@ size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, i
 
 static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
                       int64_t lda, const float* B, int64_t ldb, void* Cv, int64_t ldc, int c_bf16, const float* bias,
-                      int32_t act, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
+                      int32_t act, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream,
+                      int panel_w = 0, int64_t panel_R = 0) {
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K >= 0, GEOGCN_E_SIZE, "%s: negative size", fn);
     GEOGCN_REQUIRE(precision >= GEOGCN_GEMM_F32 && precision <= GEOGCN_GEMM_BF16, GEOGCN_E_ARG,
                    "%s: unknown precision %d", fn, precision);
@@ -727,6 +743,11 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
         GEOGCN_REQUIRE(ldc % 8 == 0 && ldc >= ((N + 7) & ~(int64_t)7), GEOGCN_E_ALIGN,
                        "%s: a bf16 C needs ldc %% 8 == 0 and >= roundup8(N) (ldc=%lld)", fn, (long long)ldc);
     }
+    if (panel_w) {
+        GEOGCN_REQUIRE(!transA && !accumulate && K > 0 && panel_w % (c_bf16 ? 8 : 4) == 0 && panel_R >= M, GEOGCN_E_ARG,
+                       "%s: panel output needs transA = 0, accumulate = 0, K > 0, panel_w %% %d == 0, panel_R >= M", fn,
+                       c_bf16 ? 8 : 4);
+    }
     if (K == 0) {
         // an empty reduction (a rank that owns no rows: dW = H^T.dZ over zero nodes): the product is the zero matrix
         if (accumulate) return 0;
@@ -735,7 +756,7 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
     }
     if (!transA && precision != GEOGCN_GEMM_F32)
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
-                                  ws_bytes, st);
+                                  ws_bytes, st, panel_w, panel_R);
     float* C = (float*)Cv;
     if (transA && precision == GEOGCN_GEMM_BF16) {
         const int rc = gemm_bf16_tn_dispatch(M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, ws, ws_bytes, st);
@@ -745,6 +766,7 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
     c.M = M; c.n_nseg = 1; c.n_kseg = 1;
     c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = C; c.ldc[0] = ldc; c.bias[0] = bias;
     c.N[0] = N; c.K[0] = K; c.act[0] = act; c.act[1] = GEOGCN_ACT_NONE; c.accumulate = accumulate;
+    c.panel_w = panel_w; c.panel_R = panel_R;
     return run_call(transA != 0, transB != 0, c, ws, ws_bytes, st);
 }
 
@@ -760,6 +782,20 @@ int geogcn_gemm_f32_bf16c(int32_t transB, int64_t M, int64_t N, int64_t K, const
                           size_t ws_bytes, void* stream) {
     return gemm_entry("gemm_f32_bf16c", 0, transB, M, N, K, A, lda, B, ldb, C, ldc, 1, bias, act, 0, GEOGCN_GEMM_BF16, ws,
                       ws_bytes, stream);
+}
+
+// C as feature panels [W][R][wp] (fp32, or bf16 with precision = GEOGCN_GEMM_BF16 and c_bf16 = 1)
+int geogcn_gemm_panels_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                           int64_t ldb, void* panels, int64_t R, int32_t W, int32_t wp, int32_t c_bf16, const float* bias,
+                           int32_t act, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(W > 0 && wp > 0 && (int64_t)W * wp >= N && R >= M, GEOGCN_E_SIZE,
+                   "gemm_panels_f32: need W * wp >= N and R >= M (W=%d wp=%d N=%lld R=%lld M=%lld)", W, wp, (long long)N,
+                   (long long)R, (long long)M);
+    GEOGCN_REQUIRE(!c_bf16 || precision == GEOGCN_GEMM_BF16, GEOGCN_E_ARG, "gemm_panels_f32: bf16 panels need precision = BF16");
+    // (ldc only has to pass the row-major checks: the panel addressing replaces it)
+    const int64_t ldc = c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3);
+    return gemm_entry("gemm_panels_f32", 0, transB, M, N, K, A, lda, B, ldb, panels, ldc, c_bf16, bias, act, 0, precision, ws,
+                      ws_bytes, stream, wp, R);
 }
 
 // (C0, C1) = (act0(op(A).B0 + bias0), act1(op(A).B1 + bias1)) in one launch, exact fp32

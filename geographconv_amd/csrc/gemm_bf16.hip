@@ -76,6 +76,8 @@ struct Bf16Args {
     int n_mt, n_nt;
     int c_bf16;
     int64_t n_store;                    // columns written per row (pads beyond N as zeros)
+    int panel_w;                        // > 0: C is laid out as feature panels [N / panel_w][panel_R][panel_w] (gemm.hip)
+    int64_t panel_R;
 };
 
 template <int BM, int BN, int NS, int NT>
@@ -304,13 +306,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
                     for (int r = 0; r < 4; ++r)
                         if (col0 + r >= a.N) x[r] = 0.f;
                     if (row_ok && col0 < a.n_store) {
+                        int64_t off = row * a.ldc + col0;
+                        if (a.panel_w) {
+                            const int64_t q = col0 / a.panel_w;
+                            off = (q * a.panel_R + row) * a.panel_w + (col0 - q * a.panel_w);
+                        }
                         if (a.c_bf16) {
                             uint2 w;
                             w.x = bf16_rne(x[0]) | (bf16_rne(x[1]) << 16);
                             w.y = bf16_rne(x[2]) | (bf16_rne(x[3]) << 16);
-                            *reinterpret_cast<uint2*>((unsigned short*)a.C + row * a.ldc + col0) = w;
+                            *reinterpret_cast<uint2*>((unsigned short*)a.C + off) = w;
                         } else {
-                            *reinterpret_cast<float4*>((float*)a.C + row * a.ldc + col0) = make_float4(x[0], x[1], x[2], x[3]);
+                            *reinterpret_cast<float4*>((float*)a.C + off) = make_float4(x[0], x[1], x[2], x[3]);
                         }
                     }
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -515,7 +522,7 @@ size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
 // called by geogcn_gemm_f32 for transA == 0 and precision != F32
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
-                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w, int64_t panel_R) {
     const int ns = (precision == GEOGCN_GEMM_BF16X3) ? 3 : 1;
     const int Kp = (int)(cdiv(K, BKH) * BKH);
     const size_t need = gemm_bf16_workspace_bytes(precision, N, K);
@@ -531,7 +538,7 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
     // (ties -> 160: fewer N tiles, and every N tile converts its A tile from fp32 again)
     const int bn = (cdiv(N, 160) * 160 <= cdiv(N, 128) * 128) ? 160 : 128;
     Bf16Args a{M, N, K, A, lda, planes, Kp, C, ldc, bias, accumulate, (int)cdiv(M, 128), (int)cdiv(N, bn), c_bf16,
-               c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3)};
+               c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3), panel_w, panel_R};
     if (ns == 3) {      // 8 waves per block: half the accumulators / staging registers per lane
         if (bn == 160) return launch_bf16<128, 160, 3, 512>(a, act, st);
         return launch_bf16<128, 128, 3, 512>(a, act, st);

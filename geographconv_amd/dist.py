@@ -1,21 +1,25 @@
 """Full-graph GCN across the GPUs of one node.  The reference has no distributed
 code at all (single process, gcnmodel.py:409-430).
 
-Rank r owns the contiguous row block [r*R, min(N, (r+1)*R)) of X, H, Y (R = ceil(N / world));
-parameters are replicated; parameter gradients and the four loss/accuracy sums are all-reduced
-once per step over a flat arena.  The only per-layer exchange is around the graph convolution
-S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two interchangeable schemes:
+Rank r owns a contiguous row block of X, H, Y; parameters are replicated; parameter gradients and the four
+loss/accuracy sums are all-reduced once per step over a flat arena.  The only per-layer exchange is around the graph
+convolution S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two interchangeable schemes:
 
 ``a2a`` (default from 3 ranks) -- REPARTITION BY FEATURES.  Every rank keeps the whole (88 MB) A_hat.  The
-    row-partitioned Z (n_local x F) is packed into `world` feature panels of width wp = ceil4(F/world)
-    and exchanged with ONE all-to-all, so that rank q holds panel q of ALL rows (N x wp); it runs
-    the SpMM on that narrow operand (bias + activation fused, they are per column) and a second
-    all-to-all returns the result to the row partition.  Per rank and exchange 2*(w-1)/w * N/w * F
-    floats move -- 116 MB at w = 8, F = 300 -- instead of the (w-1)/w * N * F (462 MB) an all-gather
-    would deliver to every rank, and an all-to-all keeps all 7 xGMI links of a GPU busy at once.
-``allgather`` -- 1-D row split of A_hat as well: the local GEMM writes Z_r straight into rank r's
-    slot of the gathered buffer, all_gather_into_tensor runs in place, the local SpMM reads the
-    whole gathered matrix.  Simple, but communication-bound beyond 2 GPUs on a graph without locality.
+    row-partitioned Z (n_local x F) is laid out as `world` feature panels of width wp = ceil4(F/world) -- the GEMM that
+    produces it writes that layout straight from its accumulators (ops.Panels, geogcn_gemm_panels_f32) -- and exchanged
+    with ONE all-to-all, so that rank q holds panel q of ALL rows (N x wp); it runs the SpMM on that narrow operand
+    (bias + activation fused, they are per column) and a second all-to-all returns the result to the row
+    partition.  Per rank and exchange 2*(w-1)/w * N/w * F floats move -- 116 MB at w = 8, F = 300 -- instead of the
+    (w-1)/w * N * F (462 MB) an all-gather would deliver to every rank, and an all-to-all keeps all 7 xGMI links of a GPU
+    busy at once.  Both all-to-alls are asynchronous: the caller runs independent work between begin / mid / end.
+``allgather`` -- 1-D row split of A_hat as well (the north_star's scheme): the local GEMM writes Z_r straight into rank
+    r's slot of the gathered buffer, all_gather_into_tensor runs in place, the local SpMM reads the whole gathered
+    matrix.  The row split is balanced by COST (stored edges + a per-row term), not by row count: on a power-law graph a
+    rank holding the hubs would otherwise do several times the SpMM work of the others.
+
+In the bf16 configuration (`gemm_precision='bf16'`, BASELINE config 5) the exchanged operand is bfloat16 in both schemes
+(the GEMM stores it as such; dS is cast while it is staged): half the bytes on the wire and per gathered row.
 
 Collectives go through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in
 the CPU tests).  GEOGCN_DIST_EXCHANGE=a2a|allgather overrides the default (all-gather at 2 ranks, a2a from 3)."""
@@ -29,41 +33,87 @@ import torch
 
 from . import backend
 
+# cost of one row in stored-edge equivalents when balancing the all-gather scheme's row split: the dense work of a row
+# (15 GEMMs + elementwise + its share of the X path: ~44 ns at the TwitterUS shape) over the SpMM cost of one stored edge
+# (6 products, ~0.97 ns) -- DESIGN.md section 5
+ROW_COST_IN_EDGES = 45.0
+
+
+def balanced_bounds(indptr, world, row_cost=ROW_COST_IN_EDGES):
+    """Row boundaries b[0..world] (b[0] = 0, b[world] = N) that equalise sum(nnz(row) + row_cost) per block."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    N = len(indptr) - 1
+    cum = indptr + row_cost * np.arange(N + 1, dtype=np.float64)          # cost of rows [0, i)
+    targets = cum[-1] * np.arange(1, world, dtype=np.float64) / world
+    cuts = np.searchsorted(cum, targets, side='left')
+    return np.concatenate([[0], np.minimum(cuts, N), [N]]).astype(np.int64)
+
 
 class RowPartition:
-    def __init__(self, N: int, world: int, rank: int):
+    """Contiguous row blocks [bounds[r], bounds[r+1]).  Exchange buffers give every rank a SLOT of R = max block size
+    rows: global row g of rank r sits at slot position r * R + (g - bounds[r]).  With the default uniform split
+    (R = ceil(N / world)) slot position == global index."""
+
+    def __init__(self, N: int, world: int, rank: int, bounds=None):
         self.N, self.world, self.rank = int(N), int(world), int(rank)
-        self.R = (self.N + self.world - 1) // self.world          # rows per slot
-        self.r0 = min(self.N, self.rank * self.R)
-        self.r1 = min(self.N, self.r0 + self.R)
+        if bounds is None:
+            R = (self.N + self.world - 1) // self.world
+            bounds = np.minimum(self.N, R * np.arange(self.world + 1, dtype=np.int64))
+            self.uniform = True
+        else:
+            bounds = np.asarray(bounds, dtype=np.int64)
+            assert len(bounds) == self.world + 1 and bounds[0] == 0 and bounds[-1] == self.N and np.all(np.diff(bounds) >= 0)
+            R = int(np.diff(bounds).max()) if self.world else 0
+            self.uniform = False
+        self.bounds_all = bounds
+        self.R = max(int(R), 1) if self.N else int(R)
+        self.r0, self.r1 = int(bounds[self.rank]), int(bounds[self.rank + 1])
         self.n_local = self.r1 - self.r0
-        self.n_gathered = self.R * self.world                       # >= N; tail rows stay zero
+        self.n_gathered = self.R * self.world                       # >= N; unused slot rows stay zero
 
     def bounds(self, rank):
-        r0 = min(self.N, rank * self.R)
-        return r0, min(self.N, r0 + self.R)
+        return int(self.bounds_all[rank]), int(self.bounds_all[rank + 1])
+
+    def slot_position(self, g):
+        """Global row indices -> positions in the gathered (slot) layout."""
+        g = np.asarray(g, dtype=np.int64)
+        owner = np.searchsorted(self.bounds_all, g, side='right') - 1
+        owner = np.clip(owner, 0, self.world - 1)
+        return owner * self.R + (g - self.bounds_all[owner])
 
     def local_rows(self, m):
         """Row block of a scipy matrix / numpy array."""
         return m[self.r0:self.r1]
 
+    def _remap_columns(self, m: sps.csr_matrix, n_cols):
+        """Same stored order (= same accumulation order as on one GPU), column ids replaced by slot positions."""
+        cols = self.slot_position(m.indices).astype(np.int32) if not self.uniform else m.indices
+        return sps.csr_matrix((m.data, cols, m.indptr), shape=(m.shape[0], n_cols))
+
     def local_rows_csr(self, m: sps.spmatrix, pad_cols_to=None):
-        """Local row block of a CSR matrix, columns widened to the gathered height so that the
-        SpMM's n_cols matches the gathered operand (extra columns are empty)."""
-        blk = sps.csr_matrix(m)[self.r0:self.r1]
-        if pad_cols_to is not None and pad_cols_to != blk.shape[1]:
-            blk = sps.csr_matrix((blk.data, blk.indices, blk.indptr), shape=(blk.shape[0], pad_cols_to))
-        return blk
+        """Local row block of a CSR matrix whose columns index the gathered operand (slot positions; the extra
+        columns are empty)."""
+        blk = sps.csr_matrix(sps.csr_matrix(m)[self.r0:self.r1])
+        width = blk.shape[1] if pad_cols_to is None else pad_cols_to
+        if self.uniform and width == blk.shape[1]:
+            return blk
+        return self._remap_columns(blk, width)
 
     def padded_square_csr(self, m: sps.spmatrix):
-        """The whole matrix grown to n_gathered x n_gathered (empty tail rows / columns): the operand
-        of the feature-partitioned SpMM, whose dense operand is laid out by gathered row index."""
+        """The whole matrix in slot coordinates, n_gathered x n_gathered (empty rows / columns where a slot is not
+        full): the operand of the feature-partitioned SpMM, whose dense operand and result are laid out by slot."""
         m = sps.csr_matrix(m)
         g = self.n_gathered
         if m.shape == (g, g):
             return m
-        indptr = np.concatenate([m.indptr, np.full(g - m.shape[0], m.indptr[-1], dtype=m.indptr.dtype)])
-        return sps.csr_matrix((m.data, m.indices, indptr), shape=(g, g))
+        if self.uniform:
+            indptr = np.concatenate([m.indptr, np.full(g - m.shape[0], m.indptr[-1], dtype=m.indptr.dtype)])
+            return sps.csr_matrix((m.data, m.indices, indptr), shape=(g, g))
+        counts = np.zeros(g, dtype=np.int64)
+        counts[self.slot_position(np.arange(m.shape[0]))] = np.diff(m.indptr)
+        indptr = np.concatenate([[0], np.cumsum(counts)]).astype(m.indptr.dtype)
+        # rows keep their relative order inside each block and blocks are ascending: the data order is unchanged
+        return sps.csr_matrix((m.data, self.slot_position(m.indices).astype(np.int32), indptr), shape=(g, g))
 
     def split_indices(self, idx: np.ndarray, y: np.ndarray = None):
         """Global row indices -> (local indices, selected labels) for the rows this rank owns."""
@@ -82,16 +132,19 @@ class Comm:
         self.part = None if N is None else RowPartition(N, 1, 0)
         self.device = device
 
+    def prepare(self, A_host):
+        """Hook called with the host adjacency before anything is partitioned (row-split balancing)."""
+
     def graph_operand(self, A_host, hub_row_bytes=None):
         K = backend.active()
         return K.SparseOperand.from_scipy(A_host, self.device, dense_head=False, hub_row_bytes=hub_row_bytes)
 
-    def matmul_target(self, F, tag=None):
+    def matmul_target(self, F, tag=None, precision=None, direct=True):
         """Where the GEMM that produces the SpMM's dense operand should write (n_local x F)."""
         K = backend.active()
         return K.DMat.empty(self.part.N, F, self.device, ld=K.gather_ld(F))
 
-    def stage_operand(self, m, F, tag=None):
+    def stage_operand(self, m, F, tag=None, precision=None):
         """An existing matrix as the SpMM's dense operand (the backward's dS): used in place on one GPU; the
         partitioned communicator copies it into its exchange buffer."""
         return m
@@ -99,10 +152,13 @@ class Comm:
     def graph_spmm(self, A_csr, z, bias, act, F, tag=None):
         return self.graph_spmm_end(self.graph_spmm_begin(A_csr, z, bias, act, F, tag))
 
-    # two-phase form: `begin` starts the exchange of Z, `end` waits for it and multiplies.  Work the caller
-    # enqueues between the two (the highway gate's GEMMs) overlaps the collective.
+    # three-phase form: `begin` starts the exchange of Z, `mid` waits for it, multiplies and starts the return exchange,
+    # `end` waits for that.  Work the caller enqueues between the phases overlaps the collectives.
     def graph_spmm_begin(self, A_csr, z, bias, act, F, tag=None):
         return dict(A=A_csr, z=z, bias=bias, act=act, F=F, tag=tag, work=None)
+
+    def graph_spmm_mid(self, h):
+        return h
 
     def graph_spmm_end(self, h):
         return backend.active().spmm(h['A'], h['z'], bias=h['bias'], act=h['act'], F=h['F'])
@@ -166,118 +222,183 @@ class TorchDistComm(Comm):
             self.exchange = 'a2a' if self.world >= 3 else 'allgather'
         if self.exchange not in ('a2a', 'allgather'):
             raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a' or 'allgather', got %r" % self.exchange)
+        self.balance = os.environ.get('GEOGCN_DIST_BALANCE', '1') != '0'
         self._bufs = {}
+
+    # -- row split ---------------------------------------------------------------------------------------
+    def prepare(self, A_host):
+        """all-gather scheme: re-cut the row blocks so that every rank gets the same cost (stored edges + per-row
+        term) instead of the same number of rows.  Every rank computes the same cuts from the same host matrix.  The
+        a2a scheme keeps the uniform split: there the SpMM work does not depend on the row split (every rank walks all of
+        A_hat on its feature panel) and the dense work is proportional to rows."""
+        if self.exchange == 'allgather' and self.balance and self.world > 1:
+            A_csr = sps.csr_matrix(A_host)
+            if A_csr.shape[0] == self.part.N:
+                self.part = RowPartition(self.part.N, self.world, self.rank, bounds=balanced_bounds(A_csr.indptr, self.world))
+                self._bufs = {}
 
     # -- constant operand ----------------------------------------------------------------------------
     def graph_operand(self, A_host, hub_row_bytes=None):
-        """A_hat as this exchange scheme needs it: the whole matrix (a2a) or the local row block with
-        the column space widened to the gathered height (allgather)."""
+        """A_hat as this exchange scheme needs it: the whole matrix (a2a) or the local row block (allgather), columns
+        (and, for a2a, rows) in slot coordinates."""
         K = backend.active()
         part = self.part
         A_csr = sps.csr_matrix(A_host).astype(np.float32)
+        A_csr.sort_indices()
         At = sps.csr_matrix(A_csr.T)
+        At.sort_indices()
         if self.exchange == 'a2a':
             Af, Ab = part.padded_square_csr(A_csr), part.padded_square_csr(At)
         else:
             Af = part.local_rows_csr(A_csr, part.n_gathered)
             Ab = part.local_rows_csr(At, part.n_gathered)
-        Af.sort_indices()
-        Ab.sort_indices()
         same = (Af.shape == Ab.shape and np.array_equal(Af.indptr, Ab.indptr) and np.array_equal(Af.indices, Ab.indices)
                 and np.array_equal(Af.data, Ab.data))
+        # (slot positions are monotone in the global index: the stored order, hence the accumulation order, is unchanged)
         fwd = K.CSR(Af, self.device, hub_row_bytes=hub_row_bytes)
         bwd = fwd if same else K.CSR(Ab, self.device, hub_row_bytes=hub_row_bytes)
         return K.SparseOperand(fwd, bwd, same)
 
     # -- buffers ---------------------------------------------------------------------------------------
-    def _gather_buffer(self, F, tag):
+    def _gather_buffer(self, F, tag, bf16=False):
         K = backend.active()
-        key = ('ag', int(F), tag)
+        key = ('ag', int(F), tag, bool(bf16))
         buf = self._bufs.get(key)
         if buf is None:
-            # zero once: the tail rows of the last slot are never written and must read as 0
-            buf = self._bufs[key] = K.DMat(self.part.n_gathered, F, self.device, ld=K.gather_ld(F))
+            # zero once: the unused rows of a slot are never written and must read as 0
+            if bf16:
+                buf = K.HMat(self.part.n_gathered, F, self.device)
+                buf.t.zero_()
+            else:
+                buf = K.DMat(self.part.n_gathered, F, self.device, ld=K.gather_ld(F))
+            self._bufs[key] = buf
         return buf
 
-    def _flat(self, key, numel):
-        t = self._bufs.get(key)
-        if t is None or t.numel() != numel:
-            t = self._bufs[key] = torch.zeros(numel, dtype=torch.float32, device=self.device)
-        return t
-
-    def matmul_target(self, F, tag=None):
+    def _panels(self, kind, F, tag, bf16=False):
         K = backend.active()
+        wp = self.panel_width(F, bf16)
+        key = (kind, wp, tag, bool(bf16))
+        p = self._bufs.get(key)
+        if p is None:
+            p = self._bufs[key] = K.Panels(self.part.n_local, self.world * wp, self.part.R, self.world, wp, self.device, bf16=bf16)
+        p.F = int(F)
+        return p
+
+    @staticmethod
+    def _bf16(precision):
+        return backend.active().bf16_gather(precision)
+
+    def matmul_target(self, F, tag=None, precision=None, direct=True):
+        """Where the product that feeds the exchange should write: my slot of the gathered buffer (allgather) or the
+        all-to-all's send panels (a2a; `direct=False`: the producer is not a GEMM and needs a plain matrix, which
+        graph_spmm_begin then packs)."""
+        K = backend.active()
+        bf16 = self._bf16(precision) and direct
         if self.exchange == 'allgather':
-            buf = self._gather_buffer(F, tag)
+            buf = self._gather_buffer(F, tag, bf16)
             lo = self.rank * self.part.R
             return buf.rows(lo, lo + self.part.n_local)         # the GEMM writes straight into my slot
-        return K.DMat.empty(self.part.n_local, F, self.device)
+        if not direct:
+            return K.DMat.empty(self.part.n_local, F, self.device)
+        return self._panels('send', F, tag, bf16)
 
-    def stage_operand(self, m, F, tag=None):
-        g = self.matmul_target(F, tag=tag)
-        g.copy_from(m)
-        return g
+    def stage_operand(self, m, F, tag=None, precision=None):
+        """The backward's dS (a plain fp32 matrix) as the exchange's operand."""
+        K = backend.active()
+        bf16 = self._bf16(precision)
+        if self.exchange == 'allgather':
+            g = self.matmul_target(F, tag=tag, precision=precision)
+            if bf16:
+                K.cast_bf16(m, out=g)
+            else:
+                g.copy_from(m)
+            return g
+        send = self._panels('send', F, tag, bf16)
+        if bf16:
+            stage = self._panels('stage', F, tag, False)
+            K.pack_panels(m, self.part.R, self.world, send.wp, stage.t)
+            K.cast_bf16_flat(stage.t, send.t, send.wp)
+        else:
+            K.pack_panels(m, self.part.R, self.world, send.wp, send.t)
+        return send
 
     # -- the exchange around A . Z ----------------------------------------------------------------------
-    def panel_width(self, F):
-        K = backend.active()
-        return K.pad4((int(F) + self.world - 1) // self.world)
+    def panel_width(self, F, bf16=False):
+        q = 8 if bf16 else 4
+        return ((int(F) + self.world - 1) // self.world + q - 1) // q * q
 
     def graph_spmm_begin(self, A_csr, z, bias, act, F, tag=None):
         """Start act(A . Z + bias) for row-partitioned Z: the exchange of Z is issued asynchronously (RCCL runs it
-        on its own stream); finish with graph_spmm_end."""
+        on its own stream); continue with graph_spmm_mid / graph_spmm_end."""
         K = backend.active()
-        part, W = self.part, self.world
-        h = dict(A=A_csr, bias=bias, act=act, F=F, tag=tag)
+        h = dict(A=A_csr, bias=bias, act=act, F=F, tag=tag, mid=False)
         if self.exchange == 'allgather':
-            buf = self._gather_buffer(F, tag)
-            R = part.R
+            buf = self._gather_buffer(F, tag, isinstance(z, K.HMat))
+            R = self.part.R
             h['buf'] = buf
             h['work'] = self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group,
                                                          async_op=True)
             return h
-        R, wp = part.R, self.panel_width(F)
-        n = W * R * wp
-        send = self._flat(('send', wp, tag), n)
-        recv = self._flat(('recv', wp, tag), n)
-        K.pack_panels(z, R, W, wp, send)
-        h.update(send=send, recv=recv, wp=wp, n=n)
-        h['work'] = self.dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        if not isinstance(z, K.Panels):                          # a producer that could not write panels itself
+            send = self._panels('send', F, tag, False)
+            K.pack_panels(z, self.part.R, self.world, send.wp, send.t)
+            z = send
+        recv = self._panels('recv', F, tag, z.bf16)
+        h.update(send=z, recv=recv, wp=z.wp)
+        h['work'] = self.dist.all_to_all_single(recv.t, z.t, group=self.group, async_op=True)
+        return h
+
+    def graph_spmm_mid(self, h):
+        """a2a: wait for panel `rank` of all rows, multiply, start the return exchange.  allgather: nothing to do."""
+        if h['mid'] or self.exchange == 'allgather':
+            return h
+        K = backend.active()
+        part = self.part
+        h['mid'] = True
+        if h['work'] is not None:
+            h['work'].wait()            # nccl: the compute stream waits for the collective; gloo: the host does
+        F, wp = h['F'], h['wp']
+        sout = self._bufs.get(('sout', wp, h['tag']))
+        if sout is None:
+            sout = self._bufs[('sout', wp, h['tag'])] = K.DMat(part.n_gathered, wp, self.device, ld=wp)
+        # my panel holds columns [rank*wp, rank*wp + Fq) of the layer (the last panels may be partly / wholly padding)
+        Fq = max(0, min(wp, F - self.rank * wp))
+        if Fq > 0:
+            bias = h['bias']
+            bslab = None if bias is None else bias[self.rank * wp: self.rank * wp + K.pad4(Fq)]
+            K.spmm(h['A'], h['recv'].as_rows(), out=sout, bias=bslab, act=h['act'], F=Fq)
+        back = self._bufs.get(('back', wp, h['tag']))
+        if back is None:
+            back = self._bufs[('back', wp, h['tag'])] = torch.zeros(sout.t.numel(), dtype=torch.float32, device=self.device)
+        h['back'] = back
+        h['work2'] = self.dist.all_to_all_single(back, sout.t.view(-1), group=self.group, async_op=True)
         return h
 
     def graph_spmm_end(self, h):
         """-> row-partitioned result (n_local x F)."""
         K = backend.active()
-        part, W = self.part, self.world
-        if h['work'] is not None:
-            h['work'].wait()            # nccl: the compute stream waits for the collective; gloo: the host does
-        A_csr, bias, act, F, tag = h['A'], h['bias'], h['act'], h['F'], h['tag']
         if self.exchange == 'allgather':
-            return K.spmm(A_csr, h['buf'], bias=bias, act=act, F=F)
-        R, wp, n, send, recv = part.R, h['wp'], h['n'], h['send'], h['recv']
-        zslab = K.DMat(part.n_gathered, wp, t=recv.view(part.n_gathered, wp))     # panel `rank` of ALL rows
-        bslab = None
-        if bias is not None:
-            bp = torch.zeros(W * wp, dtype=torch.float32, device=self.device)
-            bp[:F].copy_(bias[:F])
-            bslab = bp[self.rank * wp:(self.rank + 1) * wp]
-        sslab = K.DMat(part.n_gathered, wp, t=send.view(part.n_gathered, wp))      # reuse the send buffer
-        K.spmm(A_csr, zslab, out=sslab, bias=bslab, act=act, F=wp)
-        back = self._flat(('back', wp, tag), n)
-        self.dist.all_to_all_single(back, send, group=self.group)
-        out = K.DMat.empty(part.n_local, F, self.device)
-        K.unpack_panels(back, R, W, wp, out)
+            if h['work'] is not None:
+                h['work'].wait()
+            return K.spmm(h['A'], h['buf'], bias=h['bias'], act=h['act'], F=h['F'])
+        self.graph_spmm_mid(h)
+        h['work2'].wait()
+        out = K.DMat.empty(self.part.n_local, h['F'], self.device)
+        K.unpack_panels(h['back'], self.part.R, self.world, h['wp'], out)
         return out
 
     def all_gather_rows(self, local):
-        """(n_local x F) -> (N x F) on every rank (used only to hand the full probability matrix back)."""
+        """(n_local x F) -> (N x F) on every rank, rows in GLOBAL order."""
         K = backend.active()
         buf = self._gather_buffer(local.F, 'out')
-        lo = self.rank * self.part.R
-        buf.rows(lo, lo + self.part.n_local).copy_from(local)
         R = self.part.R
-        self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group)
-        return buf
+        lo = self.rank * R
+        buf.rows(lo, lo + self.part.n_local).copy_from(local)
+        self.dist.all_gather_into_tensor(buf.t, buf.t[lo:lo + R], group=self.group)
+        if self.part.uniform:
+            return buf
+        pos = torch.from_numpy(self.part.slot_position(np.arange(self.part.N))).to(buf.t.device)
+        return K.DMat(self.part.N, local.F, t=buf.t.index_select(0, pos).contiguous())
 
     def all_reduce_sum_(self, t: torch.Tensor):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)

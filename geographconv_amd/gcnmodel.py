@@ -497,6 +497,8 @@ class GraphConv():
             raise ValueError("Input for this layer must be sparse")
         N = X.shape[0]
         comm = self._comm_for(N)
+        if self._dist(comm):
+            comm.prepare(A)               # (all-gather scheme: cost-balanced row split, cut from this adjacency)
         part = comm.part
         if self._dist(comm):
             dA = comm.graph_operand(A, hub_row_bytes=self.hub_row_bytes)

@@ -360,7 +360,10 @@ class DenseLayer(Layer):
 
     # ---- two-phase evaluation (multi-GPU): start the exchange of the SpMM operand early, finish later --------
     def _exchange_begin_fwd(self, input, A, comm, bias, act, prec):
-        z = comm.matmul_target(self.num_units, tag='fwd')
+        # (a plain H.W product writes the exchange's layout itself -- send panels / my slot of the gathered buffer, bf16 in
+        #  the bf16 configuration; other producers hand over a row-major matrix)
+        direct = type(self)._matmul is DenseLayer._matmul and isinstance(input, backend.active().DMat)
+        z = comm.matmul_target(self.num_units, tag='fwd', precision=prec, direct=direct)
         self._matmul(input, z, prec)
         return comm.graph_spmm_begin(A.fwd, z, bias, act, self.num_units, tag='fwd')
 
@@ -427,8 +430,14 @@ class DenseLayer(Layer):
         if getattr(A, 'head_dense', None) is not None:
             raise ValueError("a graph operand with a split transpose (dense head panel) cannot be exchanged: build "
                              "it with SparseOperand.from_scipy(..., dense_head=False)")
-        g = comm.stage_operand(dS, self.num_units, tag='bwd')
+        g = comm.stage_operand(dS, self.num_units, tag='bwd', precision=kwargs.get('gemm_precision'))
         return dS, comm.graph_spmm_begin(self._transpose_operand(A, grad, kwargs), g, None, 0, self.num_units, tag='bwd')
+
+    def backward_mid(self, tape, **kwargs):
+        """Between the two exchanges of a started backward: wait for dS, multiply by A^T, start the return exchange."""
+        pend = self._pending.get(('bwd', id(tape)))
+        if pend is not None:
+            kwargs['comm'].graph_spmm_mid(pend[1])
 
     def backward(self, grad, tape, into, need_input_grad=True, **kwargs):
         K = backend.active()
@@ -471,6 +480,9 @@ class DenseLayer(Layer):
                 return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
                                     accumulate=into[0] is not None)]
             K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ
+            after_dw = kwargs.get('after_dw')
+            if after_dw is not None:
+                after_dw()            # (partitioned sweep: the sibling convolution's SpMM + return exchange start here)
             if not need_input_grad:
                 return [None]
             if into[0] is not None:
@@ -683,12 +695,12 @@ def backward(layer, grad, tape, **kwargs):
     grads = {layer: grad}
     # which layers lie on a path from a parameterised/needed layer: all of them need grads except
     # pure inputs
-    def run(l):
+    def run(l, **extra):
         g = grads.pop(l)
         ins = l.input_layers if hasattr(l, 'input_layers') else [l.input_layer]
         into = [grads.get(i) if not isinstance(i, InputLayer) else None for i in ins]
         need = [not isinstance(i, InputLayer) for i in ins]
-        outs = l.backward(g, tape, into, need_input_grad=any(need), **kwargs)
+        outs = l.backward(g, tape, into, need_input_grad=any(need), **dict(kwargs, **extra))
         for i, o in zip(ins, outs):
             if o is not None and not isinstance(i, InputLayer):
                 grads[i] = o
@@ -706,8 +718,9 @@ def backward(layer, grad, tape, **kwargs):
             nxt = rev[pos + 1]
             if (not isinstance(nxt, InputLayer) and nxt in grads and nxt not in done
                     and nxt not in get_all_layers(l)):
+                # exchange of dS  ||  the gate's dW GEMM;   then SpMM;   return exchange  ||  the gate's dH GEMM
                 l.backward_begin(grads[l], tape, **kwargs)
-                run(nxt)
+                run(nxt, after_dw=lambda l=l: l.backward_mid(tape, **kwargs))
                 done.add(nxt)
         run(l)
         done.add(l)

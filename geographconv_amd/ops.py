@@ -129,6 +129,31 @@ class HMat:
         return self.t[:, :self.F].float().cpu().numpy()
 
 
+class Panels:
+    """A row-partitioned matrix (n_rows x F) stored as W feature panels of width wp: t[q][i][j] = M[i][q*wp + j], each
+    panel padded to R rows -- the send / receive layout of the multi-GPU feature repartition (one all-to-all hands panel
+    q of every rank to rank q).  fp32, or bfloat16 (`bf16=True`: operand and wire format of the bf16 configuration).
+    Pure container (device-agnostic, like DMat)."""
+    __slots__ = ('t', 'n', 'F', 'R', 'W', 'wp', 'bf16')
+
+    def __init__(self, n, F, R, W, wp, device, bf16=False, t=None):
+        self.n, self.F, self.R, self.W, self.wp, self.bf16 = int(n), int(F), int(R), int(W), int(wp), bool(bf16)
+        assert self.W * self.wp >= self.F and self.R >= self.n and self.wp % (8 if bf16 else 4) == 0
+        if t is None:
+            t = torch.zeros(self.W * self.R * self.wp, dtype=torch.bfloat16 if bf16 else torch.float32, device=device)
+        self.t = t
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def as_rows(self):
+        """The buffer seen as ONE matrix of W*R rows and wp columns (what rank q's SpMM gathers after the exchange:
+        row r*R + i = row i of rank r)."""
+        v = self.t.view(self.W * self.R, self.wp)
+        return HMat(self.W * self.R, self.wp, t=v) if self.bf16 else DMat(self.W * self.R, self.wp, t=v)
+
+
 def bf16_ld(F):
     """Pitch (elements) of a bf16 gather operand: rows start on 128-byte lines."""
     return (int(F) + 63) // 64 * 64
@@ -300,6 +325,15 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     ws = _gemm_ws.get(dev)
     if ws is None:
         ws = _gemm_ws[dev] = Workspace(dev)
+    if isinstance(out, Panels):
+        # multi-GPU: the product goes straight into the all-to-all's send layout (feature panels)
+        if transA or accumulate:
+            raise ValueError("gemm: a panel result needs transA=False, accumulate=False")
+        prec = _ffi.GEMM_BF16 if out.bf16 else GEMM_PRECISIONS[precision or GEMM_PRECISION]
+        w = ws.get(lib.geogcn_gemm_workspace_bytes(0, int(transB), M, N, K, prec))
+        check(lib.geogcn_gemm_panels_f32(int(transB), M, N, K, _p(A.t), A.ld, _p(B.t), B.ld, _p(out.t), out.R, out.W, out.wp,
+                                         int(out.bf16), _p(bias), act, prec, _p(w), w.numel(), _stream()), 'gemm_panels_f32')
+        return out
     if isinstance(out, HMat):
         # bf16 configuration: the product lands in bf16, the SpMM's operand format (no fp32 round trip)
         if transA or accumulate or (precision or GEMM_PRECISION) != 'bf16':
@@ -514,6 +548,13 @@ def pack_panels(X: DMat, R: int, W: int, wp: int, out: torch.Tensor):
     check(_ffi.lib().geogcn_pack_panels_f32(X.n, int(R), X.F, _p(X.t), X.ld, int(W), int(wp), _p(out), _stream()),
           'pack_panels_f32')
     return out
+
+
+def cast_bf16_flat(src: torch.Tensor, dst: torch.Tensor, width: int):
+    """fp32 -> bf16 over a flat buffer seen as rows of `width` elements (panel buffers)."""
+    n = src.numel() // width
+    check(_ffi.lib().geogcn_cast_bf16_f32(n, width, _p(src), width, _p(dst), width, _stream()), 'cast_bf16_f32')
+    return dst
 
 
 def unpack_panels(inp: torch.Tensor, R: int, W: int, wp: int, out: DMat):

@@ -187,6 +187,16 @@ int geogcn_gemm_f32_bf16c(int32_t transB, int64_t M, int64_t N, int64_t K, const
                           const float* B, int64_t ldb, uint16_t* C, int64_t ldc, const float* bias,
                           int32_t act, void* ws, size_t ws_bytes, void* stream);
 
+/* The same product with C laid out as FEATURE PANELS: panels[q][i][j] = C[i][q * wp + j] for q < W, i < R, j < wp
+ * (rows i >= M and columns >= N of the buffer are left untouched) -- the send buffer of the multi-GPU feature
+ * repartition (one all-to-all around the SpMM) written straight from the MFMA accumulators instead
+ * of by a separate pack pass.  transA = 0 only.  c_bf16 = 0: fp32 panels, wp % 4 == 0, any precision;  c_bf16 = 1:
+ * bfloat16 panels (the SpMM operand and wire format of the bf16 configuration), wp % 8 == 0, precision must be
+ * GEOGCN_GEMM_BF16.  No reference counterpart (the reference is single-device).                                */
+int geogcn_gemm_panels_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                           int64_t ldb, void* panels, int64_t R, int32_t W, int32_t wp, int32_t c_bf16, const float* bias,
+                           int32_t act, int32_t precision, void* ws, size_t ws_bytes, void* stream);
+
 /* Highway block, both weights in one launch (gcnmodel.py:281-286: the conv branch l_h and the gate l_t take the same
  * `incoming`).  Exact fp32 MFMA, same arithmetic per element as two geogcn_gemm_f32 calls:
  *   (C0, C1) = (act0(op(A) . B0 + bias0), act1(op(A) . B1 + bias1))       op(A) = A (transA = 0) or A^T (transA = 1)

@@ -8,7 +8,7 @@ import numpy as np
 import scipy.sparse as sps
 import torch
 
-from geographconv_amd.ops import DMat, gather_ld, pad4  # noqa: F401  (pure containers, device-agnostic)
+from geographconv_amd.ops import DMat, HMat, Panels, gather_ld, pad4  # noqa: F401  (pure containers, device-agnostic)
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 
@@ -62,7 +62,7 @@ def spmm(A, B, out=None, bias=None, act=ACT_NONE, F=None):
     r = np.asarray(A.m @ B.t.numpy()[:A.shape[1], :F])
     if bias is not None:
         r = r + bias.numpy()[:F]
-    _v(out)[...] = _act(r.astype(np.float32), act)
+    out.t.numpy()[:, :F] = _act(r.astype(np.float32), act)        # (F may be narrower than the output buffer)
     return out
 
 
@@ -81,6 +81,13 @@ def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, ac
     if bias is not None:
         r = r + bias.numpy()[:r.shape[1]]
     r = _act(r.astype(np.float32), act)
+    if isinstance(out, Panels):                      # the all-to-all's send layout, written by the product itself
+        o = out.t.numpy().reshape(out.W, out.R, out.wp)
+        for q in range(out.W):
+            c0, c1 = q * out.wp, min(r.shape[1], (q + 1) * out.wp)
+            if c1 > c0:
+                o[q, :r.shape[0], :c1 - c0] = r[:, c0:c1]
+        return out
     if out is None:
         out = DMat(r.shape[0], r.shape[1], A.device)
     if accumulate:

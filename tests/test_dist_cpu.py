@@ -44,6 +44,44 @@ def test_partition_split_indices_and_csr_padding():
     assert blk.shape == (2, 12) and (blk[:, :10] != A[8:10]).nnz == 0
 
 
+def test_cost_balanced_bounds_and_slot_layout():
+    """all-gather scheme: row blocks cut by cost (stored edges + a per-row term); the gathered buffer gives every rank a
+    slot of R = max block rows, and A's columns are renumbered to slot positions WITHOUT changing the stored order."""
+    from geographconv_amd.dist import balanced_bounds
+    A = synth.powerlaw_ahat(3000, 40000, seed=3)
+    w = 4
+    b = balanced_bounds(A.indptr, w, row_cost=10.0)
+    assert b[0] == 0 and b[-1] == 3000 and np.all(np.diff(b) > 0)
+    cost = np.diff(A.indptr) + 10.0
+    per = [cost[b[r]:b[r + 1]].sum() for r in range(w)]
+    assert max(per) <= 1.05 * (cost.sum() / w) + cost.max()              # balanced up to one (hub) row
+    rows = [b[r + 1] - b[r] for r in range(w)]
+    assert max(rows) > min(rows)                                        # not the uniform split
+    parts = [RowPartition(3000, w, r, bounds=b) for r in range(w)]
+    R = parts[0].R
+    assert R == max(rows) and parts[0].n_gathered == R * w
+    seen = np.zeros(3000, int)
+    for p in parts:
+        seen[p.r0:p.r1] += 1
+        pos = p.slot_position(np.arange(p.r0, p.r1))
+        assert np.array_equal(pos, p.rank * R + np.arange(p.n_local))
+        blk = p.local_rows_csr(A, p.n_gathered)
+        ref = A[p.r0:p.r1]
+        assert blk.shape == (p.n_local, R * w) and np.array_equal(blk.indptr, ref.indptr) and np.array_equal(blk.data, ref.data)
+        assert np.array_equal(blk.indices, p.slot_position(ref.indices))
+        assert blk.has_sorted_indices                                   # slot positions are monotone in the global index
+    assert np.all(seen == 1)
+    # the product through the slot layout equals the plain one
+    Z = np.random.RandomState(0).randn(3000, 7).astype(np.float32)
+    G = np.zeros((R * w, 7), np.float32)
+    G[parts[0].slot_position(np.arange(3000))] = Z
+    for p in parts:
+        assert np.array_equal(p.local_rows_csr(A, p.n_gathered) @ G, A[p.r0:p.r1] @ Z)
+    sq = parts[1].padded_square_csr(A)
+    S = sq @ G
+    assert np.array_equal(S[parts[0].slot_position(np.arange(3000))], A @ Z)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))

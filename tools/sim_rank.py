@@ -18,6 +18,11 @@ from geographconv_amd.dist import RowPartition, TorchDistComm  # noqa: E402
 from geographconv_amd.gcnmodel import GraphConv  # noqa: E402
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class FakeDist:
     class ReduceOp:
         SUM = 0
@@ -34,12 +39,14 @@ class FakeDist:
 
     def all_to_all_single(self, out, inp, group=None, async_op=False):
         out.copy_(inp)                                   # same bytes through HBM instead of xGMI
-        self.bytes_a2a += inp.numel() * 4 * (self.world - 1) // self.world
+        self.bytes_a2a += inp.numel() * inp.element_size() * (self.world - 1) // self.world
         self.n_a2a += 1
+        return _Done()
 
     def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
-        self.bytes_ag += out.numel() * 4 * (self.world - 1) // self.world
+        self.bytes_ag += out.numel() * out.element_size() * (self.world - 1) // self.world
         self.n_ag += 1
+        return _Done()
 
     def all_reduce(self, t, op=None, group=None):
         pass
@@ -53,6 +60,7 @@ class SimComm(TorchDistComm):
         self.part = RowPartition(N, world, rank)
         self.device = device
         self.exchange = exchange
+        self.balance = os.environ.get('GEOGCN_DIST_BALANCE', '1') != '0'
         self._bufs = {}
 
 
@@ -63,11 +71,13 @@ def main():
     ap.add_argument('--exchange', default='a2a')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--shape', default='twus')
+    ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
+    ap.add_argument('--gemm-precision', default='f32')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     A, X, Y, (tr, dv, te), C = synth.make_graph(args.shape)
     comm = SimComm(A.shape[0], dev, args.rank, args.world, args.exchange)
-    clf = GraphConv(X.shape[1], C, [300, 300, 300], 0.0, 0.5, highway=True, device=dev, comm=comm)
+    clf = GraphConv(X.shape[1], C, args.hid, 0.0, 0.5, highway=True, device=dev, comm=comm, gemm_precision=args.gemm_precision)
     clf.build_model(A, seed=77)
     for _ in range(2):
         clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
@@ -79,9 +89,10 @@ def main():
         clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print('world=%d rank=%d exchange=%s: %.2f ms compute per step; per step: %d all-to-all (%.0f MB on the wire), '
-          '%d all-gather (%.0f MB)' % (args.world, args.rank, args.exchange, ms, d.n_a2a // args.steps,
-                                       d.bytes_a2a / args.steps / 1e6, d.n_ag // args.steps, d.bytes_ag / args.steps / 1e6))
+    print('world=%d rank=%d exchange=%s %s rows %d (of %d): %.2f ms compute per step; per step: %d all-to-all (%.0f MB on the wire), '
+          '%d all-gather (%.0f MB)' % (args.world, args.rank, args.exchange, args.gemm_precision, comm.part.n_local, comm.part.N, ms,
+                                       d.n_a2a // args.steps, d.bytes_a2a / args.steps / 1e6, d.n_ag // args.steps,
+                                       d.bytes_ag / args.steps / 1e6))
 
 
 if __name__ == '__main__':
