@@ -315,9 +315,13 @@ class TorchDistComm(Comm):
             return g
         send = self._panels('send', F, tag, bf16)
         if bf16:
-            stage = self._panels('stage', F, tag, False)
-            K.pack_panels(m, self.part.R, self.world, send.wp, stage.t)
-            K.cast_bf16_flat(stage.t, send.t, send.wp)
+            # fp32 staging buffer with the bf16 panels' geometry (their width is a multiple of 8, not of 4)
+            key = ('stage', send.wp, tag)
+            stage = self._bufs.get(key)
+            if stage is None:
+                stage = self._bufs[key] = torch.zeros(send.t.numel(), dtype=torch.float32, device=self.device)
+            K.pack_panels(m, self.part.R, self.world, send.wp, stage)
+            K.cast_bf16_flat(stage, send.t, send.wp)
         else:
             K.pack_panels(m, self.part.R, self.world, send.wp, send.t)
         return send

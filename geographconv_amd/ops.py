@@ -128,6 +128,10 @@ class HMat:
     def numpy(self):
         return self.t[:, :self.F].float().cpu().numpy()
 
+    def rows(self, r0, r1):
+        """View of a row range (shares storage)."""
+        return HMat(r1 - r0, self.F, t=self.t[r0:r1])
+
 
 class Panels:
     """A row-partitioned matrix (n_rows x F) stored as W feature panels of width wp: t[q][i][j] = M[i][q*wp + j], each

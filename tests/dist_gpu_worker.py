@@ -46,7 +46,6 @@ def main():
         assert np.array_equal(pred[safe], z['val_pred'][safe]), name
     # the partitioned graph product against the one-GPU kernel on the same rows: BITWISE (row order and per-row
     # accumulation order do not depend on the partition; meaningful from 2 ranks on, trivially true at 1)
-    import numpy as np
     from geographconv_amd import ops, synth
     A = synth.powerlaw_ahat(6000, 70000, seed=1)
     Zh = np.random.RandomState(1).randn(6000, 44).astype(np.float32)
