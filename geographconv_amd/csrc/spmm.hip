@@ -510,6 +510,9 @@ int spmm_csr_impl(const char* fn, const geogcn_spmm_plan* plan, int32_t n_rows, 
     // narrow operands (F <= 32, e.g. the per-rank feature panels of C = 256 over 8 GPUs): 8 lanes per row,
     // twice as many rows in flight per wave (measured 0.306 -> 0.267 ms at F = 16); otherwise 16 lanes per row
     if (F4 <= 8) return launch_k4<1, 8, 0>(plan, n_rows, rowptr, colidx, val, B, ldb, C, ldc, F, bias, act, wsf, st, nnz, hw);
+    // (36..64 columns -- the per-rank feature panel of a 300-wide layer over 8 GPUs is 40 -- stay on 16 lanes x 1 float4:
+    //  8 lanes x 2 float4, eight rows in flight per wave, measured slower: 0.411 vs 0.385 ms at F = 40.  What sets the
+    //  time of these narrow products is the number of 128-byte lines per gathered row: F = 32 0.25 ms, F = 40 0.39, F = 64 0.41)
     const int K4 = (F4 + kGroup - 1) / kGroup;
     switch (K4) {
 #define GEOGCN_CASE(K)                                                                             \
