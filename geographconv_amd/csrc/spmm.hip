@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
-    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split, const HwArgs hw) {
+    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split, const HwArgs hw, const int per_xcd) {
     const int lane16 = threadIdx.x % G;
     const int nF4 = (F + 3) >> 2;
     float4 acc[K4];
@@ -230,7 +230,14 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
         }
         return;
     }
-    const int row = (blockIdx.x - n_chunk_blocks) * (kBlock / G) + (threadIdx.x / G);
+    // XCD-aware row blocks: block b runs on XCD b % 8 (measured; speed only), so XCD x takes the CONTIGUOUS range of row
+    // blocks [x * per_xcd, (x + 1) * per_xcd) and walks it in launch order.  When the node numbering has locality
+    // (geographconv_amd.graph: community reordering) the rows an XCD works on at any moment share their neighbours, and
+    // the gathered rows of B stay in that XCD's 4 MB L2; with the plain b -> row block map the eight L2s would each
+    // see every community in flight.  per_xcd = 0: plain map.
+    int rb = blockIdx.x - n_chunk_blocks;
+    if (per_xcd > 0) rb = (rb % kNumXCD) * per_xcd + rb / kNumXCD;
+    const int row = rb * (kBlock / G) + (threadIdx.x / G);
     if (row >= n_rows) return;
     const int s = rowptr[row];
     const int e = rowptr[row + 1];
@@ -370,9 +377,16 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     constexpr int kGroupsPerBlock = kBlock / G;
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
-    const int n_chunk_blocks = (int)cdiv(n_chunks, kGroupsPerBlock);
+    static const int xcd_rows = [] {
+        const char* e = getenv("GEOGCN_SPMM_XCD_ROWS");       // 0 = plain block -> row-block map (A/B switch)
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    // (chunk blocks padded to a multiple of 8 so that the row blocks start on XCD 0; surplus blocks exit at once)
+    const int n_chunk_blocks = (int)(cdiv(cdiv(n_chunks, kGroupsPerBlock), kNumXCD) * kNumXCD);
     const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
-    const dim3 grid((unsigned)(n_chunk_blocks + cdiv(n_rows, kGroupsPerBlock)));
+    const int n_row_blocks = (int)cdiv(n_rows, kGroupsPerBlock);
+    const int per_xcd = xcd_rows ? (int)cdiv(n_row_blocks, kNumXCD) : 0;
+    const dim3 grid((unsigned)(n_chunk_blocks + (per_xcd ? per_xcd * kNumXCD : n_row_blocks)));
     geogcn_timer* tm = g_spmm_timer;
     const bool timed = tm && (g_spmm_timer_F == 0 || g_spmm_timer_F == F) &&
                        (g_spmm_timer_nnz == 0 || g_spmm_timer_nnz == nnz) && tm->used < (int)tm->begin.size() &&
@@ -394,7 +408,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF, HW_>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
-                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw)
+                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw, per_xcd)
     if (n_rows > 0) {
         if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 0, 1); }        // highway epilogue: tanh branch only (checked by the caller)
         else if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }

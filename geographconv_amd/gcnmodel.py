@@ -382,7 +382,8 @@ class GraphConv():
     '''
 
     def __init__(self, input_size, output_size, hid_size_list, regul_coef, drop_out, dtype='float32',
-                 batchnorm=False, highway=True, device=None, comm=None, gemm_precision=None, hip_graph=None):
+                 batchnorm=False, highway=True, device=None, comm=None, gemm_precision=None, hip_graph=None,
+                 reorder=None):
         self.input_size = int(input_size)
         self.output_size = int(output_size)
         self.hid_size_list = list(hid_size_list)
@@ -399,6 +400,13 @@ class GraphConv():
         self.comm = comm
         # how H.W products are formed: None/'f32' exact fp32 MFMA (default), 'bf16x3', 'bf16' (BASELINE config 5)
         self.gemm_precision = gemm_precision
+        # node renumbering applied on the device side (geographconv_amd.graph: None | 'degree' | 'rcm' | 'bfs' | 'lpa'):
+        # callers keep using ORIGINAL node ids everywhere -- X / A rows, index vectors, injected masks go in permuted,
+        # per-node outputs come back restored.  Changes where the graph product's gathers land, never a value.
+        from . import graph as _graph
+        if reorder not in _graph.REORDERINGS:
+            raise ValueError("reorder must be one of %r" % (_graph.REORDERINGS,))
+        self.reorder = None if reorder in (None, 'none') else reorder
         self._graph_cache = {}
         self._idx_cache = {}
         self._injected_mask = None
@@ -493,10 +501,16 @@ class GraphConv():
         hit = self._graph_cache.get(key)
         if hit is not None and hit['X_ref'] is X and hit['A_ref'] is A:
             return hit
+        X_in, A_in = X, A
         if not sps.issparse(X):
             raise ValueError("Input for this layer must be sparse")
         N = X.shape[0]
         comm = self._comm_for(N)
+        ro = None
+        if self.reorder is not None and sps.issparse(A) and A.shape[0] == A.shape[1] == N:
+            from . import graph as _graph
+            ro = _graph.reordering(A, self.reorder)
+            A, X = ro.matrix(A), sps.csr_matrix(X)[ro.perm]
         if self._dist(comm):
             comm.prepare(A)               # (all-gather scheme: cost-balanced row split, cut from this adjacency)
         part = comm.part
@@ -508,7 +522,7 @@ class GraphConv():
             #  A^T as one CSR -- it only exists when A is not symmetric)
             dA = K.SparseOperand.from_scipy(A, self.device, dense_head=False, hub_row_bytes=self.hub_row_bytes)
             dX = K.SparseOperand.from_scipy(X, self.device)
-        hit = {'X_ref': X, 'A_ref': A, 'X': dX, 'A': dA, 'N': N, 'comm': comm}
+        hit = {'X_ref': X_in, 'A_ref': A_in, 'X': dX, 'A': dA, 'N': N, 'comm': comm, 'ro': ro, 'A_host': A}
         self._graph_cache = {key: hit}          # one graph resident at a time
         self._idx_cache = {}
         return hit
@@ -520,6 +534,8 @@ class GraphConv():
         hit = g.get('A_tr')
         if hit is not None and hit[0] == key:
             return hit[1]
+        if g.get('ro') is not None:
+            A, idx = g['A_host'], g['ro'].indices(idx)
         At = sps.csr_matrix(sps.csr_matrix(A).T).astype(np.float32)
         keep = np.zeros(At.shape[1], dtype=bool)
         keep[idx] = True
@@ -532,8 +548,9 @@ class GraphConv():
         g['A_tr'] = (key, csr)
         return csr
 
-    def _device_indices(self, comm, idx, y=None):
-        """Index / label vectors on the device (local share when distributed) + the global count.  Cached by content."""
+    def _device_indices(self, comm, idx, y=None, ro=None):
+        """Index / label vectors on the device (local share when distributed) + the global count.  Cached by content.
+        `ro`: the graph's node reordering (original ids -> device positions)."""
         import torch
         idx = np.asarray(idx)
         ya = None if y is None else np.asarray(y)
@@ -543,6 +560,8 @@ class GraphConv():
             return hit
         if idx.size and (idx.min() < 0 or idx.max() >= comm.part.N):
             raise IndexError("index out of bounds for %d nodes" % comm.part.N)
+        if ro is not None:
+            idx = ro.indices(idx)
         if ya is not None:
             if len(ya) != len(idx):
                 raise ValueError("%d labels for %d indices" % (len(ya), len(idx)))
@@ -585,7 +604,7 @@ class GraphConv():
         s = [float(v) for v in self._scal.cpu().numpy()]   # the one host sync of the step
         l_tr = s[0] / max(1, n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
         out = [np.float32(l_tr), np.float64(s[1] / max(1, n_tr)), np.float32(s[2] / max(1, n_dv)),
-               np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm)]
+               np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm, g.get('ro'))]
         return out
 
     def _train_step(self, g, y_train, y_dev, A, train_indices, dev_indices, counters):
@@ -594,11 +613,14 @@ class GraphConv():
         K = backend.active()
         import torch
         comm = g['comm']
-        tr_idx, tr_y, n_tr = self._device_indices(comm, train_indices, y_train)
-        dv_idx, dv_y, n_dv = self._device_indices(comm, dev_indices, y_dev)
+        ro = g.get('ro')
+        tr_idx, tr_y, n_tr = self._device_indices(comm, train_indices, y_train, ro)
+        dv_idx, dv_y, n_dv = self._device_indices(comm, dev_indices, y_dev, ro)
         mask = None
         if self._injected_mask is not None and self.drop_out > 0:
             m = self._injected_mask
+            if ro is not None:
+                m = ro.rows(m)
             if self._dist(comm):
                 m = m[comm.part.r0:comm.part.r1]
             mask = torch.from_numpy(np.ascontiguousarray(m)).to(self.device)
@@ -669,21 +691,23 @@ class GraphConv():
         with torch.cuda.graph(graph):
             P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, 'captured')
         # (the capture refers to the device index vectors: hold them, the content-keyed cache may drop its entries)
-        keep = (self._device_indices(g['comm'], train_indices, y_train), self._device_indices(g['comm'], dev_indices, y_dev))
+        keep = (self._device_indices(g['comm'], train_indices, y_train, g.get('ro')),
+                self._device_indices(g['comm'], dev_indices, y_dev, g.get('ro')))
         hg.update(graph=graph, P=P, n_tr=n_tr, n_dv=n_dv, dropouts=drops, keep=keep)
         graph.replay()          # capture records, it does not run: this replay IS the step just counted
         return P, n_tr, n_dv
 
-    def _lazy_output(self, P, comm):
+    def _lazy_output(self, P, comm, ro=None):
         N = comm.part.N
         if self._dist(comm):
             la = LazyArray(lambda: P.numpy(), (N, P.F), sharded=True)
-            la._P, la._comm = P, comm
+            la._P, la._comm, la._ro = P, comm, ro
             return la
+        fetch = (lambda: P.numpy()) if ro is None else (lambda: ro.restore_rows(P.numpy()))
         if self._hg is not None and self._hg.get('graph') is not None and P is self._hg.get('P'):
             serial = self._step_serial
-            return LazyArray(lambda: P.numpy(), (N, P.F), still_valid=lambda: self._step_serial == serial)
-        return LazyArray(lambda: P.numpy(), (N, P.F))
+            return LazyArray(fetch, (N, P.F), still_valid=lambda: self._step_serial == serial)
+        return LazyArray(fetch, (N, P.F))
 
     def gather_output(self, out):
         """The full N x C matrix behind an f_train output.  COLLECTIVE when the graph is row-partitioned: every rank
@@ -692,7 +716,8 @@ class GraphConv():
             return np.asarray(out)
         if not out.sharded:
             return out.get()
-        return self._gather_rows(out._P, out._comm)
+        full = self._gather_rows(out._P, out._comm)
+        return full if out._ro is None else out._ro.restore_rows(full)
 
     def _gather_rows(self, M, comm):
         """Row-partitioned DMat -> full numpy matrix on every rank (collective)."""
@@ -711,10 +736,11 @@ class GraphConv():
         P = L.get_output(self.l_out, {self.l_in: g['X']}, tape=tape, **kw)
         amax = tape[self.l_out]['argmax']
         idx = np.asarray(test_indices)
+        ro = g.get('ro')
         if self._dist(comm):
-            rows = self._gather_rows(P, comm)[idx]
+            rows = self._gather_rows(P, comm)[idx if ro is None else ro.indices(idx)]
             return rows.argmax(-1).astype(np.int64), rows
-        t_idx, _, _ = self._device_indices(comm, idx)
+        t_idx, _, _ = self._device_indices(comm, idx, None, ro)
         rows = K.gather_rows(P, t_idx).cpu().numpy()
         pred = amax[t_idx.long()].cpu().numpy().astype(np.int64)
         return pred, rows
@@ -726,9 +752,8 @@ class GraphConv():
             kw = dict(A=g['A'], deterministic=True, comm=self._layer_comm(comm),
                       gemm_precision=self.gemm_precision)
             T = L.get_output(layer, {self.l_in: g['X']}, **kw)
-            if self._dist(comm):
-                return self._gather_rows(T, comm)          # collective: get_gates is called on every rank
-            return T.numpy()
+            full = self._gather_rows(T, comm) if self._dist(comm) else T.numpy()      # (partitioned: a collective)
+            return full if g.get('ro') is None else g['ro'].restore_rows(full)
         return f_gate
 
     # -- training loop (reference gcnmodel.py:418-450) -------------------------------------------

@@ -41,6 +41,41 @@ def powerlaw_ahat(N: int, E_target: int, alpha: float = 0.8, seed: int = 0) -> s
     return normalize_adjacency(A)
 
 
+def community_edges(N: int, E_target: int, n_comm: int, p_in: float = 0.9, alpha: float = 0.8, seed: int = 0):
+    """Edge list of a graph with the pinned generator's size and degree skew AND community structure: nodes belong to
+    `n_comm` equal communities (membership shuffled over the node ids, so the given numbering has no locality at all);
+    each of the m draws picks its first endpoint with the power-law weights of `powerlaw_ahat` and its second endpoint
+    inside the first one's community with probability p_in, anywhere otherwise.  -> (edges (m x 2) int64, community id
+    per node).  Used to show what the graph product does when the gather CAN be made local (geographconv_amd.graph)."""
+    rng = np.random.RandomState(seed)
+    w = np.arange(1, N + 1, dtype=np.float64) ** -alpha
+    rng.shuffle(w)
+    p = w / w.sum()
+    comm = rng.permutation(N) % n_comm                       # community of node i
+    order = np.argsort(comm, kind='stable')                  # members of community k: order[start[k]:start[k+1]]
+    start = np.concatenate([[0], np.cumsum(np.bincount(comm, minlength=n_comm))])
+    # duplicates inside a community collapse when the adjacency is binarised: oversample so that the stored count lands
+    # near E_target (factor fitted once for the pinned call below)
+    m = int((E_target - N) // 2 * 1.30)
+    r = rng.choice(N, size=m, p=p)
+    inside = rng.rand(m) < p_in
+    k = comm[r]
+    c_in = order[start[k] + (rng.rand(m) * (start[k + 1] - start[k])).astype(np.int64)]
+    c = np.where(inside, c_in, rng.randint(0, N, size=m))
+    keep = r != c
+    return np.stack([r[keep], c[keep]], axis=1), comm
+
+
+def community_ahat(N: int, E_target: int, n_comm: int, p_in: float = 0.9, alpha: float = 0.8, seed: int = 0) -> sps.csr_matrix:
+    """Normalised adjacency (gcnmain.py:115-128) of `community_edges`."""
+    edges, _ = community_edges(N, E_target, n_comm, p_in, alpha, seed)
+    r, c = edges[:, 0], edges[:, 1]
+    A = sps.coo_matrix((np.ones(2 * len(r), dtype=np.int64), (np.r_[r, c], np.r_[c, r])), shape=(N, N)).tocsr()
+    A.data[:] = 1
+    A = (A + sps.identity(N, dtype=np.int64, format='csr')).tocsr()
+    return normalize_adjacency(A)
+
+
 def normalize_adjacency(A: sps.spmatrix, dtype=np.float32) -> sps.csr_matrix:
     """D^-1/2 A D^-1/2 in float64, then cast (reference gcnmain.py:121-128).
 
@@ -128,10 +163,18 @@ def check_pinned(shape: str, which: str, M: sps.csr_matrix) -> bool:
     return fingerprint(M) == PINNED[(shape, which)]
 
 
+# TwitterUS size with community structure: 220 communities of 2,000 nodes, 90 % of the draws inside the community
+TWUS_SBM_COMMUNITIES = 220
+
+
 def make_graph(shape: str):
-    """(A_hat, X, Y, (train_idx, dev_idx, test_idx), C) for 'cmu' or 'twus'."""
-    s = SHAPES[shape]
-    A = powerlaw_ahat(s.N, s.E_target)
+    """(A_hat, X, Y, (train_idx, dev_idx, test_idx), C) for 'cmu', 'twus' or 'twus_sbm' (TwitterUS size and skew with
+    community structure; same X, Y and split as 'twus')."""
+    s = SHAPES['twus' if shape == 'twus_sbm' else shape]
+    if shape == 'twus_sbm':
+        A = community_ahat(s.N, s.E_target, TWUS_SBM_COMMUNITIES)
+    else:
+        A = powerlaw_ahat(s.N, s.E_target)
     X = bow_x(s.N, s.V, s.mean_nnz)
     Y = labels(s.N, s.C)
     return A, X, Y, split_indices(s.N), s.C
