@@ -199,6 +199,10 @@ __device__ __forceinline__ float4 highway_mix(const float4 t, const float4 hc, c
                        t.z * hc.z + (1.0f - t.z) * h.z, t.w * hc.w + (1.0f - t.w) * h.w);
 }
 
+struct XcdRows {
+    int lo[kNumXCD + 1];
+};
+
 // ONE launch covers every stored edge: the leading `n_chunk_blocks` blocks take the 128-nonzero chunks
 // of the long rows (raw partial sums into the workspace P), the remaining blocks take one CSR row per
 // 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
@@ -209,7 +213,8 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
-    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split, const HwArgs hw, const int per_xcd) {
+    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split, const HwArgs hw, const int per_xcd,
+    const XcdRows xr) {
     const int lane16 = threadIdx.x % G;
     const int nF4 = (F + 3) >> 2;
     float4 acc[K4];
@@ -234,11 +239,18 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     // blocks [x * per_xcd, (x + 1) * per_xcd) and walks it in launch order.  When the node numbering has locality
     // (geographconv_amd.graph: community reordering) the rows an XCD works on at any moment share their neighbours, and
     // the gathered rows of B stay in that XCD's 4 MB L2; with the plain b -> row block map the eight L2s would each
-    // see every community in flight.  per_xcd = 0: plain map.
+    // see every community in flight.  The ranges hold equal numbers of stored entries, not of rows (a hub-first
+    // numbering would otherwise give one XCD all the work).  per_xcd = 0: plain map.
     int rb = blockIdx.x - n_chunk_blocks;
-    if (per_xcd > 0) rb = (rb % kNumXCD) * per_xcd + rb / kNumXCD;
+    int row_end = n_rows;
+    if (per_xcd > 0) {
+        // XCD x owns rows [xr.lo[x], xr.lo[x + 1]) (multiples of 32: balanced by stored entries on the host)
+        const int x = rb % kNumXCD;
+        rb = xr.lo[x] / (kBlock / G) + rb / kNumXCD;
+        row_end = xr.lo[x + 1];
+    }
     const int row = rb * (kBlock / G) + (threadIdx.x / G);
-    if (row >= n_rows) return;
+    if (row >= row_end) return;
     const int s = rowptr[row];
     const int e = rowptr[row + 1];
     if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks
@@ -356,6 +368,7 @@ struct geogcn_spmm_plan {
     int* d_chunk_end = nullptr;    // [n_chunks]
     int* d_rowsplit = nullptr;     // [n_rows]   cache hint (nullable)
     int* d_chunk_split = nullptr;  // [n_chunks] rowsplit clamped into each chunk
+    int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per-XCD row ranges (multiples of 32), equal stored entries
 };
 
 struct geogcn_timer {
@@ -385,7 +398,15 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     const int n_chunk_blocks = (int)(cdiv(cdiv(n_chunks, kGroupsPerBlock), kNumXCD) * kNumXCD);
     const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
     const int n_row_blocks = (int)cdiv(n_rows, kGroupsPerBlock);
-    const int per_xcd = xcd_rows ? (int)cdiv(n_row_blocks, kNumXCD) : 0;
+    XcdRows xr;
+    int per_xcd = 0;
+    if (xcd_rows && plan) {
+        for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = plan->xcd_lo[x];
+        for (int x = 0; x < kNumXCD; ++x) per_xcd = std::max(per_xcd, (int)cdiv(xr.lo[x + 1] - xr.lo[x], kGroupsPerBlock));
+    } else if (xcd_rows) {
+        per_xcd = (int)cdiv(cdiv(n_row_blocks, kNumXCD) * kGroupsPerBlock, 32) * 32 / kGroupsPerBlock;
+        for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = (int)std::min<int64_t>(n_rows, (int64_t)x * per_xcd * kGroupsPerBlock);
+    }
     const dim3 grid((unsigned)(n_chunk_blocks + (per_xcd ? per_xcd * kNumXCD : n_row_blocks)));
     geogcn_timer* tm = g_spmm_timer;
     const bool timed = tm && (g_spmm_timer_F == 0 || g_spmm_timer_F == F) &&
@@ -408,7 +429,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF, HW_>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
-                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw, per_xcd)
+                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw, per_xcd, xr)
     if (n_rows > 0) {
         if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 0, 1); }        // highway epilogue: tanh branch only (checked by the caller)
         else if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }
@@ -635,6 +656,28 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const in
     }
     long_first.push_back((int)cs.size());
     auto* plan = new geogcn_spmm_plan();
+    {
+        // row ranges of the 8 XCDs: cut where the running count of (short-row) stored entries + a per-row term crosses
+        // k/8 of the total, rounded to 32 rows (= whole row blocks for 8- and 16-lane groups)
+        auto cost = [&](int r) -> int64_t {
+            const int64_t nz = rowptr_host[r + 1] - rowptr_host[r];
+            return (nz > long_row_nnz ? 0 : nz) + 4;
+        };
+        int64_t total = 0;
+        for (int r = 0; r < n_rows; ++r) total += cost(r);
+        int64_t run = 0;
+        int x = 1;
+        for (int r = 0; r < n_rows && x < 8; ++r) {
+            run += cost(r);
+            while (x < 8 && run * 8 >= total * x) {
+                plan->xcd_lo[x] = std::min(n_rows, (r + 1 + 31) / 32 * 32);
+                ++x;
+            }
+        }
+        for (; x < 8; ++x) plan->xcd_lo[x] = n_rows;
+        plan->xcd_lo[8] = n_rows;
+        for (int k = 1; k <= 8; ++k) plan->xcd_lo[k] = std::max(plan->xcd_lo[k], plan->xcd_lo[k - 1]);
+    }
     plan->n_rows = n_rows;
     plan->long_row_nnz = long_row_nnz;
     plan->chunk_nnz = chunk_nnz;

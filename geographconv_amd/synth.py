@@ -152,6 +152,8 @@ PINNED = {
     ('cmu', 'X'): (685_615, 0x6c70f752, 0x6611042e),
     ('twus', 'A'): (10_730_596, 0x38c7a66c, 0x8601fd3c),
     ('twus', 'X'): (21_458_408, 0xdf8585c4, 0x3542a305),
+    # community_ahat(440000, 10_000_000, 220): degree mean 25.84 / median 20 / p99 131 / max 11,833 / min 3 (numpy 2.2.6)
+    ('twus_sbm', 'A'): (11_368_850, 0x219cf29c, 0x27282978),
 }
 
 

@@ -1,5 +1,6 @@
 """Pinned generators reproduce SURVEY.md §8d (CRC32 of the index arrays)."""
 import numpy as np
+import pytest
 
 from geographconv_amd import synth
 
@@ -41,3 +42,25 @@ def test_normalize_zero_degree_row():
     A = sps.csr_matrix(np.array([[1, 1, 0], [1, 1, 0], [0, 0, 0]], dtype=np.float64))
     Ah = synth.normalize_adjacency(A).toarray()
     assert np.all(np.isfinite(Ah)) and np.all(Ah[2] == 0)     # inf -> 0 (gcnmain.py:125)
+
+
+def test_community_generator_small_is_stable_and_structured():
+    """The community-structured generator (tools/spmm_locality.py, bench.py --shape twus_sbm): deterministic, exactly
+    symmetric, 90 % of the stored off-diagonal entries inside the planted communities, node ids carry no locality."""
+    edges, comm = synth.community_edges(5000, 70000, n_comm=10, p_in=0.9, seed=1)
+    edges2, _ = synth.community_edges(5000, 70000, n_comm=10, p_in=0.9, seed=1)
+    assert np.array_equal(edges, edges2)
+    A = synth.community_ahat(5000, 70000, 10, seed=1)
+    assert abs(A - A.T).max() == 0.0 and A.dtype == np.float32
+    row_of = np.repeat(np.arange(5000), np.diff(A.indptr))
+    off = row_of != A.indices
+    inside = comm[row_of[off]] == comm[A.indices[off]]
+    assert 0.85 < inside.mean() < 0.95
+    assert np.bincount(comm).min() == np.bincount(comm).max() == 500
+
+
+@pytest.mark.timeout(120)
+def test_twus_sbm_pinned():
+    A = synth.make_graph('twus_sbm')[0]
+    assert synth.fingerprint(A) == synth.PINNED[('twus_sbm', 'A')]
+    assert abs(A.data.astype(np.float64).sum() - 373162.166052) < 1e-4

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--cases', default='pinned,pinned+degree,pinned+lpa,sbm,sbm+degree,sbm+rcm,sbm+bfs,sbm+lpa')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--F', type=int, default=300)
+    ap.add_argument('--communities', type=int, default=synth.TWUS_SBM_COMMUNITIES)
     ap.add_argument('--out', default='gpurun_out/spmm_locality.json')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -32,7 +33,7 @@ def main():
         name, _, method = case.partition('+')
         if name not in base:
             t0 = time.time()
-            base[name] = synth.powerlaw_ahat(s.N, s.E_target) if name == 'pinned' else synth.community_ahat(s.N, s.E_target, synth.TWUS_SBM_COMMUNITIES)
+            base[name] = synth.powerlaw_ahat(s.N, s.E_target) if name == 'pinned' else synth.community_ahat(s.N, s.E_target, args.communities)
             print('[%s generated in %.1f s: nnz %d]' % (name, time.time() - t0, base[name].nnz), flush=True)
         A = base[name]
         t0 = time.time()
