@@ -7,17 +7,25 @@
 A "step" is one full-graph ``GraphConv.f_train``: forward + backward + Adam of the 3x300 highway
 GCN (BASELINE.json configs[2]: synthetic TwitterUS-shape CSR, N=440,000, nnz(A_hat)=10,730,596,
 V=10,000, C=256, fp32, dropout 0.5) with (A_hat, X, Y) already resident in HBM.  Every step runs
-3 graph-convolution layers forward and backward over all stored edges, so
+3 graph-convolution layers forward and backward over the stored edges, so
 
     value = n_conv_layers * nnz(A_hat) * K / t_K        [GCN-layer fwd+bwd edges/s, whole job]
+
+(nominal: the output layer's backward product only walks the edges into the training nodes, because the
+cross-entropy gradient is zero elsewhere; `config.edges_traversed_per_step` has the exact count.)
 
 With --gpus N the SAME graph is row-partitioned over N ranks (strong scaling; per conv layer and
 direction the SpMM operand is exchanged over RCCL: in-place all-gather at 2 ranks, a feature
 repartition with two all-to-alls from 3 ranks -- DESIGN.md section 5).  The JSON line also carries
-  roofline     : the dominant kernel (spmm_rows_kernel, A_hat.Z at F=300), algorithmic bytes / its
-                 average launch duration measured live with hipEvents on the launch stream;
-  cpu_baseline : the NumPy/SciPy oracle (oracle/gcn_oracle.py, kind "port") timed on this box's
-                 host cores on a bounded sample (rank 0, N=1 only).
+  roofline       : the dominant kernel (spmm_rows_kernel, A_hat^T . dS at F=300: the two plain full-graph products of
+                   a step), algorithmic bytes / average duration measured live with library-side hipEvent pairs on the
+                   launch stream around every such product inside the timed region; `traffic` comes from a separate
+                   rocprofv3 --pmc pass (profiles/, `traffic_source` says which); `others` = the other hot kernels timed
+                   live in isolation on the same operands right after the timed region;
+  step_ms        : median / p10 / p90 of the per-step times (events per step, same region);
+  cpu_baseline   : the NumPy/SciPy oracle (oracle/gcn_oracle.py, kind "port": SpMM single-threaded like Theano's
+                   StructuredDot, BLAS sgemm on all threads) timed on this box's host cores (rank 0, N=1 only);
+  cpu_baseline_mt: the same step with the sparse products on all cores (oracle/cpu_mt.c, OpenMP).
 """
 from __future__ import annotations
 
@@ -33,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.md)
 
 
 def log(*a):
@@ -45,50 +54,138 @@ def spmm_algorithmic_bytes(n_rows_out, n_cols, nnz, F, b_bytes=4):
     return 8 * nnz + 4 * (n_rows_out + 1) + b_bytes * n_cols * F + 4 * n_rows_out * F
 
 
-def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample):
-    """Oracle timed on the host: one f_train step ('step') or one conv layer fwd+bwd ('layer')."""
-    from oracle import gcn_oracle as O
-    nnz = A.nnz
-    threads = os.cpu_count() or 1
-    model = ''
+def _cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
             if line.startswith('model name'):
-                model = line.split(':', 1)[1].strip()
-                break
+                return line.split(':', 1)[1].strip()
     except OSError:
         pass
+    return ''
+
+
+def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample, multithreaded=False):
+    """Oracle timed on the host: one f_train step ('step') or one conv layer fwd+bwd ('layer')."""
+    from oracle import gcn_oracle as O
+    import contextlib
+    nnz = A.nnz
+    threads = os.cpu_count() or 1
+    ctx = contextlib.nullcontext()
+    spmm_note = "scipy CSR SpMM is single-threaded like Theano's StructuredDot"
+    if multithreaded:
+        import scipy.sparse as sps
+        from oracle import cpu_mt
+        cpu_mt.build()
+        At = A if abs(A - A.T).max() == 0 else sps.csr_matrix(A.T)
+        ctx = cpu_mt.patched(O, {id(A): At, id(X): sps.csr_matrix(X.T)})           # transposes prepared once, untimed
+        spmm_note = "sparse products on %d OpenMP threads (oracle/cpu_mt.c)" % cpu_mt.threads()
     if sample == 'layer':
         rng = np.random.RandomState(1)
         H = rng.randn(A.shape[0], 300).astype(np.float32)
         G = rng.randn(A.shape[0], 300).astype(np.float32)
         W = (rng.randn(300, 300) * 0.05).astype(np.float32)
         b = np.zeros(300, np.float32)
-        t0 = time.time()
-        O.conv_layer_fwd_bwd(H, W, b, A, G)
-        t = time.time() - t0
-        return {"value": nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": model, "kind": "port", "seconds": round(t, 2),
-                "sample": "1 ConvolutionDenseLayer2 fwd+bwd (300->300) on the full %s graph; scipy CSR SpMM is "
-                          "single-threaded like Theano's StructuredDot, BLAS sgemm uses %d threads" % (shape, threads)}
+        with ctx:
+            t0 = time.time()
+            O.conv_layer_fwd_bwd(H, W, b, A, G)
+            t = time.time() - t0
+        return {"value": nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": _cpu_model(), "kind": "port", "seconds": round(t, 2),
+                "sample": "1 ConvolutionDenseLayer2 fwd+bwd (300->300) on the full %s graph; %s, BLAS sgemm uses %d "
+                          "threads" % (shape, spmm_note, threads)}
     params = O.random_params(X.shape[1], hid, C, True, seed=7)
     mask = (np.random.RandomState(3).rand(X.shape[0], hid[0]) < 0.5).astype(np.float32)
     st = O.AdamState(params)
-    t0 = time.time()
-    O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.5, mask)
-    t = time.time() - t0
+    with ctx:
+        t0 = time.time()
+        O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.5, mask)
+        t = time.time() - t0
     n_conv = len(hid)
-    return {"value": n_conv * nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": model, "kind": "port", "seconds": round(t, 2),
+    return {"value": n_conv * nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": _cpu_model(), "kind": "port", "seconds": round(t, 2),
             "sample": "1 full f_train step (same workload, same unit: %d conv layers x nnz / step time) on the full %s "
-                      "graph; scipy CSR SpMM is single-threaded like Theano's StructuredDot, BLAS sgemm uses %d "
-                      "threads" % (n_conv, shape, threads)}
+                      "graph; %s, BLAS sgemm uses %d threads" % (n_conv, shape, spmm_note, threads)}
+
+
+def time_isolated(fn, reps=10, warmup=2):
+    import torch
+    for _ in range(warmup):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def other_kernels(clf, g, hid, N, C, precision):
+    """Live, isolated timings of the other hot kernels on the model's own operands (median of 10 launches each):
+    HBM-bound ones priced with their algorithmic bytes, the GEMMs with their flops against the fp32 MFMA peak."""
+    import torch
+    from geographconv_amd import ops
+    dev = clf.device
+    F = hid[0]
+    out = []
+
+    def hbm(name, ms, alg, note=''):
+        out.append({"kernel": name, "bound": "hbm", "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS, "note": note})
+
+    def mfma(name, ms, flops, note=''):
+        out.append({"kernel": name, "bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "note": note})
+    X, A = g['X'], g['A']
+    W0 = clf.store.params[0].data
+    b0 = clf.store.params[1].data
+    S0 = ops.DMat(N, F, dev)
+    nnzX, V = X.fwd.nnz, X.shape[1]
+    hbm("X . W0 + b0, tanh  (spmm_hot_kernel: hot rows of W0 in LDS)", time_isolated(lambda: ops.spmm_x(X, W0, out=S0, bias=b0, act=ops.ACT_TANH)),
+        8 * nnzX + 4 * (N + 1) + 4 * V * F + 4 * N * F)
+    G = ops.DMat.empty(N, F, dev, ld=ops.gather_ld(F))
+    G.t.normal_()
+    dW0 = ops.DMat(V, F, dev)
+    hbm("X^T . dS0  (head panel GEMM + xt_tail_kernel + combine)", time_isolated(lambda: ops.spmm_t(X, G, out=dW0)),
+        8 * nnzX + 4 * N * F + 4 * V * F)
+    if len(hid) > 1 and F == hid[1]:
+        T = ops.DMat(N, F, dev)
+        T.t.uniform_()
+        H = ops.DMat(N, F, dev)
+        H.t.normal_()
+        bh = torch.zeros(ops.pad4(F), device=dev)
+        nnz = A.fwd.nnz
+        hbm("tanh(A_hat . Z + bh) with the highway mix in the epilogue  (spmm_rows_kernel<.., HW>)",
+            time_isolated(lambda: ops.spmm_highway(A.fwd, G, bh, T, H)), spmm_algorithmic_bytes(N, N, nnz, F) + 3 * 4 * N * F,
+            "algorithmic bytes = the plain product's + T, H read and Hout written")
+        if precision == 'f32':
+            Wh = ops.DMat(F, F, dev)
+            Wt = ops.DMat(F, F, dev)
+            Wh.t.normal_(0, 0.05)
+            Wt.t.normal_(0, 0.05)
+            bt = torch.full((ops.pad4(F),), -4.0, device=dev)
+            Z = ops.DMat.empty(N, F, dev, ld=ops.gather_ld(F))
+            T2 = ops.DMat(N, F, dev)
+            fl = 2.0 * N * F * F
+            mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_kernel NN, dual)",
+                 time_isolated(lambda: ops.gemm_dual(H, Wh, Wt, out0=Z, out1=T2, bias1=bt, act1=ops.ACT_SIGMOID)), 2 * fl)
+            dWh, dWt = ops.DMat(F, F, dev), ops.DMat(F, F, dev)
+            mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)",
+                 time_isolated(lambda: ops.gemm_dual(H, G, T, out0=dWh, out1=dWt, transA=True)), 2 * fl)
+            dH = ops.DMat(N, F, dev)
+            dH.t.zero_()
+            mfma("dH += dZ . Wh^T + dU . Wt^T  (gemm_kernel NT, K-concatenated)",
+                 time_isolated(lambda: ops.gemm_kcat(G, Wh, T, Wt, out=dH, transB=True, accumulate=True)), 2 * fl)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--shape', default='twus', choices=['twus', 'cmu'])
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--shape', default='twus', choices=['twus', 'cmu', 'twus_sbm'])
+    ap.add_argument('--reorder', default=None, choices=['degree', 'rcm', 'bfs', 'lpa'],
+                    help='node renumbering applied on the device side (outputs stay in original ids)')
     ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
     ap.add_argument('--dropout', type=float, default=0.5)
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
@@ -131,7 +228,7 @@ def main():
         comm = TorchDistComm(N, device)
 
     clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm,
-                    gemm_precision=args.gemm_precision)
+                    gemm_precision=args.gemm_precision, reorder=args.reorder)
     clf.build_model(A, seed=77)
     clf._force_dist = force_dist
     y_tr, y_dev = Y[tr], Y[dev]
@@ -146,22 +243,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # roofline leg: library-side hipEvent pairs around the F=hid SpMM row kernel, on the launch stream
+    # roofline leg: library-side hipEvent pairs around the F=hid SpMM products, on the launch stream
     timer = ops.SpmmTimer(capacity=max(16, 8 * args.steps))
     # the dense operand of the timed SpMM: F = hid at one GPU; one feature panel per rank under the a2a scheme
     F_spmm = args.hid[-1]
+    bf16_operand = args.gemm_precision == 'bf16'
     if comm is not None and comm.exchange == 'a2a':
-        F_spmm = comm.panel_width(args.hid[-1])
-    timer.attach(only_F=F_spmm, only_nnz=clf._device_graph(X, A)['A'].fwd.nnz)
+        F_spmm = comm.panel_width(args.hid[-1], bf16_operand)
+    g0 = clf._device_graph(X, A)
+    timer.attach(only_F=F_spmm, only_nnz=g0['A'].fwd.nnz)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         last = step()
+        marks[i + 1].record()
     barrier()
     t = time.perf_counter() - t0
     timer.detach()
     kern_ms = timer.read_ms()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     if world > 1:
         tt = torch.tensor([t], dtype=torch.float64, device=device)
@@ -171,39 +274,60 @@ def main():
     value = n_conv * nnz * args.steps / t
 
     if rank == 0:
-        g = clf._device_graph(X, A)
+        g = g0
         csr = g['A'].fwd
         rp = csr.rowptr_host
         deg = np.diff(rp)
         F = F_spmm
-        # one launch of spmm_rows_kernel covers every stored edge of the local row block (short rows with
-        # the fused epilogue + the 128-nonzero chunks of the long rows): algorithmic bytes = SURVEY.md §8d
-        bf16_operand = args.gemm_precision == 'bf16' and world == 1       # (the partitioned path exchanges fp32)
+        # one product = spmm_rows_kernel over every stored edge of the local row block (short rows with the fused epilogue
+        # + the 128-nonzero chunks of the long rows) + the long rows' ordered combine: algorithmic bytes = SURVEY.md §8d
         alg = spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F, 2 if bf16_operand else 4)
-        e_short = int(csr.nnz)
         avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = alg / (avg_ms * 1e-3) / 1e9 if kern_ms else None
-        traffic = None            # PMC passes are collected at 1 GPU, F = hid (profiles/pmc_spmm_latest.json)
+        traffic, traffic_source = None, None
         pmc_file = os.path.join(ROOT, 'profiles', 'pmc_spmm_bf16_latest.json' if bf16_operand else 'pmc_spmm_latest.json')
-        if os.path.exists(pmc_file) and world == 1 and F == 300 and args.shape == 'twus':
+        if os.path.exists(pmc_file) and world == 1 and F == 300 and args.shape == 'twus' and args.reorder is None:
             try:
-                traffic = json.load(open(pmc_file)).get('hbm_bytes_per_launch')
+                pm = json.load(open(pmc_file))
+                traffic = pm.get('hbm_bytes_per_launch')
+                traffic_source = ("NOT measured in this run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of this command "
+                                  "at state %s, %s; 2 x FETCH_SIZE + WRITE_SIZE per launch; the counter tallies L2 -> fabric requests, "
+                                  "Infinity-Cache hits included" % (pm.get('state', 'r01_h'), os.path.relpath(pmc_file, ROOT)))
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> (A_hat.Z, F=%d%s)" % (
+        roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> + spmm_long_reduce_kernel (A_hat^T . dS, F=%d%s)" % (
                         (F + 63) // 64, F, "" if world == 1 else ", rank 0's feature panel of all rows"),
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                    "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": len(kern_ms),
-                    "edges_per_launch": e_short, "bytes_per_edge": alg / max(1, e_short)}
+                    "launches_sampled": "every plain (not highway-fused) graph product with F = %d over all %d stored edges inside "
+                                        "the timed region (the backward products of the hidden layers), hipEvent pairs recorded by "
+                                        "the library on the launch stream around row kernel + long-row combine" % (F, int(csr.nnz)),
+                    "edges_per_launch": int(csr.nnz), "bytes_per_edge": alg / max(1, int(csr.nnz))}
+        if world == 1 and args.shape != 'cmu':
+            try:
+                roofline["others"] = other_kernels(clf, g, args.hid, N, C, args.gemm_precision)
+            except Exception as e:                       # evidence only: never fail the headline line over it
+                roofline["others_error"] = repr(e)
+        nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
         out = {
             "metric": "GCN-layer fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3,
+            "step_ms": {"median": step_ms[len(step_ms) // 2], "p10": step_ms[int(0.1 * (len(step_ms) - 1))],
+                        "p90": step_ms[int(round(0.9 * (len(step_ms) - 1)))], "min": step_ms[0], "max": step_ms[-1],
+                        "how": "torch.cuda.Event after every step of the timed region (device time between consecutive steps)"},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.gemm_precision != "bf16" else "bf16", "data": "synthetic",
-            "config": {"workload": "TwitterUS-shape synthetic power-law CSR (BASELINE configs[2]): N=%d, nnz(A_hat)=%d, "
+            "config": {"workload": "%s synthetic CSR (BASELINE configs[2]%s): N=%d, nnz(A_hat)=%d, "
                                    "X %dx%d nnz=%d, C=%d; %s highway GCN, dropout %.2f, Adam; full-graph f_train step"
-                                   % (N, nnz, N, X.shape[1], X.nnz, C, 'x'.join(map(str, args.hid)), args.dropout),
-                       "edges_per_step": n_conv * nnz, "parallelism": "rows%d" % world if world > 1 else "single",
+                                   % ({'twus': 'TwitterUS-shape power-law', 'cmu': 'CMU-shape power-law',
+                                       'twus_sbm': 'TwitterUS-size community-structured'}[args.shape],
+                                      '' if args.shape == 'twus' else ' shape variant', N, nnz, N, X.shape[1], X.nnz, C,
+                                      'x'.join(map(str, args.hid)), args.dropout),
+                       "edges_per_step": n_conv * nnz,
+                       "edges_traversed_per_step": 2 * (n_conv - 1) * nnz + nnz + nnz_bwd_out,
+                       "parallelism": "rows%d" % world if world > 1 else "single",
+                       "world_size": world, "collectives": None if comm is None else "RCCL (torch.distributed nccl), exchange = %s" % comm.exchange,
+                       "reorder": args.reorder,
                        "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
                                 "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
                        "train_loss_last": float(last[0])},
@@ -212,6 +336,11 @@ def main():
         if world == 1 and args.cpu_sample != 'none':
             log('[bench] timing the CPU oracle (%s sample)...' % args.cpu_sample)
             out["cpu_baseline"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample)
+            log('[bench] ... and with the sparse products on all cores')
+            try:
+                out["cpu_baseline_mt"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample, multithreaded=True)
+            except Exception as e:
+                out["cpu_baseline_mt"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         # RCCL prints a version banner through C stdio; flush it so that the JSON line is the LAST line of stdout

@@ -152,3 +152,23 @@ def test_f_train_dev_metrics_use_dropout_pass():
     assert outs[4].shape == (X.shape[0], 5)
     pred, probs = O.f_val(newp, X, A, dev, [8, 8, 8], True)
     assert pred.dtype == np.int64 and probs.shape == (len(dev), 5)
+
+
+def test_multithreaded_cpu_leg_equals_the_oracle_products():
+    """oracle/cpu_mt.c (bench.py's `cpu_baseline_mt`): OpenMP over the rows, same per-row order as the single-threaded
+    loop -- equal to scipy's product up to fma contraction; patched() swaps it into the oracle for one timed step."""
+    import scipy.sparse as sps
+    from oracle import cpu_mt
+    cpu_mt.build()
+    assert cpu_mt.threads() >= 1
+    A = sps.random(3000, 2000, density=0.01, format='csr', dtype=np.float32, random_state=0)
+    B = np.random.RandomState(0).randn(2000, 129).astype(np.float32)
+    ref = O.spmm(A, B)
+    got = cpu_mt.spmm(A, B)
+    assert np.abs(got - ref).max() <= 4e-6 * np.asarray(abs(A) @ np.abs(B)).max()
+    G = np.random.RandomState(1).randn(3000, 7).astype(np.float32)
+    with cpu_mt.patched(O, {id(A): sps.csr_matrix(A.T)}):
+        r = O.spmm_t(A, G)
+        r64 = O.spmm_t(A, G.astype(np.float64))                 # fp64 calls (gradient checks) stay on scipy
+    assert np.abs(r - A.T @ G).max() <= 1e-5 and r64.dtype == np.float64
+    assert O.spmm_t(A, G).dtype == np.float32 and O.spmm.__name__ == 'spmm'      # restored
