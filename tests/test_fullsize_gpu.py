@@ -161,7 +161,20 @@ def test_forward_full_size_matches_oracle_argmax_exact(twus):
     top2 = np.partition(ref, -2, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 2 * (tol + 3e-5 * top2[:, 1])
     assert clear.mean() > 0.99
-    assert np.array_equal(pred[clear], ref.argmax(-1)[clear])
+    a32 = ref.argmax(-1)
+    assert np.array_equal(pred[clear], a32[clear])
+    # the rows INSIDE the tie band are arbitrated by the fp64 oracle (as the CMU test does): every label the HIP path
+    # emits is the fp32 oracle's or the fp64 oracle's, and against the fp64 arbiter the HIP path is no worse than the
+    # fp32 oracle itself
+    ref64 = O.forward(params, t['X'], t['A'], hid, True, dtype=np.float64)['P']
+    a64 = ref64.argmax(-1)
+    either = (pred == a32) | (pred == a64)
+    n_hip, n_cpu32 = int((pred != a64).sum()), int((a32 != a64).sum())
+    print("TWUS argmax: %d of %d rows inside the tie band; label mismatches vs the fp64 oracle: HIP %d, fp32 oracle %d; "
+          "HIP vs fp32 oracle %d" % (int((~clear).sum()), N, n_hip, n_cpu32, int((pred != a32).sum())))
+    assert either.all(), int((~either).sum())
+    assert n_hip <= n_cpu32 + 2
+    assert np.abs(probs - ref64).max() <= tol + 3e-5
 
 
 def test_train_step_full_size_matches_oracle(twus):
@@ -191,3 +204,39 @@ def test_train_step_full_size_matches_oracle(twus):
     for i, (q, r) in enumerate(zip(L.get_all_param_values(clf.l_out), new)):
         assert np.abs(q - r).max() <= 2e-3 * 0.05 + 1e-7, i        # Adam's normalised step (see test_e2e_gpu)
         assert np.mean(np.abs(q - r)) <= 2e-6
+
+
+def test_config5_shape_bf16_six_layers_600_hidden_full_size(twus):
+    """BASELINE configs[4]'s shape on one GPU: 6 x 600 highway GCN at the FULL TwitterUS size with bf16 H.W products
+    (fp32 accumulate) and the bf16 gathered operand, deterministic forward over all 440,000 nodes against the fp32
+    oracle (~1 min of CPU).  bf16 carries 8 mantissa bits per product operand, so the comparison is statistical:
+    probabilities within a bf16-class envelope on every row, label agreement rate, and a second run bitwise equal."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    from oracle import gcn_oracle as O
+    t = twus
+    hid = [600] * 6
+    params = O.random_params(t['X'].shape[1], hid, t['C'], True, seed=11)
+    clf = GraphConv(t['X'].shape[1], t['C'], hid, 0.0, 0.5, highway=True, gemm_precision='bf16')
+    clf.build_model(t['A'], seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    N = t['A'].shape[0]
+    idx = np.arange(N, dtype=np.int32)
+    pred, probs = clf.predict(t['X'], t['A'], idx)
+    ref = O.forward(params, t['X'], t['A'], hid, True, dtype=np.float32)['P']
+    assert np.all(np.isfinite(probs)) and np.allclose(probs.sum(1), 1.0, atol=1e-4)
+    err = np.abs(probs - ref)
+    # envelope: 6 layers of products with 2^-8 relative operand rounding; measured max ~3e-3 absolute on probabilities
+    # of ~4e-3 (near-uniform softmax at init), i.e. tens of per cent relative on single entries but tiny in KL
+    kl = (ref * (np.log(ref + 1e-30) - np.log(probs + 1e-30))).sum(1)
+    agree = float((pred == ref.argmax(-1)).mean())
+    print("config5 shape, bf16 vs fp32 oracle: max |dP| %.3g, mean |dP| %.3g, max KL %.3g, label agreement %.4f"
+          % (err.max(), err.mean(), kl.max(), agree))
+    assert err.max() <= 0.05 and err.mean() <= 2e-4 and kl.max() <= 5e-3
+    assert agree >= 0.90
+    # where the fp32 oracle's top-2 margin exceeds the bf16 noise, the labels must agree
+    top2 = np.partition(ref, -2, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 10 * err.mean() + 4 * err.std()
+    assert np.array_equal(pred[clear], ref.argmax(-1)[clear]) or (pred[clear] != ref.argmax(-1)[clear]).mean() < 1e-3
+    pred2, probs2 = clf.predict(t['X'], t['A'], idx)
+    assert np.array_equal(pred, pred2) and np.array_equal(probs, probs2)
