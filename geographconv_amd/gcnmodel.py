@@ -602,9 +602,11 @@ class GraphConv():
         else:
             P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, None)
         s = [float(v) for v in self._scal.cpu().numpy()]   # the one host sync of the step
-        l_tr = s[0] / max(1, n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
-        out = [np.float32(l_tr), np.float64(s[1] / max(1, n_tr)), np.float32(s[2] / max(1, n_dv)),
-               np.float64(s[3] / max(1, n_dv)), self._lazy_output(P, comm, g.get('ro'))]
+        # (a mean over an EMPTY index set is NaN, as the reference's T.mean / numpy give it -- gcnmodel.py:380-382,389)
+        mean = lambda total, n: total / n if n else float('nan')
+        l_tr = mean(s[0], n_tr) + (s[4] if self.regul_coef > 0 else 0.0)
+        out = [np.float32(l_tr), np.float64(mean(s[1], n_tr)), np.float32(mean(s[2], n_dv)),
+               np.float64(mean(s[3], n_dv)), self._lazy_output(P, comm, g.get('ro'))]
         return out
 
     def _train_step(self, g, y_train, y_dev, A, train_indices, dev_indices, counters):
