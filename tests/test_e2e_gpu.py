@@ -101,6 +101,35 @@ def test_fused_highway_gemms_match_the_separate_launches(cmu, monkeypatch):
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max() + 1e-12, (i, np.abs(a - b).max(), np.abs(b).max())
 
 
+@pytest.mark.parametrize("method", ['rcm', 'lpa', 'degree'])
+def test_node_reordering_is_invisible_to_the_caller(cmu, method):
+    """GraphConv(reorder=...): the graph, X, the index vectors and the injected mask are renumbered on the way to the
+    device and every per-node output is restored -- the caller sees the same losses, hit counts, probabilities (in
+    ORIGINAL node order), labels and gradients as without reordering, up to the fp32 summation order inside a row."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    res = {}
+    for ro in (None, method):
+        clf = GraphConv(c['X'].shape[1], c['C'], c['hid'], 0.0, 0.5, highway=True, reorder=ro)
+        clf.build_model(c['A'], seed=77)
+        L.set_all_param_values(clf.l_out, c['params'])
+        clf.inject_dropout_mask(c['mask'])
+        out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+        grads = clf.get_grads()
+        L.set_all_param_values(clf.l_out, c['params'])
+        pred, probs = clf.predict(c['X'], c['A'], c['te'])
+        gates = clf.get_gates(c['X'], c['A'])
+        res[ro] = (out[:4], np.asarray(out[4]), grads, pred, probs, gates[0])
+    a, b = res[None], res[method]
+    assert abs(a[0][0] - b[0][0]) <= 2e-6 * abs(a[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3]
+    assert np.abs(a[1] - b[1]).max() <= PROB_ATOL
+    for i, (g, r) in enumerate(zip(b[2], a[2])):
+        assert np.abs(g - r).max() <= 2e-5 * np.abs(r).max() + 1e-10, i
+    assert np.array_equal(a[3], b[3]) and np.abs(a[4] - b[4]).max() <= PROB_ATOL
+    assert np.abs(a[5] - b[5]).max() <= 1e-5
+
+
 def test_cmu_plain_gcn_and_regularisation(cmu):
     c = cmu
     hid = [300, 200, 100]
