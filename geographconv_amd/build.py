@@ -20,6 +20,8 @@ LIB = os.path.join(HERE, 'libgeogcn.so')
 SOURCES = ['core.hip', 'spmm.hip', 'spmm_hot.hip', 'xt.hip', 'gemm.hip', 'gemm_bf16.hip', 'elementwise.hip', 'softmax_adam.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-Wall', '-Wno-unused-function']
+# ablation / experiment builds: GEOGCN_BUILD_DEFINES="GEOGCN_BF16_PROBE_BUILD ..." python -m geographconv_amd.build --force
+FLAGS += ['-D' + d for d in os.environ.get('GEOGCN_BUILD_DEFINES', '').split()]
 
 
 def _hipcc():

@@ -14,6 +14,8 @@
 // Same persistent, flattened-k-pipeline structure as gemm.hip (one LDS image, two blocks per CU).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace geogcn {
@@ -29,11 +31,15 @@ constexpr int ROWB = 80;                 // bytes per LDS row: 32 bf16 (64 B) + 
 __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
-// round-to-nearest-even fp32 -> bf16 (upper 16 bits); inputs are finite on this path
-__device__ __forceinline__ uint32_t bf16_rne(float x) {
-    const uint32_t u = f2u(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// round-to-nearest-even fp32 -> bf16: gfx950's v_cvt_pk_bf16_f32 converts two values per instruction (the integer
+// sequence (u + 0x7fff + lsb) >> 16 it replaces was five VALU instructions per value; same result for finite inputs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
+__device__ __forceinline__ uint32_t bf16_rne(float x) { return bf16_pack(x, 0.f) & 0xffffu; }
 
 // x -> NS bf16 terms; the residuals are exact in fp32 (Dekker-style splitting)
 template <int NS>
@@ -111,7 +117,9 @@ __device__ __forceinline__ float4 tn_load4(__amdgpu_buffer_rsrc_t r, uint32_t of
 }
 
 
-template <int BM, int BN, int NS, int ACT, int NT>
+// PROBE (ablation, GEOGCN_BF16_PROBE; 0 in normal use): 1 = no global loads in the loop, 2 = no LDS stores,
+// 4 = no fragment reads / MFMAs, 8 = no barrier
+template <int BM, int BN, int NS, int ACT, int NT, int PROBE = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
     using Cfg = BCfg<BM, BN, NS, NT>;
     constexpr int kRowsPerPass = NT / 8;
@@ -195,17 +203,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
         unsigned char* Bs = As + Cfg::kABytes;
 #pragma unroll
         for (int i = 0; i < Cfg::kAIters; ++i) {
-            const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            uint32_t t[4][NS];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16<NS>(xs[e], t[e]);
             const int row = a_rr + kRowsPerPass * i;
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl) {
+            if constexpr (NS == 1) {
                 uint2 w;
-                w.x = t[0][pl] | (t[1][pl] << 16);
-                w.y = t[2][pl] | (t[3][pl] << 16);
-                *reinterpret_cast<uint2*>(As + (pl * BM + row) * ROWB + a_f4 * 8) = w;
+                w.x = bf16_pack(ra[i].x, ra[i].y);
+                w.y = bf16_pack(ra[i].z, ra[i].w);
+                *reinterpret_cast<uint2*>(As + row * ROWB + a_f4 * 8) = w;
+            } else {
+                const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                uint32_t t[4][NS];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_bf16<NS>(xs[e], t[e]);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) {
+                    uint2 w;
+                    w.x = t[0][pl] | (t[1][pl] << 16);
+                    w.y = t[2][pl] | (t[3][pl] << 16);
+                    *reinterpret_cast<uint2*>(As + (pl * BM + row) * ROWB + a_f4 * 8) = w;
+                }
             }
         }
 #pragma unroll
@@ -237,16 +252,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
     int64_t cm0 = (int64_t)cm_t * BM, cn0 = (int64_t)cn_t * BN;
     // (xa) = free A set, receives stage s+2;  (ya) = A set holding stage s+1
     auto step = [&](float4 (&xa)[Cfg::kAIters], const float4 (&ya)[Cfg::kAIters]) {
-        gloadA(xa, lj, lkt);
+        if (!(PROBE & 1)) gloadA(xa, lj, lkt);
         adv(lj, lkt);
-        gloadB(pj, pkt);
+        if (!(PROBE & 1)) gloadB(pj, pkt);
         const unsigned char* As = smem_raw + (Cfg::kDouble ? cur : 0) * Cfg::kStageBytes;
         const unsigned char* Bs = As + Cfg::kABytes;
         // ---- MFMAs on the resident stage ----
         // fragments are re-read from LDS per (column tile, row tile) pair: 24 live fragment registers instead
         // of 60+ -- the register file is needed for the two-stage prefetch, LDS bandwidth is not the limit
 #pragma unroll
-        for (int j = 0; j < Cfg::NR; ++j) {
+        for (int j = 0; j < ((PROBE & 4) ? 0 : Cfg::NR); ++j) {
             bf16x8 bf[NS];
 #pragma unroll
             for (int pl = 0; pl < NS; ++pl)
@@ -313,8 +328,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
                         }
                         if (a.c_bf16) {
                             uint2 w;
-                            w.x = bf16_rne(x[0]) | (bf16_rne(x[1]) << 16);
-                            w.y = bf16_rne(x[2]) | (bf16_rne(x[3]) << 16);
+                            w.x = bf16_pack(x[0], x[1]);
+                            w.y = bf16_pack(x[2], x[3]);
                             *reinterpret_cast<uint2*>((unsigned short*)a.C + off) = w;
                         } else {
                             *reinterpret_cast<float4*>((float*)a.C + off) = make_float4(x[0], x[1], x[2], x[3]);
@@ -325,8 +340,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
             }
         }
         if constexpr (!Cfg::kDouble) __syncthreads();     // single image: everybody done reading first
-        sstore(cur ^ 1, ya);
-        __syncthreads();
+        if (!(PROBE & 2)) sstore(cur ^ 1, ya);
+        if (!(PROBE & 8)) __syncthreads();
         cur ^= 1;
         adv(pj, pkt);
         if (++ckt == nk) {
@@ -397,10 +412,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3, li = lane & 15, lg = lane >> 4;
 
+    // Block b runs on XCD b % 8.  All tiles of one K slab go to the SAME XCD and start together: they read the same rows
+    // of A and B, so one of them fetches a row from HBM and the others hit that XCD's L2 (with slab = b / tiles the ten
+    // tiles of a slab sat on eight different XCDs and every one fetched its own copy: 7.0 GB per launch for 2.1 GB of
+    // operands, profiles/r02_c_bf16_gemm.md).  Slabs beyond nsplit (grid rounded up to whole XCD rounds) do nothing.
     const int b = blockIdx.x;
-    const int nt = __builtin_amdgcn_readfirstlane(b % a.n_nt);
-    const int mt = __builtin_amdgcn_readfirstlane((b / a.n_nt) % a.n_mt);
-    const int z = __builtin_amdgcn_readfirstlane(b / (a.n_nt * a.n_mt));
+    const int xcd = b % kNumXCD, s = b / kNumXCD;
+    const int tiles = a.n_nt * a.n_mt;
+    const int tile = s % tiles;
+    const int nt = __builtin_amdgcn_readfirstlane(tile % a.n_nt);
+    const int mt = __builtin_amdgcn_readfirstlane(tile / a.n_nt);
+    const int z = __builtin_amdgcn_readfirstlane(xcd + kNumXCD * (s / tiles));
+    if (z >= a.nsplit) return;
     const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
     const int64_t kbeg = (int64_t)z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const int nk = (int)((kend - kbeg + BKH - 1) / BKH);
@@ -436,10 +459,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             uint4 w;
-            w.x = bf16_rne(f[0 + e]) | (bf16_rne(f[4 + e]) << 16);
-            w.y = bf16_rne(f[8 + e]) | (bf16_rne(f[12 + e]) << 16);
-            w.z = bf16_rne(f[16 + e]) | (bf16_rne(f[20 + e]) << 16);
-            w.w = bf16_rne(f[24 + e]) | (bf16_rne(f[28 + e]) << 16);
+            w.x = bf16_pack(f[0 + e], f[4 + e]);
+            w.y = bf16_pack(f[8 + e], f[12 + e]);
+            w.z = bf16_pack(f[16 + e], f[20 + e]);
+            w.w = bf16_pack(f[24 + e], f[28 + e]);
             *reinterpret_cast<uint4*>(img + (c4 * 4 + e) * ROWB + k8 * 16) = w;
         }
     };
@@ -505,6 +528,7 @@ inline bool tn_plan(int64_t M, int64_t N, int64_t K, TnPlan& p) {
     p.n_nt = (int)cdiv(N, p.bn);
     const int64_t tiles = (int64_t)p.n_mt * p.n_nt;
     int64_t ns = std::max<int64_t>(1, kNumCU / tiles);
+    if (ns >= kNumXCD) ns = ns / kNumXCD * kNumXCD;              // whole XCD rounds (the kernel groups a slab's tiles per XCD)
     ns = std::min(ns, std::max<int64_t>(1, K / (BKH * 4)));
     p.kchunk = cdiv(cdiv(K, ns), BKH) * BKH;
     p.nsplit = (int)cdiv(K, p.kchunk);
@@ -543,6 +567,31 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
         if (bn == 160) return launch_bf16<128, 160, 3, 512>(a, act, st);
         return launch_bf16<128, 128, 3, 512>(a, act, st);
     }
+#ifdef GEOGCN_BF16_PROBE_BUILD      // ablation build only (hipcc -DGEOGCN_BF16_PROBE_BUILD; profiles/r02_c_bf16_gemm.md)
+    static const int probe = [] { const char* e = getenv("GEOGCN_BF16_PROBE"); return e ? atoi(e) : 0; }();
+    if (probe && bn == 160 && act == GEOGCN_ACT_NONE) {
+        using Cfg = BCfg<128, 160, 1, 256>;
+        const int G = (int)std::min<int64_t>((int64_t)kNumCU * 2, cdiv((int64_t)a.n_mt * a.n_nt, kNumXCD) * kNumXCD);
+#define GEOGCN_P(P_)                                                                                                  \
+    do {                                                                                                              \
+        auto kern = gemm_bf16_kernel<128, 160, 1, GEOGCN_ACT_NONE, 256, P_>;                                          \
+        GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), Cfg::kLdsBytes, st, a);                              \
+    } while (0)
+        switch (probe) {
+            case 1: GEOGCN_P(1); break;
+            case 2: GEOGCN_P(2); break;
+            case 3: GEOGCN_P(3); break;
+            case 4: GEOGCN_P(4); break;
+            case 7: GEOGCN_P(7); break;
+            case 8: GEOGCN_P(8); break;
+            case 15: GEOGCN_P(15); break;
+            default: break;
+        }
+#undef GEOGCN_P
+        if (probe == 1 || probe == 2 || probe == 3 || probe == 4 || probe == 7 || probe == 8 || probe == 15) return 0;
+    }
+#endif
     if (bn == 160) return launch_bf16<128, 160, 1, 256>(a, act, st);
     return launch_bf16<128, 128, 1, 256>(a, act, st);
 }
@@ -566,7 +615,7 @@ int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64
                    ws_bytes, need);
     const int64_t ldw = (N + 3) & ~(int64_t)3;
     TnArgs a{M, N, K, A, lda, B, ldb, (float*)ws, ldw, p.kchunk, p.n_mt, p.n_nt, p.nsplit};
-    const dim3 grid((unsigned)((int64_t)p.n_mt * p.n_nt * p.nsplit));
+    const dim3 grid((unsigned)((int64_t)p.n_mt * p.n_nt * cdiv(p.nsplit, kNumXCD) * kNumXCD));
 #define GEOGCN_TN(BM_, BN_)                                                                                     \
     do {                                                                                                        \
         auto kern = gemm_bf16_tn_kernel<BM_, BN_>;                                                              \

@@ -89,13 +89,21 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
                                                  const float* __restrict__ val,
                                                  const void* __restrict__ B, int64_t ldb,
                                                  float4 (&acc)[K4]) {
+    // (col, val) of batch i+1 are loaded before batch i's gathers are issued: a row of the TwitterUS-shape graph has 24
+    // entries on average = two batches, and the second index load would otherwise sit between two gather phases
+    int c = 0;
+    float a = 0.f;
+    if (s + lane16 < e) {
+        c = colidx[s + lane16];
+        a = val[s + lane16];
+    }
     for (int base = s; base < e; base += G) {
-        const int j = base + lane16;
-        int c = 0;
-        float a = 0.f;
-        if (j < e) {
-            c = colidx[j];
-            a = val[j];
+        const int jn = base + G + lane16;
+        int cn = 0;
+        float an = 0.f;
+        if (jn < e) {
+            cn = colidx[jn];
+            an = val[jn];
         }
         const int cnt = min(G, e - base);
         int t = 0;
@@ -163,6 +171,8 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
                 }
             }
         }
+        c = cn;
+        a = an;
     }
 }
 

@@ -600,6 +600,7 @@ DENSE_HEAD_MAX_COLS = 512
 # through the document-blocked kernel (geogcn_xt_dot_f32) from XT_MIN_NNZ stored tail entries on (below that dS0 sits
 # in the L2 / Infinity Cache anyway and the plain row gather is as fast).
 XT_MIN_NNZ = int(os.environ.get('GEOGCN_XT_MIN_NNZ', 1_000_000))
+XT_MAX_F = int(os.environ.get('GEOGCN_XT_MAX_F', 320))
 # forward X.W0: the tail's W0 rows are gathered in column slabs of this many floats so that the slab (n_tail_words x
 # slab x 4 bytes) stays inside one XCD's 4 MB L2; 0 = one pass over all columns
 X_FWD_SLAB = int(os.environ.get('GEOGCN_X_FWD_SLAB', 0))
@@ -742,14 +743,21 @@ def sparse_dropout(x: SparseOperand, p, seed, call):
 
 def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff)."""
-    plan = x.xt_plan(G.F)
-    if plan is not None:
+    # column slabs of <= XT_MAX_F: the kernel keeps 2 x F/64 float4 accumulators per lane in registers; up to 320 columns
+    # that leaves room for 1024-thread workgroups, beyond it halves the threads and doubles the batches (F = 600 in one
+    # piece: 5.5 ms, slower than the row gather's 4.0; as two slabs of 300: see DESIGN.md 4.2)
+    n_slab = -(-G.F // XT_MAX_F)
+    width = pad4(-(-G.F // n_slab))
+    if x.xt_plan(min(width, G.F)) is not None:
         # tail rows through the document-blocked kernel (every row written; head rows as zeros)
         if out is None:
             out = DMat.empty(x.bwd.shape[0], G.F, G.device)
-        w = _ws_for(G.device).get(plan.ws_bytes)
-        check(_ffi.lib().geogcn_xt_dot_f32(plan._h, _p(x.bwd.colidx), _p(x.bwd.val), _p(G.t), G.ld, _p(out.t), out.ld,
-                                           _p(w), w.numel(), _stream()), 'xt_dot_f32')
+        for c0 in range(0, G.F, width):
+            plan = x.xt_plan(min(width, G.F - c0))
+            w = _ws_for(G.device).get(plan.ws_bytes)
+            check(_ffi.lib().geogcn_xt_dot_f32(plan._h, _p(x.bwd.colidx), _p(x.bwd.val), C.c_void_p(G.t.data_ptr() + 4 * c0), G.ld,
+                                               C.c_void_p(out.t.data_ptr() + 4 * c0), out.ld, _p(w), w.numel(), _stream()),
+                  'xt_dot_f32')
     else:
         out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)
     if x.head_dense is not None:

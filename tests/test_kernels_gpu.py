@@ -433,6 +433,10 @@ def test_xt_dot_document_blocked_matches_oracle(dev, n_docs, n_words, mean, F, m
     dG2 = ops.DMat.empty(n_docs, F, dev, ld=ops.gather_ld(F))
     dG2.copy_from(dG)
     assert torch.equal(ops.spmm_t(x, dG2).t[:, :F], out.t[:, :F])
+    # wide outputs run as column slabs of <= XT_MAX_F; in one piece the rows are cut into different parts (the plan
+    # depends on the width), so: the same numbers up to summation order
+    monkeypatch.setattr(ops, 'XT_MAX_F', 1 << 30)
+    assert np.all(np.abs(ops.spmm_t(x, dG).numpy() - out.numpy()) <= 4e-6 * mag + 1e-6)
 
 
 def test_xt_dot_with_dense_head_and_value_dropout(dev, monkeypatch):

@@ -18,12 +18,13 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--shape', default='twus')
     ap.add_argument('--only', default='all', choices=['all', 'fwd', 'xt'])
+    ap.add_argument('--F', type=int, default=300)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     s = synth.SHAPES[args.shape]
     X = synth.bow_x(s.N, s.V, s.mean_nnz)
     x = ops.SparseOperand.from_scipy(X, dev)
-    F = 300
+    F = args.F
     rng = np.random.RandomState(1)
     W = ops.DMat.from_numpy((rng.randn(s.V, F) * 0.05).astype(np.float32), dev)
     b = torch.zeros(ops.pad4(F), device=dev)
@@ -54,7 +55,7 @@ def main():
       show('X.W0   dense head GEMM + tail', timeit(lambda: ops.spmm_x(x, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
     if args.only == 'fwd':
         return
-    print('doc block %s rows, rendezvous %s' % (os.environ.get('GEOGCN_XT_DOC_BLOCK', '1024'), os.environ.get('GEOGCN_XT_RENDEZVOUS', '1')))
+    print('doc block %s rows, rendezvous %s' % (os.environ.get('GEOGCN_XT_DOC_BLOCK', 'default'), os.environ.get('GEOGCN_XT_RENDEZVOUS', '0')))
     for name, g in (('ld 320', G), ('ld 300', G300)):
         ops.XT_MIN_NNZ = 0
         show('X^T.dS0  head GEMM + document-blocked tail (%s)' % name, timeit(lambda: ops.spmm_t(x, g, out=dW), args.reps)[0], alg_bwd)

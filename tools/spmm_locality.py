@@ -31,6 +31,18 @@ def main():
     res = []
     for case in args.cases.split(','):
         name, _, method = case.partition('+')
+        if name not in base and name == 'band':
+            # every neighbour within +-600 rows: the gather's ideal case (an upper bound for what reordering can give)
+            import scipy.sparse as sps
+            rng = np.random.RandomState(0)
+            k = 24
+            rows = np.repeat(np.arange(s.N), k)
+            cols = np.clip(rows + rng.randint(-600, 601, size=len(rows)), 0, s.N - 1)
+            B0 = sps.coo_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(s.N, s.N)).tocsr()
+            B0.data[:] = 1.0 / k
+            B0.sort_indices()
+            base[name] = B0
+            print('[band generated: nnz %d]' % B0.nnz, flush=True)
         if name not in base:
             t0 = time.time()
             base[name] = synth.powerlaw_ahat(s.N, s.E_target) if name == 'pinned' else synth.community_ahat(s.N, s.E_target, args.communities)
