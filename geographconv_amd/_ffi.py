@@ -16,6 +16,7 @@ GEMM_F32, GEMM_BF16X3, GEMM_BF16 = 0, 1, 2
 
 c_i32, c_i64, c_f32, c_sz, c_ptr = C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_void_p
 c_u64 = C.c_uint64
+COMM_ID_BYTES = 128        # GEOGCN_COMM_ID_BYTES
 
 # name -> (restype, argtypes); mirrors include/geogcn.h one to one
 SIGNATURES = {
@@ -86,6 +87,15 @@ SIGNATURES = {
                                              c_ptr, c_sz, c_ptr]),
     'geogcn_gather_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_scatter_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'geogcn_comm_available': (c_i32, []),
+    'geogcn_comm_unique_id': (c_i32, [c_ptr, c_sz]),
+    'geogcn_comm_init_rank': (c_i32, [c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
+    'geogcn_comm_destroy': (None, [c_ptr]),
+    'geogcn_comm_world': (c_i32, [c_ptr]),
+    'geogcn_comm_rank': (c_i32, [c_ptr]),
+    'geogcn_comm_allreduce_sum_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
+    'geogcn_comm_allgather': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'geogcn_comm_alltoall': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'geogcn_pack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     'geogcn_unpack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,
@@ -136,5 +146,5 @@ def lib():
 def check(rc: int, what: str = ''):
     if rc != 0:
         msg = lib().geogcn_last_error().decode('utf-8', 'replace')
-        kind = 'argument error' if rc < 0 else 'hipError'
+        kind = 'argument error' if rc < 0 else ('hipError' if rc < 1000 else 'ncclResult + 1000')
         raise GeoGcnError("%s failed (%s %d): %s" % (what or 'geogcn call', kind, rc, msg))

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libgeogcn.so')
-SOURCES = ['core.hip', 'spmm.hip', 'spmm_hot.hip', 'xt.hip', 'gemm.hip', 'gemm_bf16.hip', 'elementwise.hip', 'softmax_adam.hip']
+SOURCES = ['core.hip', 'spmm.hip', 'spmm_hot.hip', 'xt.hip', 'gemm.hip', 'gemm_bf16.hip', 'elementwise.hip', 'softmax_adam.hip', 'comm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-Wall', '-Wno-unused-function']
 # ablation / experiment builds: GEOGCN_BUILD_DEFINES="GEOGCN_BF16_PROBE_BUILD ..." python -m geographconv_amd.build --force

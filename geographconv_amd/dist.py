@@ -25,6 +25,7 @@ Collectives go through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
 the CPU tests).  GEOGCN_DIST_EXCHANGE=a2a|allgather overrides the default (all-gather at 2 ranks, a2a from 3)."""
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import numpy as np
@@ -204,8 +205,94 @@ class StreamOverlapComm(Comm):
         return h['out']
 
 
+class _StreamWork:
+    """What an asynchronous NativeRccl collective returns: wait() orders the CURRENT stream after it (no host block)."""
+
+    def __init__(self, done):
+        self._done = done
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self._done)
+        return True
+
+
+class NativeRccl:
+    """The three collectives TorchDistComm uses, through the library's OWN RCCL entry points (include/geogcn.h
+    geogcn_comm_*) instead of torch.distributed -- same call shapes, so TorchDistComm does not care which it holds
+    (`GEOGCN_DIST_BACKEND=native`).  A synchronous call is enqueued on the current stream; an asynchronous one on a side
+    stream that first waits for the current stream (the semantics of torch's NCCL process group)."""
+
+    class ReduceOp:
+        SUM = 'sum'
+
+    def __init__(self, world, rank, unique_id: bytes, device):
+        from . import _ffi
+        self._ffi = _ffi
+        self._lib = _ffi.lib()
+        if not self._lib.geogcn_comm_available():
+            raise RuntimeError("GEOGCN_DIST_BACKEND=native: RCCL is not available in this process")
+        torch.cuda.set_device(device)
+        self._h = C.c_void_p(0)
+        idbuf = C.create_string_buffer(bytes(unique_id), _ffi.COMM_ID_BYTES)
+        _ffi.check(self._lib.geogcn_comm_init_rank(idbuf, int(world), int(rank), C.byref(self._h)), 'comm_init_rank')
+        self.world, self.rank = int(world), int(rank)
+        self.side = torch.cuda.Stream(device=device)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _ffi
+        buf = C.create_string_buffer(_ffi.COMM_ID_BYTES)
+        _ffi.check(_ffi.lib().geogcn_comm_unique_id(buf, _ffi.COMM_ID_BYTES), 'comm_unique_id')
+        return buf.raw
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.geogcn_comm_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _run(self, enqueue, async_op, tensors):
+        cur = torch.cuda.current_stream()
+        if not async_op:
+            enqueue(C.c_void_p(cur.cuda_stream))
+            return None
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.side.wait_event(ready)
+        enqueue(C.c_void_p(self.side.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(self.side)
+        for t in tensors:
+            t.record_stream(self.side)
+        return _StreamWork(done)
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        return self._run(lambda st: self._ffi.check(self._lib.geogcn_comm_allreduce_sum_f32(
+            self._h, C.c_void_p(t.data_ptr()), t.numel(), st), 'comm_allreduce_sum_f32'), async_op, (t,))
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        nbytes = inp.numel() * inp.element_size()
+        assert out.is_contiguous() and inp.is_contiguous() and out.numel() * out.element_size() == nbytes * self.world
+        return self._run(lambda st: self._ffi.check(self._lib.geogcn_comm_allgather(
+            self._h, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), nbytes, st), 'comm_allgather'), async_op, (out, inp))
+
+    def all_to_all_single(self, out, inp, group=None, async_op=False):
+        nbytes = inp.numel() * inp.element_size()
+        assert out.is_contiguous() and inp.is_contiguous() and out.numel() * out.element_size() == nbytes and nbytes % self.world == 0
+        return self._run(lambda st: self._ffi.check(self._lib.geogcn_comm_alltoall(
+            self._h, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), nbytes // self.world, st), 'comm_alltoall'),
+            async_op, (out, inp))
+
+
 class TorchDistComm(Comm):
-    """One process per GPU; RCCL (or gloo) through torch.distributed."""
+    """One process per GPU; RCCL (or gloo) through torch.distributed -- or, with GEOGCN_DIST_BACKEND=native, rendezvous
+    through torch.distributed and the data path through the library's own RCCL entry points (NativeRccl)."""
 
     def __init__(self, N, device, group=None, exchange=None):
         import torch.distributed as dist
@@ -213,6 +300,10 @@ class TorchDistComm(Comm):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        if os.environ.get('GEOGCN_DIST_BACKEND', 'torch') == 'native' and torch.device(device).type == 'cuda':
+            box = [NativeRccl.unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            self.dist = NativeRccl(self.world, self.rank, box[0], device)
         self.part = RowPartition(N, self.world, self.rank)
         self.device = device
         self.exchange = exchange or os.environ.get('GEOGCN_DIST_EXCHANGE', 'auto')

@@ -321,6 +321,33 @@ int geogcn_pack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* X,
 int geogcn_unpack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* in, int32_t W, int32_t wp,
                              float* Y, int64_t ldy, void* stream);
 
+/* ---- collectives of the partitioned step: RCCL over xGMI, one process per GPU ------------------------------------
+ * No reference counterpart (the reference is one process on one device; the step partitioned here is
+ * gcnmodel.py:409-430).  These are what a host WITHOUT torch.distributed binds; RCCL is looked up at run time (dlopen),
+ * so the library loads without it and geogcn_comm_available() says whether the calls below can work.
+ * Protocol: rank 0 calls geogcn_comm_unique_id and hands the 128 bytes to every rank by any means (file, socket, MPI);
+ * every rank selects its GPU (hipSetDevice) and calls geogcn_comm_init_rank -- collective, blocks until all have
+ * joined.  All operations are enqueued on `stream` and return immediately; buffers are borrowed until the stream has
+ * passed them.  Errors: <0 GEOGCN_E_*, >0 a hipError_t, >= 1000 an ncclResult_t + 1000 (text in geogcn_last_error).  */
+#define GEOGCN_COMM_ID_BYTES 128
+typedef struct geogcn_comm geogcn_comm;
+int     geogcn_comm_available(void);
+int     geogcn_comm_unique_id(void* id_out, size_t id_bytes);
+int     geogcn_comm_init_rank(const void* id, int32_t world, int32_t rank, geogcn_comm** out);
+void    geogcn_comm_destroy(geogcn_comm* comm);
+int32_t geogcn_comm_world(const geogcn_comm* comm);
+int32_t geogcn_comm_rank(const geogcn_comm* comm);
+/* gradients, loss sums:  buf[i] = sum over ranks of buf[i]  (in place; the summation order is RCCL's, hence the
+ * 1e-6 relative tolerance of the N-GPU == 1-GPU tests on everything that passes through it)                        */
+int     geogcn_comm_allreduce_sum_f32(geogcn_comm* comm, float* buf, int64_t n, void* stream);
+/* row shards of Z / dS:  recv = [rank 0's bytes | rank 1's | ...], bytes_per_rank each (equal slots: the cost-balanced
+ * split pads the shorter shards, dist.py RowPartition.R); in place when send == recv + rank * bytes_per_rank        */
+int     geogcn_comm_allgather(geogcn_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+/* feature repartition:  panel p of `send` goes to rank p, panel q of `recv` comes from rank q (the [W][R][wp] layout
+ * geogcn_gemm_panels_f32 writes and the narrow SpMM reads); W - 1 point-to-point transfers in one group, one per xGMI
+ * link.  send and recv must not alias.                                                                              */
+int     geogcn_comm_alltoall(geogcn_comm* comm, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+
 /* ---- K11/K12: lasagne.updates.adam (+ l1/l2 penalty gradient), gcnmodel.py:383-387,407 ------
  * flat arenas of n floats: t is the step index AFTER increment (1 for the first call).
  *   g' = g + regmask*(l1*sign(p) + 2*l2*p);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2

@@ -80,7 +80,7 @@ def main():
             for g, r in zip(got[2], ref[2]):
                 assert np.allclose(g, r, rtol=5e-2, atol=5e-3 * np.abs(r).max() + 1e-7)
     if dist.get_rank() == 0:
-        print('DIST_GPU_OK world=%d' % dist.get_world_size())
+        print('DIST_GPU_OK world=%d backend=%s' % (dist.get_world_size(), type(comm.dist).__name__))
     dist.destroy_process_group()
 
 

@@ -21,3 +21,55 @@ def test_torchrun_nccl_world1_matches_golden():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_GPU_OK world=%d' % n in r.stdout
+
+
+def test_torchrun_native_rccl_entry_points_match_golden():
+    """The same worker with the data path on the library's own RCCL entry points (include/geogcn.h geogcn_comm_*,
+    GEOGCN_DIST_BACKEND=native) instead of torch.distributed's."""
+    import torch
+    n = min(2, torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GEOGCN_DIST_BACKEND='native')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', '29519', os.path.join(root, 'tests', 'dist_gpu_worker.py')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'DIST_GPU_OK world=%d' % n in r.stdout
+    assert 'backend=NativeRccl' in r.stdout
+
+
+def test_comm_entry_points_world1():
+    """geogcn_comm_* at world 1 (all a 1-GPU box allows): unique id, init, the three collectives on device buffers (an
+    all-reduce over one rank is the identity, the all-gather is in place, the all-to-all copies the own panel), error
+    codes, destroy."""
+    import ctypes as C
+
+    import torch
+    from geographconv_amd import _ffi, dist as gdist
+    lib = _ffi.lib()
+    assert lib.geogcn_comm_available() == 1
+    dev = torch.device('cuda:0')
+    uid = gdist.NativeRccl.unique_id()
+    assert len(uid) == _ffi.COMM_ID_BYTES and any(uid)
+    small = C.create_string_buffer(16)
+    assert lib.geogcn_comm_unique_id(small, 16) == -2                       # GEOGCN_E_SIZE
+    c = gdist.NativeRccl(1, 0, uid, dev)
+    assert lib.geogcn_comm_world(c._h) == 1 and lib.geogcn_comm_rank(c._h) == 0
+    x = torch.arange(1000, dtype=torch.float32, device=dev)
+    ref = x.clone()
+    c.all_reduce(x)
+    w = c.all_reduce(x, async_op=True)
+    w.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    buf = torch.randn(64, 40, device=dev)
+    keep = buf.clone()
+    c.all_gather_into_tensor(buf, buf[0:64])
+    send = torch.randn(3, 128, device=dev).to(torch.bfloat16)
+    recv = torch.zeros_like(send)
+    c.all_to_all_single(recv.view(-1), send.view(-1), async_op=True).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, keep) and torch.equal(recv, send)
+    assert lib.geogcn_comm_alltoall(c._h, C.c_void_p(send.data_ptr()), C.c_void_p(send.data_ptr()), 16, None) == -1   # aliased
+    assert lib.geogcn_comm_allreduce_sum_f32(None, C.c_void_p(x.data_ptr()), 4, None) == -1
+    c.close()
