@@ -7,6 +7,8 @@
 // [F, ld) written as zero, no LDS staging (no reuse to capture).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace geogcn {
@@ -512,7 +514,10 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
     return 0;
 }
 
-static int64_t hw_parts(int64_t n) { return std::max<int64_t>(1, std::min<int64_t>(768, cdiv(n, 64))); }
+static int64_t hw_parts(int64_t n) {
+    static const int64_t cap = [] { const char* e = getenv("GEOGCN_HW_PARTS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : 768; }();
+    return std::max<int64_t>(1, std::min<int64_t>(cap, cdiv(n, 64)));
+}
 
 size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F) {
     if (n <= 0 || F <= 0) return 0;

@@ -93,6 +93,7 @@ def main():
     # streaming kernels
     if not do('stream'):
         return
+    G = ops.DMat.from_numpy(rng.randn(N, 300).astype(np.float32), dev)
     T = ops.DMat.from_numpy(rng.rand(N, 300).astype(np.float32), dev)
     Hc = ops.DMat.from_numpy(rng.randn(N, 300).astype(np.float32), dev)
     o = ops.DMat(N, 300, dev)
@@ -103,6 +104,13 @@ def main():
     med, mn = timeit(lambda: ops.highway_bwd(G, T, Hc, H, a, b, c), args.reps)
     print('highway_bwd: %.3f ms  %.0f GB/s' % (med, 7 * N * 300 * 4 / med / 1e6), flush=True)
     res['highway_bwd'] = {'ms': med, 'GBps': 7 * N * 300 * 4 / med / 1e6}
+    dbS, dbU = torch.zeros(300, device=dev), torch.zeros(300, device=dev)
+    med, mn = timeit(lambda: ops.highway_bwd(G, T, Hc, H, a, b, c, dbS, dbU), args.reps)
+    print('highway_bwd + column sums: %.3f ms  %.0f GB/s' % (med, 7 * N * 300 * 4 / med / 1e6), flush=True)
+    res['highway_bwd_colsum'] = {'ms': med, 'GBps': 7 * N * 300 * 4 / med / 1e6}
+    med, mn = timeit(lambda: ops.act_bwd_colsum(G, Hc, ops.ACT_TANH, dbS, out=a), args.reps)
+    print('act_bwd + column sums: %.3f ms  %.0f GB/s' % (med, 3 * N * 300 * 4 / med / 1e6), flush=True)
+    res['act_bwd_colsum'] = {'ms': med, 'GBps': 3 * N * 300 * 4 / med / 1e6}
     med, mn = timeit(lambda: ops.colsum(G), args.reps)
     print('colsum: %.3f ms  %.0f GB/s' % (med, N * 300 * 4 / med / 1e6), flush=True)
     res['colsum'] = {'ms': med}
