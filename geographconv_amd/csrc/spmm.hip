@@ -252,15 +252,19 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     // see every community in flight.  The ranges hold equal numbers of stored entries, not of rows (a hub-first
     // numbering would otherwise give one XCD all the work).  per_xcd = 0: plain map.
     int rb = blockIdx.x - n_chunk_blocks;
-    int row_end = n_rows;
+    int row_lo = 0, row_end = n_rows;
     if (per_xcd > 0) {
         // XCD x owns rows [xr.lo[x], xr.lo[x + 1]) (multiples of 32: balanced by stored entries on the host)
         const int x = rb % kNumXCD;
         rb = xr.lo[x] / (kBlock / G) + rb / kNumXCD;
+        row_lo = xr.lo[x];
         row_end = xr.lo[x + 1];
     }
     const int row = rb * (kBlock / G) + (threadIdx.x / G);
-    if (row >= row_end) return;
+    // (a boundary clamped to n_rows need not be a multiple of the block's rows: the division above then starts the block
+    //  BELOW row_lo, inside the previous XCD's range -- harmless for a plain product, which would just be written twice,
+    //  but the accumulate form reads what it writes)
+    if (row < row_lo || row >= row_end) return;
     const int s = rowptr[row];
     const int e = rowptr[row + 1];
     if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks

@@ -1,0 +1,265 @@
+"""Randomised (seeded, reproducible) sweeps over the C-ABI entry points: odd sizes, padded pitches, empty rows / empty
+matrices, rows around the long-row threshold, every epilogue -- each case against an fp64 NumPy product with an envelope
+scaled by the magnitudes that enter the sum (|A|.|B|), i.e. the tolerance is that of fp32 summation in ANY order:
+   |got - ref| <= 4e-6 * (|A| . |B| [+ |bias|]) * act_lipschitz + 1e-6
+The fixed-shape tests in test_kernels_gpu.py pin the interesting corners; this file is the net under them."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from geographconv_amd import ops
+    ops.require_gpu()
+    return torch.device("cuda:0")
+
+
+def _act(x, act):
+    if act == 1:
+        return np.tanh(x)
+    if act == 2:
+        return 1.0 / (1.0 + np.exp(-x))
+    return x
+
+
+def _dmat(ops, dev, a, rng, pad=True):
+    """Device matrix with a random legal pitch (>= pad4(F), multiple of 4), pads zero."""
+    n, F = a.shape
+    ld = ops.pad4(F) + (4 * rng.randint(0, 3) if pad else 0)
+    m = ops.DMat.empty(n, F, dev, ld=max(ld, 4))
+    m.t.zero_()
+    if n and F:
+        m.t[:, :F].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    return m
+
+
+def _csr(rng, n_rows, n_cols, mean, long_every=0, long_nnz=0):
+    rows, cols = [], []
+    for r in range(n_rows):
+        k = 0 if rng.rand() < 0.15 else min(n_cols, rng.poisson(mean))
+        if long_every and r % long_every == 1:
+            k = min(n_cols, long_nnz)
+        if k:
+            rows += [r] * k
+            cols += list(rng.choice(n_cols, size=k, replace=False))
+    vals = rng.randn(len(rows)).astype(np.float32)
+    m = sps.csr_matrix((vals, (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))), shape=(n_rows, n_cols),
+                       dtype=np.float32)
+    m.sort_indices()
+    return m
+
+
+def _close(got, ref, mag, what, slack=4e-6):
+    err = np.abs(got.astype(np.float64) - ref)
+    bound = slack * mag + 1e-6
+    assert np.all(err <= bound), (what, float(err.max()), float((err - bound).max()))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gemm_random_shapes(dev, seed):
+    """geogcn_gemm_f32 in all four layouts that the path uses, with bias / activation / accumulate."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(1000 + seed)
+    for case in range(14):
+        M, N, K = (int(rng.choice([1, 3, 17, 64, 100, 129, 255, 300, 321, 700])) for _ in range(3))
+        transA, transB = bool(rng.randint(2)), bool(rng.randint(2))
+        if transA:
+            transB = False                                   # (A^T . B^T is never formed on the path)
+        act = int(rng.choice([0, 1, 2])) if not transA else 0
+        use_bias = bool(rng.randint(2)) and not transA
+        accumulate = bool(rng.randint(2))
+        A = rng.randn(K, M).astype(np.float32) if transA else rng.randn(M, K).astype(np.float32)
+        B = rng.randn(N, K).astype(np.float32) if transB else rng.randn(K, N).astype(np.float32)
+        bias = rng.randn(N).astype(np.float32) if use_bias else None
+        C0 = rng.randn(M, N).astype(np.float32)
+        a64 = (A.T if transA else A).astype(np.float64)
+        b64 = (B.T if transB else B).astype(np.float64)
+        pre = a64 @ b64 + (bias.astype(np.float64) if use_bias else 0.0)
+        ref = _act(pre, act) + (C0 if accumulate else 0.0)
+        mag = np.abs(a64) @ np.abs(b64) + (np.abs(bias) if use_bias else 0.0) + (np.abs(C0) if accumulate else 0.0)
+        dA, dB = _dmat(ops, dev, A, rng), _dmat(ops, dev, B, rng)
+        out = _dmat(ops, dev, C0, rng)
+        bt = None
+        if use_bias:
+            bt = torch.zeros(ops.pad4(N), device=dev)
+            bt[:N] = torch.from_numpy(bias)
+        got = ops.gemm(dA, dB, out=out, transA=transA, transB=transB, bias=bt, act=act, accumulate=accumulate)
+        _close(got.numpy(), ref, mag, ('gemm', seed, case, M, N, K, transA, transB, act, use_bias, accumulate))
+        assert torch.all(got.t[:, N:ops.pad4(N)] == 0), ('pad columns', seed, case)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_gemm_dual_and_kcat_random_shapes(dev, seed):
+    """The highway block's fused launches: two weights on one input (plain and transposed input), two products into one
+    accumulator."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(2000 + seed)
+    for case in range(8):
+        M = int(rng.choice([5, 130, 257, 1000, 2311]))
+        K = int(rng.choice([3, 64, 129, 300]))
+        N0, N1 = (int(rng.choice([1, 40, 129, 300])) for _ in range(2))
+        H = rng.randn(M, K).astype(np.float32)
+        W0, W1 = rng.randn(K, N0).astype(np.float32) * 0.2, rng.randn(K, N1).astype(np.float32) * 0.2
+        b1 = rng.randn(N1).astype(np.float32)
+        dH, dW0, dW1 = _dmat(ops, dev, H, rng), _dmat(ops, dev, W0, rng), _dmat(ops, dev, W1, rng)
+        bt = torch.zeros(ops.pad4(N1), device=dev)
+        bt[:N1] = torch.from_numpy(b1)
+        z, t = ops.gemm_dual(dH, dW0, dW1, bias1=bt, act1=ops.ACT_SIGMOID)
+        h64 = H.astype(np.float64)
+        _close(z.numpy(), h64 @ W0, np.abs(h64) @ np.abs(W0), ('dual z', seed, case))
+        _close(t.numpy(), _act(h64 @ W1 + b1, 2), np.abs(h64) @ np.abs(W1) + np.abs(b1), ('dual t', seed, case))
+        # transposed input: (K x N0, K x N1) = H^T . (G0, G1) with M the reduction
+        G0, G1 = rng.randn(M, N0).astype(np.float32), rng.randn(M, N1).astype(np.float32)
+        g0, g1 = ops.gemm_dual(dH, _dmat(ops, dev, G0, rng), _dmat(ops, dev, G1, rng), transA=True)
+        _close(g0.numpy(), h64.T @ G0, np.abs(h64.T) @ np.abs(G0), ('dual tn 0', seed, case))
+        _close(g1.numpy(), h64.T @ G1, np.abs(h64.T) @ np.abs(G1), ('dual tn 1', seed, case))
+        # k-concatenated: out (M x K) = G0 . W0^T + G1 . W1^T [+ out]
+        C0 = rng.randn(M, K).astype(np.float32)
+        out = _dmat(ops, dev, C0, rng)
+        acc = bool(rng.randint(2))
+        got = ops.gemm_kcat(_dmat(ops, dev, G0, rng), dW0, _dmat(ops, dev, G1, rng), dW1, out=out, transB=True, accumulate=acc)
+        ref = G0.astype(np.float64) @ W0.T + G1.astype(np.float64) @ W1.T + (C0 if acc else 0.0)
+        mag = np.abs(G0) @ np.abs(W0.T) + np.abs(G1) @ np.abs(W1.T) + (np.abs(C0) if acc else 0.0)
+        _close(got.numpy(), ref, mag, ('kcat', seed, case, acc))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_spmm_random_structures(dev, seed):
+    """geogcn_spmm_csr_f32 / _acc_f32 / _highway_f32 on random structures: empty rows, empty matrices, rows around the
+    long-row threshold (forced low so that the chunked path runs), random widths and pitches."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(3000 + seed)
+    for case in range(10):
+        n_rows = int(rng.choice([1, 2, 33, 257, 900]))
+        n_cols = int(rng.choice([1, 7, 300, 1200]))
+        F = int(rng.choice([1, 4, 37, 64, 129, 300, 333]))
+        long_nnz = int(rng.choice([48, 256]))
+        A = _csr(rng, n_rows, n_cols, mean=rng.choice([0, 3, 20]), long_every=int(rng.choice([0, 9])), long_nnz=long_nnz + 70)
+        B = rng.randn(n_cols, F).astype(np.float32)
+        act = int(rng.choice([0, 1]))
+        bias = rng.randn(F).astype(np.float32) if rng.randint(2) else None
+        dA = ops.CSR(A, dev, long_row_nnz=long_nnz, chunk_nnz=int(rng.choice([16, 128])))
+        dB = _dmat(ops, dev, B, rng)
+        bt = None
+        if bias is not None:
+            bt = torch.zeros(ops.pad4(F), device=dev)
+            bt[:F] = torch.from_numpy(bias)
+        a64 = A.astype(np.float64)
+        pre = np.asarray(a64 @ B.astype(np.float64)) + (bias if bias is not None else 0.0)
+        mag = np.asarray(abs(a64) @ np.abs(B).astype(np.float64)) + (np.abs(bias) if bias is not None else 0.0)
+        got = ops.spmm(dA, dB, bias=bt, act=act)
+        _close(got.numpy(), _act(pre, act), mag, ('spmm', seed, case, n_rows, n_cols, F, long_nnz))
+        # accumulate form: out = act(out + A . B + b)
+        C0 = rng.randn(n_rows, F).astype(np.float32)
+        out = _dmat(ops, dev, C0, rng, pad=False)
+        got = ops.spmm(dA, dB, out=out, bias=bt, act=act, accumulate=True)
+        _close(got.numpy(), _act(pre + C0, act), mag + np.abs(C0), ('spmm acc', seed, case))
+        # highway epilogue: Hout = T * tanh(A . B + b) + (1 - T) * H
+        if F % 4 == 0 or True:
+            T = rng.rand(n_rows, F).astype(np.float32)
+            Hm = rng.randn(n_rows, F).astype(np.float32)
+            ld = ops.pad4(F)
+            dT, dHm = ops.DMat.empty(n_rows, F, dev, ld=ld), ops.DMat.empty(n_rows, F, dev, ld=ld)
+            for d, a in ((dT, T), (dHm, Hm)):
+                d.t.zero_()
+                if n_rows:
+                    d.t[:, :F].copy_(torch.from_numpy(a))
+            hc, hout = ops.spmm_highway(dA, dB, bt, dT, dHm)
+            ref_hc = np.tanh(pre)
+            _close(hc.numpy(), ref_hc, mag, ('highway hc', seed, case))
+            _close(hout.numpy(), T * ref_hc + (1.0 - T) * Hm, mag + np.abs(Hm), ('highway out', seed, case))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bow_products_random(dev, seed, monkeypatch):
+    """X . W0 with the hot rows of W0 in LDS and X^T . G through the document-blocked kernel, random bag-of-words
+    structures (Zipfian columns), against fp64."""
+    from geographconv_amd import ops, synth
+    monkeypatch.setattr(ops, 'XT_MIN_NNZ', 0)
+    monkeypatch.setattr(ops, 'HOT_MIN_NNZ', 0)
+    rng = np.random.RandomState(4000 + seed)
+    for case in range(4):
+        n_docs = int(rng.choice([300, 2100, 9000]))
+        n_words = int(rng.choice([40, 333, 1500]))
+        F = int(rng.choice([5, 64, 129, 300, 340]))
+        X = sps.csr_matrix(synth.bow_x(n_docs, n_words, int(rng.choice([3, 12, 30])), seed=seed * 10 + case))
+        X.data[::5] *= -1.0
+        W = rng.randn(n_words, F).astype(np.float32)
+        G = rng.randn(n_docs, F).astype(np.float32)
+        b = rng.randn(F).astype(np.float32)
+        x = ops.SparseOperand.from_scipy(X, dev, dense_head=bool(rng.randint(2)))
+        bt = torch.zeros(ops.pad4(F), device=dev)
+        bt[:F] = torch.from_numpy(b)
+        x64 = X.astype(np.float64)
+        got = ops.spmm_x(x, _dmat(ops, dev, W, rng), bias=bt, act=1)
+        _close(got.numpy(), np.tanh(np.asarray(x64 @ W.astype(np.float64)) + b), np.asarray(abs(x64) @ np.abs(W)) + np.abs(b),
+               ('X.W0', seed, case, n_docs, n_words, F))
+        got = ops.spmm_t(x, _dmat(ops, dev, G, rng))
+        _close(got.numpy(), np.asarray(x64.T @ G.astype(np.float64)), np.asarray(abs(x64).T @ np.abs(G)),
+               ('X^T.G', seed, case, n_docs, n_words, F))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_softmax_ce_random(dev, seed):
+    """Row softmax + argmax, cross-entropy sums / hit counts on random index sets (with repeats), CE gradient."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(5000 + seed)
+    for case in range(6):
+        N = int(rng.choice([1, 50, 1000]))
+        C = int(rng.choice([2, 3, 129, 256, 700]))
+        L = (rng.randn(N, C) * rng.choice([0.1, 3.0])).astype(np.float32)
+        dL = _dmat(ops, dev, L, rng)
+        am = torch.zeros(N, dtype=torch.int32, device=dev)
+        P = ops.softmax_rows(dL, argmax=am)
+        e = np.exp(L.astype(np.float64) - L.max(axis=1, keepdims=True))
+        ref = e / e.sum(axis=1, keepdims=True)
+        assert np.allclose(P.numpy(), ref, rtol=2e-6, atol=1e-7), ('softmax', seed, case)
+        srt = np.sort(ref, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-6 if C > 1 else np.ones(N, bool)
+        assert np.array_equal(am.cpu().numpy()[clear], ref.argmax(axis=1)[clear]), ('argmax', seed, case)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_gemm_panel_output_and_reduced_precisions_random(dev, seed):
+    """The product written as feature panels (send layout of the multi-GPU repartition), fp32 and bf16 panels; and the
+    bf16 / bf16x3 arithmetic against fp64 with their own envelopes (bf16: 2^-8 per operand; bf16x3: fp32 class)."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(6000 + seed)
+    for case in range(6):
+        M = int(rng.choice([7, 200, 1031]))
+        K = int(rng.choice([5, 64, 300]))
+        N = int(rng.choice([3, 40, 129, 300]))
+        W = int(rng.choice([1, 2, 3, 8]))
+        transB = bool(rng.randint(2))
+        A = rng.randn(M, K).astype(np.float32)
+        B = (rng.randn(N, K) if transB else rng.randn(K, N)).astype(np.float32)
+        a64, b64 = A.astype(np.float64), (B.T if transB else B).astype(np.float64)
+        ref, mag = a64 @ b64, np.abs(a64) @ np.abs(b64)
+        dA, dB = _dmat(ops, dev, A, rng), _dmat(ops, dev, B, rng)
+        for bf16 in (False, True):
+            q = 8 if bf16 else 4
+            wp = (-(-N // W) + q - 1) // q * q
+            R = M + int(rng.randint(0, 5))
+            p = ops.Panels(M, N, R, W, wp, dev, bf16=bf16)
+            ops.gemm(dA, dB, out=p, transB=transB)
+            t = p.t.float().view(W, R, wp)[:, :M, :].permute(1, 0, 2).reshape(M, W * wp).cpu().numpy()
+            if bf16:
+                # bf16 operands (2^-9 relative each) and a bf16 result (2^-9 relative)
+                assert np.all(np.abs(t[:, :N] - ref) <= 2.0 ** -7 * mag + 2.0 ** -8 * np.abs(ref) + 1e-6), ('bf16 panels', seed, case)
+            else:
+                _close(t[:, :N], ref, mag, ('panels', seed, case, M, N, K, W, wp))
+            # (columns >= N are left untouched by contract -- include/geogcn.h; the buffer starts zeroed, nothing may leak in)
+            assert np.all(t[:, N:] == 0), ('panel pad columns', seed, case, bf16)
+        got = ops.gemm(dA, dB, transB=transB, precision='bf16x3')
+        _close(got.numpy(), ref, mag, ('bf16x3', seed, case), slack=8e-6)
+        got = ops.gemm(dA, dB, transB=transB, precision='bf16')
+        assert np.all(np.abs(got.numpy() - ref) <= 2.0 ** -7 * mag + 1e-6), ('bf16', seed, case)
+        if K >= 64:
+            G = rng.randn(M, N).astype(np.float32)
+            got = ops.gemm(dA, _dmat(ops, dev, G, rng), transA=True, precision='bf16')          # dW = A^T . G, M the reduction
+            assert np.all(np.abs(got.numpy() - a64.T @ G) <= 2.0 ** -7 * (np.abs(a64.T) @ np.abs(G)) + 1e-6), ('bf16 tn', seed, case)
