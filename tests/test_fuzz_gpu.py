@@ -263,3 +263,120 @@ def test_gemm_panel_output_and_reduced_precisions_random(dev, seed):
             G = rng.randn(M, N).astype(np.float32)
             got = ops.gemm(dA, _dmat(ops, dev, G, rng), transA=True, precision='bf16')          # dW = A^T . G, M the reduction
             assert np.all(np.abs(got.numpy() - a64.T @ G) <= 2.0 ** -7 * (np.abs(a64.T) @ np.abs(G)) + 1e-6), ('bf16 tn', seed, case)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_training_step_random_models(dev, seed):
+    """Whole f_train steps of randomly shaped models (odd widths, highway on / off, dropout with an injected mask,
+    L1+L2, index sets with gaps, graphs with empty rows) against the CPU restatement: losses, hit counts, probabilities,
+    every gradient, the Adam update -- then f_val."""
+    from geographconv_amd.nn import layers as L
+    from geographconv_amd import synth
+    from oracle import gcn_oracle as O
+    from tests.helpers import make_clf
+    rng = np.random.RandomState(7000 + seed)
+    N = int(rng.choice([19, 64, 150, 333]))
+    V = int(rng.choice([11, 40, 97]))
+    C = int(rng.choice([2, 3, 7, 33]))
+    highway = bool(rng.randint(2))
+    depth = int(rng.choice([1, 2, 3]))
+    w = int(rng.choice([4, 9, 16, 37]))
+    hid = [w] * depth if highway else [int(rng.choice([4, 9, 16, 37])) for _ in range(depth)]
+    p = float(rng.choice([0.0, 0.3, 0.5]))
+    reg = float(rng.choice([0.0, 1e-3]))
+    A, X, Y = synth.small_graph(N, 4.0, V, 6, C, seed=seed, empty_rows=int(rng.randint(0, 3)))
+    params = O.random_params(V, hid, C, highway, seed=seed + 1, scale=0.5)
+    perm = rng.permutation(N)
+    n_tr, n_dev = max(1, int(0.5 * N)), max(1, int(0.2 * N))
+    tr = np.sort(perm[:n_tr]).astype(np.int32)
+    dv = np.sort(perm[n_tr:n_tr + n_dev]).astype(np.int32)
+    te = np.sort(perm[n_tr + n_dev:]).astype(np.int32)
+    mask = (rng.rand(N, hid[0]) < (1 - p)).astype(np.uint8) if p > 0 else np.ones((N, hid[0]), np.uint8)
+    cfg = dict(N=N, V=V, C=C, hid=hid, highway=highway, p=p, reg=reg)
+    clf = make_clf(cfg, [q.copy() for q in params], device=dev)
+    clf.inject_dropout_mask(mask)
+    st = O.AdamState(params)
+    cur = [q.copy() for q in params]
+    what = (seed, cfg)
+    for step in range(2):
+        new, outs, grads = O.f_train(cur, st, X, Y[tr], Y[dv], A, tr, dv, hid, highway, p, mask.astype(np.float32), reg)
+        o = clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
+        assert np.allclose([float(v) for v in o[:4]], outs[:4], rtol=2e-5, atol=2e-6), (what, step, o[:4], outs[:4])
+        assert np.allclose(np.asarray(o[4]), outs[4], rtol=2e-4, atol=2e-6), (what, step)
+        for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+            assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (what, step, i, np.abs(g - r).max())
+        for i, (q, r) in enumerate(zip(L.get_all_param_values(clf.l_out), new)):
+            assert np.allclose(q, r, rtol=1e-4, atol=5e-5), (what, step, 'param', i, np.abs(q - r).max())
+        cur = new
+    # continue the comparison from the DEVICE's parameters (Adam amplifies rounding differences of tiny gradients)
+    cur = [q.copy() for q in L.get_all_param_values(clf.l_out)]
+    pred, probs = O.f_val(cur, X, A, te, hid, highway)
+    gp, gprobs = clf.predict(X, A, te)
+    assert np.allclose(gprobs, probs, rtol=2e-4, atol=2e-6), what
+    srt = np.sort(probs, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert np.array_equal(gp[clear], pred[clear]), what
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_elementwise_random(dev, seed):
+    """Highway mix and its backward (with and without the fused column sums), activation backward (+ column sums,
+    + dropout mask), dropout apply, column sums, pack / unpack of feature panels -- random sizes and pitches."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(8000 + seed)
+    for case in range(8):
+        n = int(rng.choice([1, 2, 63, 64, 65, 700, 4099]))
+        F = int(rng.choice([1, 3, 4, 37, 128, 300, 301]))
+        T = rng.rand(n, F).astype(np.float32)
+        Hc = np.tanh(rng.randn(n, F)).astype(np.float32)
+        H, G = rng.randn(n, F).astype(np.float32), rng.randn(n, F).astype(np.float32)
+        ld = ops.pad4(F)
+        mk = lambda a: _dmat(ops, dev, a, rng, pad=False)
+        dT, dHc, dH, dG = mk(T), mk(Hc), mk(H), mk(G)
+        out = ops.highway_fwd(dT, dHc, dH)
+        assert np.allclose(out.numpy(), T * Hc + (1 - T) * H, rtol=1e-6, atol=1e-6), ('highway_fwd', seed, case)
+        rS = G * T * (1 - Hc * Hc)
+        rU = G * (Hc - H) * T * (1 - T)
+        rC = G * (1 - T)
+        for with_sums in (False, True):
+            dbS = torch.full((ld,), 9.0, device=dev) if with_sums else None
+            dbU = torch.full((ld,), 9.0, device=dev) if with_sums else None
+            dS, dU, dC = ops.highway_bwd(dG, dT, dHc, dH, dbS=dbS, dbU=dbU)
+            for got, ref, nm in ((dS, rS, 'dS'), (dU, rU, 'dU'), (dC, rC, 'dHcarry')):
+                assert np.allclose(got.numpy(), ref, rtol=2e-6, atol=1e-6), (nm, seed, case, with_sums)
+            if with_sums:
+                for got, ref, nm in ((dbS, rS, 'dbS'), (dbU, rU, 'dbU')):
+                    r64 = ref.astype(np.float64).sum(axis=0)
+                    assert np.all(np.abs(got.cpu().numpy()[:F] - r64) <= 4e-6 * np.abs(ref).sum(axis=0) + 1e-6), (nm, seed, case)
+        keep = (rng.rand(n, F) < 0.6).astype(np.uint8)
+        dk = torch.from_numpy(keep).to(dev)
+        for act, dfun in ((1, lambda y: 1 - y * y), (2, lambda y: y * (1 - y))):
+            Yv = (np.tanh(H) if act == 1 else T).astype(np.float32)
+            dY = mk(Yv)
+            for km, scale in ((None, 1.0), (dk, 1.0 / 0.6)):
+                m = 1.0 if km is None else keep * np.float32(scale)
+                ref = G * m * dfun(Yv)
+                got = ops.act_bwd(dG, dY, act, keep_mask=km, scale=scale)
+                assert np.allclose(got.numpy(), ref, rtol=3e-6, atol=1e-6), ('act_bwd', seed, case, act)
+                db = torch.full((ld,), 9.0, device=dev)
+                got = ops.act_bwd_colsum(dG, dY, act, db, keep_mask=km, scale=scale)
+                assert np.allclose(got.numpy(), ref, rtol=3e-6, atol=1e-6), ('act_bwd_colsum', seed, case, act)
+                assert np.all(np.abs(db.cpu().numpy()[:F] - ref.astype(np.float64).sum(axis=0)) <= 4e-6 * np.abs(ref).sum(axis=0) + 1e-6)
+        got = ops.dropout_apply(dH, dk, 0.4)
+        assert np.allclose(got.numpy(), H * keep * np.float32(1 / 0.6), rtol=2e-6, atol=1e-7), ('dropout_apply', seed, case)
+        cs = ops.colsum(dG)
+        assert np.all(np.abs(cs.cpu().numpy()[:F] - G.astype(np.float64).sum(axis=0)) <= 4e-6 * np.abs(G).sum(axis=0) + 1e-6)
+        # feature panels: pack, then unpack, is the identity on the n x F block
+        W = int(rng.choice([1, 2, 3, 8]))
+        wp = (-(-F // W) + 3) // 4 * 4
+        R = n + int(rng.randint(0, 4))
+        buf = torch.full((W * R * wp,), 5.0, device=dev)
+        ops.pack_panels(dG, R, W, wp, buf)
+        v = buf.view(W, R, wp).cpu().numpy()
+        full = np.zeros((R, W * wp), np.float32)
+        full[:n, :F] = G
+        assert np.array_equal(v.transpose(1, 0, 2).reshape(R, W * wp), full), ('pack', seed, case)
+        back = ops.DMat.empty(n, F, dev)
+        back.t.fill_(3.0)
+        ops.unpack_panels(buf, R, W, wp, back)
+        assert np.array_equal(back.numpy(), G) and torch.all(back.t[:, F:] == 0), ('unpack', seed, case)
