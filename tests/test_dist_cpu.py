@@ -222,3 +222,88 @@ def test_multi_rank_asymmetric_adjacency(exchange, world):
     assert np.allclose(P, ref[4], rtol=1e-4, atol=2e-6)
     for i, (g, r) in enumerate(zip(grads, rg)):
         assert np.allclose(g, r, rtol=2e-4, atol=2e-7 + 1e-5 * np.abs(r).max()), i
+
+
+def _random_worker(rank, world, port, q, exchange):
+    """Random models through the partitioned path: N not divisible by (or smaller than) the world size, widths that do not
+    divide into equal panels, tiny class counts, index sets with gaps -- every rank checks against the restatement."""
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    err = None
+    try:
+        from geographconv_amd import backend
+        from geographconv_amd.dist import TorchDistComm
+        from geographconv_amd.nn import layers as L
+        from tests import cpu_backend_double
+        from tests.helpers import make_clf
+        backend.use(cpu_backend_double)
+        for seed in range(7):
+            rng = np.random.RandomState(9000 + seed)
+            N = int(rng.choice([2, 5, 23, 64, 131]))
+            V = int(rng.choice([6, 19, 40]))
+            C = int(rng.choice([2, 5, 17]))
+            highway = bool(rng.randint(2))
+            depth = int(rng.choice([1, 2, 3]))
+            w = int(rng.choice([3, 8, 13]))
+            hid = [w] * depth if highway else [int(rng.choice([3, 8, 13])) for _ in range(depth)]
+            p = float(rng.choice([0.0, 0.4]))
+            reg = float(rng.choice([0.0, 1e-3]))
+            A, X, Y = synth.small_graph(N, 3.0, V, 5, C, seed=seed, empty_rows=int(rng.randint(0, 2)))
+            params = O.random_params(V, hid, C, highway, seed=seed + 1, scale=0.5)
+            perm = rng.permutation(N)
+            n_tr = max(1, N // 2)
+            tr, dv = np.sort(perm[:n_tr]).astype(np.int32), np.sort(perm[n_tr:n_tr + max(1, N // 4)]).astype(np.int32)
+            if len(dv) == 0:
+                dv = tr[:1].copy()
+            mask = (rng.rand(N, hid[0]) < (1 - p)).astype(np.uint8) if p > 0 else np.ones((N, hid[0]), np.uint8)
+            cfg = dict(N=N, V=V, C=C, hid=hid, highway=highway, p=p, reg=reg)
+            comm = TorchDistComm(N, torch.device('cpu'), exchange=exchange)
+            comm.prepare(A)
+            clf = make_clf(cfg, [q_.copy() for q_ in params], device=torch.device('cpu'), comm=comm)
+            clf.inject_dropout_mask(mask)
+            st = O.AdamState(params)
+            cur = [q_.copy() for q_ in params]
+            for step in range(2):
+                new, outs, grads = O.f_train(cur, st, X, Y[tr], Y[dv], A, tr, dv, hid, highway, p, mask.astype(np.float32), reg)
+                o = clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
+                P = clf.gather_output(o[4])
+                what = (exchange, world, seed, cfg, step)
+                assert np.allclose([float(v) for v in o[:4]], outs[:4], rtol=2e-5, atol=2e-6), (what, o[:4], outs[:4])
+                assert np.allclose(P, outs[4], rtol=2e-4, atol=2e-6), what
+                for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+                    assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (what, i)
+                for i, (a, b) in enumerate(zip(L.get_all_param_values(clf.l_out), new)):
+                    assert np.allclose(a, b, rtol=1e-4, atol=5e-5), (what, 'param', i)
+                cur = new
+    except BaseException as e:          # noqa: BLE001 -- reported to the parent, which fails the test
+        import traceback
+        err = traceback.format_exc()[-3000:]
+        raise
+    finally:
+        if rank == 0:
+            q.put(err or 'ok')
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 3), ("a2a", 4)])
+def test_multi_rank_gloo_random_models(exchange, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_random_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = q.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert res == 'ok', res
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
