@@ -380,3 +380,64 @@ def test_elementwise_random(dev, seed):
         back.t.fill_(3.0)
         ops.unpack_panels(buf, R, W, wp, back)
         assert np.array_equal(back.numpy(), G) and torch.all(back.t[:, F:] == 0), ('unpack', seed, case)
+
+
+@pytest.mark.parametrize("variant", ["reorder-degree", "reorder-lpa", "reorder-rcm", "reorder-bfs", "hip_graph", "bf16x3", "bf16"])
+@pytest.mark.parametrize("seed", range(3))
+def test_training_step_random_models_variants(dev, seed, variant):
+    """The same random models through the optional paths: node reorderings (invisible to the caller: indices, labels and
+    outputs stay in ORIGINAL node order), the captured-and-replayed step, the reduced-precision GEMMs."""
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    from geographconv_amd import synth
+    from oracle import gcn_oracle as O
+    rng = np.random.RandomState(7500 + seed)
+    N = int(rng.choice([40, 150, 333]))
+    V = int(rng.choice([11, 40, 97]))
+    C = int(rng.choice([3, 7, 33]))
+    highway = bool(rng.randint(2))
+    depth = int(rng.choice([1, 2, 3]))
+    w = int(rng.choice([9, 16, 37]))
+    hid = [w] * depth if highway else [int(rng.choice([9, 16, 37])) for _ in range(depth)]
+    graphed = variant == 'hip_graph'
+    p = 0.0 if graphed else float(rng.choice([0.0, 0.5]))      # (a captured step draws its own Philox mask: compare at p = 0)
+    A, X, Y = synth.small_graph(N, 4.0, V, 6, C, seed=seed + 50, empty_rows=1)
+    params = O.random_params(V, hid, C, highway, seed=seed + 51, scale=0.5)
+    perm = rng.permutation(N)
+    tr = np.sort(perm[:N // 2]).astype(np.int32)
+    dv = np.sort(perm[N // 2:N // 2 + N // 5]).astype(np.int32)
+    mask = (rng.rand(N, hid[0]) < (1 - p)).astype(np.uint8) if p > 0 else np.ones((N, hid[0]), np.uint8)
+    kw = {}
+    if variant.startswith('reorder-'):
+        kw['reorder'] = variant.split('-')[1]
+    if variant in ('bf16x3', 'bf16'):
+        kw['gemm_precision'] = variant
+    clf = GraphConv(V, C, hid, 0.0, p, highway=highway, device=dev, hip_graph=graphed, **kw)
+    clf.build_model(A if 'reorder' in kw else None, seed=77)
+    L.set_all_param_values(clf.l_out, [q.copy() for q in params])
+    if p > 0:
+        clf.inject_dropout_mask(mask)
+    st = O.AdamState(params)
+    cur = [q.copy() for q in params]
+    loose = variant == 'bf16'
+    n_steps = 4 if graphed else 2                             # (two eager steps, the capture, one replay)
+    for step in range(n_steps):
+        new, outs, grads = O.f_train(cur, st, X, Y[tr], Y[dv], A, tr, dv, hid, highway, p, mask.astype(np.float32), 0.0)
+        o = clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
+        what = (variant, seed, dict(N=N, V=V, C=C, hid=hid, highway=highway, p=p), step)
+        P = np.asarray(o[4])
+        if loose:
+            assert np.allclose([float(v) for v in o[:4]], outs[:4], rtol=3e-2, atol=3e-2), (what, o[:4], outs[:4])
+            assert np.allclose(P, outs[4], rtol=5e-2, atol=2e-2), what
+        else:
+            assert np.allclose([float(v) for v in o[:4]], outs[:4], rtol=5e-5, atol=5e-6), (what, o[:4], outs[:4])
+            assert np.allclose(P, outs[4], rtol=3e-4, atol=3e-6), what
+            for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+                assert np.allclose(g, r, rtol=1e-3, atol=1e-6 + 4e-5 * np.abs(r).max()), (what, i, np.abs(g - r).max())
+        # keep the two trajectories together: continue the restatement from the device's parameters
+        cur = [q.copy() for q in L.get_all_param_values(clf.l_out)]
+        if not loose:
+            for i, (a, b) in enumerate(zip(cur, new)):
+                assert np.allclose(a, b, rtol=2e-4, atol=1e-4), (what, 'param', i, np.abs(a - b).max())
+        else:
+            break                                              # (bf16: one step; Adam would amplify the operand rounding)
