@@ -14,14 +14,15 @@ from geographconv_amd import ops  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 440000
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+LD = int(sys.argv[4]) if len(sys.argv) > 4 else None      # pitch of the streamed operands (default: roundup4(F))
 dev = torch.device('cuda:0')
 rng = np.random.RandomState(1)
-H = ops.DMat.empty(N, F, dev); H.t.normal_()
-G = ops.DMat.empty(N, F, dev); G.t.normal_()
+H = ops.DMat.empty(N, F, dev, ld=LD); H.t.zero_(); H.t[:, :F].normal_()
+G = ops.DMat.empty(N, F, dev, ld=LD); G.t.zero_(); G.t[:, :F].normal_()
 W = ops.DMat.from_numpy((rng.randn(F, F) * 0.05).astype(np.float32), dev)
 b = torch.zeros(F, device=dev)
 Zb = ops.HMat(N, F, dev)
-T = ops.DMat.empty(N, F, dev)
+T = ops.DMat.empty(N, F, dev, ld=LD)
 dW = ops.DMat.empty(F, F, dev)
 
 
