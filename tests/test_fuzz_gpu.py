@@ -7,9 +7,18 @@ import numpy as np
 import pytest
 import scipy.sparse as sps
 
+import os
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
+
+# GEOGCN_FUZZ_SCALE=10 multiplies the number of seeds of every sweep (a longer soak; the default runs in ~10 s)
+_SCALE = max(1, int(os.environ.get('GEOGCN_FUZZ_SCALE', '1')))
+
+
+def _seeds(n):
+    return range(n * _SCALE)
 
 
 @pytest.fixture(scope="module")
@@ -60,7 +69,7 @@ def _close(got, ref, mag, what, slack=4e-6):
     assert np.all(err <= bound), (what, float(err.max()), float((err - bound).max()))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_gemm_random_shapes(dev, seed):
     """geogcn_gemm_f32 in all four layouts that the path uses, with bias / activation / accumulate."""
     from geographconv_amd import ops
@@ -93,7 +102,7 @@ def test_gemm_random_shapes(dev, seed):
         assert torch.all(got.t[:, N:ops.pad4(N)] == 0), ('pad columns', seed, case)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_gemm_dual_and_kcat_random_shapes(dev, seed):
     """The highway block's fused launches: two weights on one input (plain and transposed input), two products into one
     accumulator."""
@@ -128,7 +137,7 @@ def test_gemm_dual_and_kcat_random_shapes(dev, seed):
         _close(got.numpy(), ref, mag, ('kcat', seed, case, acc))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_spmm_random_structures(dev, seed):
     """geogcn_spmm_csr_f32 / _acc_f32 / _highway_f32 on random structures: empty rows, empty matrices, rows around the
     long-row threshold (forced low so that the chunked path runs), random widths and pitches."""
@@ -175,7 +184,7 @@ def test_spmm_random_structures(dev, seed):
             _close(hout.numpy(), T * ref_hc + (1.0 - T) * Hm, mag + np.abs(Hm), ('highway out', seed, case))
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_bow_products_random(dev, seed, monkeypatch):
     """X . W0 with the hot rows of W0 in LDS and X^T . G through the document-blocked kernel, random bag-of-words
     structures (Zipfian columns), against fp64."""
@@ -204,7 +213,7 @@ def test_bow_products_random(dev, seed, monkeypatch):
                ('X^T.G', seed, case, n_docs, n_words, F))
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", _seeds(3))
 def test_softmax_ce_random(dev, seed):
     """Row softmax + argmax, cross-entropy sums / hit counts on random index sets (with repeats), CE gradient."""
     from geographconv_amd import ops
@@ -224,7 +233,7 @@ def test_softmax_ce_random(dev, seed):
         assert np.array_equal(am.cpu().numpy()[clear], ref.argmax(axis=1)[clear]), ('argmax', seed, case)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", _seeds(3))
 def test_gemm_panel_output_and_reduced_precisions_random(dev, seed):
     """The product written as feature panels (send layout of the multi-GPU repartition), fp32 and bf16 panels; and the
     bf16 / bf16x3 arithmetic against fp64 with their own envelopes (bf16: 2^-8 per operand; bf16x3: fp32 class)."""
@@ -265,7 +274,7 @@ def test_gemm_panel_output_and_reduced_precisions_random(dev, seed):
             assert np.all(np.abs(got.numpy() - a64.T @ G) <= 2.0 ** -7 * (np.abs(a64.T) @ np.abs(G)) + 1e-6), ('bf16 tn', seed, case)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24))
 def test_training_step_random_models(dev, seed):
     """Whole f_train steps of randomly shaped models (odd widths, highway on / off, dropout with an injected mask,
     L1+L2, index sets with gaps, graphs with empty rows) against the CPU restatement: losses, hit counts, probabilities,
@@ -318,7 +327,7 @@ def test_training_step_random_models(dev, seed):
     assert np.array_equal(gp[clear], pred[clear]), what
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_elementwise_random(dev, seed):
     """Highway mix and its backward (with and without the fused column sums), activation backward (+ column sums,
     + dropout mask), dropout apply, column sums, pack / unpack of feature panels -- random sizes and pitches."""
@@ -383,7 +392,7 @@ def test_elementwise_random(dev, seed):
 
 
 @pytest.mark.parametrize("variant", ["reorder-degree", "reorder-lpa", "reorder-rcm", "reorder-bfs", "hip_graph", "bf16x3", "bf16"])
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", _seeds(3))
 def test_training_step_random_models_variants(dev, seed, variant):
     """The same random models through the optional paths: node reorderings (invisible to the caller: indices, labels and
     outputs stay in ORIGINAL node order), the captured-and-replayed step, the reduced-precision GEMMs."""
