@@ -184,7 +184,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--shape', default='twus', choices=['twus', 'cmu', 'twus_sbm'])
-    ap.add_argument('--reorder', default=None, choices=['degree', 'rcm', 'bfs', 'lpa'],
+    ap.add_argument('--reorder', default=None, choices=['degree', 'rcm', 'bfs', 'lpa', 'auto'],
                     help='node renumbering applied on the device side (outputs stay in original ids)')
     ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
     ap.add_argument('--dropout', type=float, default=0.5)

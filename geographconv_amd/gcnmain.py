@@ -200,7 +200,7 @@ def main(data, args, **kwargs):
     clf = GraphConv(input_size=ds.input_size, output_size=ds.output_size, hid_size_list=kwargs.get('hidden', [100]),
                     regul_coef=kwargs.get('regularization', 1e-6), drop_out=kwargs.get('dropout', 0.0),
                     batchnorm=args.batchnorm, highway=model_args.highway, device=device, comm=comm,
-                    gemm_precision=getattr(args, 'gemm_precision', None))
+                    gemm_precision=getattr(args, 'gemm_precision', None), reorder=getattr(args, 'reorder', None))
     clf.build_model(ds.A, use_text=args.notxt, use_labels=args.lp, seed=model_args.seed)
     results, train_indices = [], None
     for fraction in args.lblfraction:
@@ -291,6 +291,9 @@ def parse_args(argv):
     parser.add_argument('--synthetic', choices=['cmu', 'twus'], default=None, help='use the pinned synthetic graph instead of dump.pkl')
     parser.add_argument('--gemm-precision', choices=['f32', 'bf16x3', 'bf16'], default=None,
                         help="how H.W products are formed: f32 = exact fp32 MFMA (default), bf16x3 = 3-term bf16 split, bf16 = BASELINE config 5")
+    parser.add_argument('--reorder', choices=['auto', 'lpa', 'rcm', 'bfs', 'degree'], default=None,
+                        help="renumber the nodes on the device side (results stay in original node order); auto = label "
+                             "propagation when it makes the graph product's gathers local, else nothing")
     parser.add_argument('--epochs', type=int, default=10000, help='max epochs (reference hard-codes 10000, gcnmain.py:221)')
     return parser.parse_args(argv)
 

@@ -509,8 +509,9 @@ class GraphConv():
         ro = None
         if self.reorder is not None and sps.issparse(A) and A.shape[0] == A.shape[1] == N:
             from . import graph as _graph
-            ro = _graph.reordering(A, self.reorder)
-            A, X = ro.matrix(A), sps.csr_matrix(X)[ro.perm]
+            ro = _graph.reordering(A, self.reorder)         # ('auto' may decide against: None)
+            if ro is not None:
+                A, X = ro.matrix(A), sps.csr_matrix(X)[ro.perm]
         if self._dist(comm):
             comm.prepare(A)               # (all-gather scheme: cost-balanced row split, cut from this adjacency)
         part = comm.part

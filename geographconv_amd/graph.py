@@ -23,7 +23,7 @@ from scipy.sparse import csgraph
 
 from .synth import normalize_adjacency
 
-REORDERINGS = (None, 'none', 'degree', 'rcm', 'bfs', 'lpa')
+REORDERINGS = (None, 'none', 'degree', 'rcm', 'bfs', 'lpa', 'auto')
 
 
 def adjacency_from_edges(edges, N: int) -> sps.csr_matrix:
@@ -104,9 +104,17 @@ def reordering(A: sps.spmatrix, method) -> Reordering | None:
       'degree'  decreasing stored-edge count (hubs first; a locality-free baseline that only groups the hot rows),
       'rcm'     reverse Cuthill-McKee (bandwidth reduction: neighbours end up close in index),
       'bfs'     breadth-first order, components in order of their highest-degree node,
-      'lpa'     communities found by label propagation, largest first, hubs first inside each."""
+      'lpa'     communities found by label propagation, largest first, hubs first inside each,
+      'auto'    'lpa' if that at least doubles the share of edges inside an L2 window of their row (to >= 30 %), else none."""
     if method in (None, 'none'):
         return None
+    if method == 'auto':
+        # label propagation, kept only when it pays: the share of edges inside one L2 window of their row must at least
+        # double and reach 30 % (a graph without communities -- the pinned power-law generator -- stays as it is)
+        before = locality_profile(A)['within_window']
+        ro = reordering(A, 'lpa')
+        after = locality_profile(ro.matrix(A))['within_window']
+        return ro if after >= max(0.3, 2.0 * before) else None
     A = sps.csr_matrix(A)
     N = A.shape[0]
     deg = np.diff(A.indptr)

@@ -391,7 +391,7 @@ def test_elementwise_random(dev, seed):
         assert np.array_equal(back.numpy(), G) and torch.all(back.t[:, F:] == 0), ('unpack', seed, case)
 
 
-@pytest.mark.parametrize("variant", ["reorder-degree", "reorder-lpa", "reorder-rcm", "reorder-bfs", "hip_graph", "bf16x3", "bf16"])
+@pytest.mark.parametrize("variant", ["reorder-degree", "reorder-lpa", "reorder-rcm", "reorder-bfs", "reorder-auto", "hip_graph", "bf16x3", "bf16"])
 @pytest.mark.parametrize("seed", _seeds(3))
 def test_training_step_random_models_variants(dev, seed, variant):
     """The same random models through the optional paths: node reorderings (invisible to the caller: indices, labels and

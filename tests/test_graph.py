@@ -65,3 +65,15 @@ def test_label_propagation_recovers_planted_communities_and_reordering_makes_the
     assert before < 0.25 and after > 0.8, (before, after)
     # bfs / rcm on a small-world graph do not (documented negative result)
     assert graph.locality_profile(graph.reordering(base, 'rcm').matrix(base), window_rows=600)['within_window'] < after
+
+
+def test_auto_reordering_adopts_label_propagation_only_when_it_pays():
+    """'auto' = label propagation if it at least doubles the share of edges inside an L2 window (to >= 30 %), else nothing:
+    a community graph with shuffled ids gets reordered, the structure-free power-law generator does not."""
+    from geographconv_amd import graph, synth
+    A = synth.community_ahat(40000, 600000, 20, seed=3)
+    ro = graph.reordering(A, 'auto')
+    assert ro is not None
+    assert graph.locality_profile(ro.matrix(A))['within_window'] >= 2 * graph.locality_profile(A)['within_window']
+    B = synth.powerlaw_ahat(40000, 600000, seed=3)
+    assert graph.reordering(B, 'auto') is None
