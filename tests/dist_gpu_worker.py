@@ -13,12 +13,63 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+class StagedGloo:
+    """torch.distributed look-alike for ONE-GPU boxes: several ranks share cuda:0 (RCCL refuses that), the collectives go
+    through host copies and the gloo backend.  Slow and synchronous -- it exists so that the REAL kernels can be run under
+    a REAL multi-rank partition (panels, narrow SpMM, slot layout, bf16 wire) where no second GPU is available."""
+    ReduceOp = dist.ReduceOp
+
+    @staticmethod
+    def _bytes(t):
+        return t.detach().contiguous().view(-1).view(torch.uint8).cpu()
+
+    def _gather_bytes(self, t):
+        ci = self._bytes(t)
+        parts = [torch.empty_like(ci) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, ci)
+        return parts
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        t.copy_(c)
+        return _Done()
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        parts = self._gather_bytes(inp)
+        out.view(-1).view(torch.uint8).copy_(torch.cat(parts))
+        return _Done()
+
+    def all_to_all_single(self, out, inp, group=None, async_op=False):
+        # (gloo's own all-to-all rejects some dtypes: every rank gathers every send buffer and keeps its own panel of each)
+        w, r = dist.get_world_size(), dist.get_rank()
+        parts = self._gather_bytes(inp)
+        n = parts[0].numel() // w
+        out.view(-1).view(torch.uint8).copy_(torch.cat([p[r * n:(r + 1) * n] for p in parts]))
+        return _Done()
+
+
 def main():
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    staged = os.environ.get('GEOGCN_TEST_STAGED_GLOO') == '1'
+    local = 0 if staged else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    dist.init_process_group('nccl', device_id=device)
-    from geographconv_amd.dist import TorchDistComm
+    if staged:
+        dist.init_process_group('gloo')
+    else:
+        dist.init_process_group('nccl', device_id=device)
+    from geographconv_amd.dist import TorchDistComm as _TorchDistComm
+
+    def TorchDistComm(N, dev, exchange=None):
+        comm = _TorchDistComm(N, dev, exchange=exchange)
+        if staged:
+            comm.dist = StagedGloo()
+        return comm
     from geographconv_amd.nn import layers as L
     from tests.helpers import load_case, make_clf
     for name, exchange in [('tiny_highway', 'a2a'), ('tiny_plain_reg', 'a2a'), ('tiny_odd_widths', 'a2a'),
@@ -79,6 +130,36 @@ def main():
             assert np.allclose(got[1], ref[1], rtol=2e-2, atol=2e-3)
             for g, r in zip(got[2], ref[2]):
                 assert np.allclose(g, r, rtol=5e-2, atol=5e-3 * np.abs(r).max() + 1e-7)
+    # a mid-size model (rows, widths and classes that do not divide by the world size; hub rows -> chunked long rows in
+    # every rank's block): partitioned vs the same process's one-GPU run
+    from geographconv_amd import synth as _synth
+    from oracle import gcn_oracle as O
+    A_, X_, Y_ = _synth.small_graph(5003, 9.0, 700, 12, 11, seed=5, empty_rows=3)
+    hid, C_ = [52, 52], 11
+    params = O.random_params(700, hid, C_, True, seed=6, scale=0.3)
+    rng = np.random.RandomState(7)
+    perm = rng.permutation(5003)
+    tr_, dv_ = np.sort(perm[:2500]).astype(np.int32), np.sort(perm[2500:3500]).astype(np.int32)
+    mask_ = (rng.rand(5003, 52) < 0.5).astype(np.uint8)
+    ref = None
+    for exchange in (None, 'a2a', 'allgather'):
+        comm = None if exchange is None else TorchDistComm(5003, device, exchange=exchange)
+        clf = GraphConv(700, C_, hid, 0.0, 0.5, highway=True, device=device, comm=comm)
+        clf.build_model(None, seed=77)
+        L.set_all_param_values(clf.l_out, [q.copy() for q in params])
+        clf.inject_dropout_mask(mask_)
+        res = []
+        for step in range(2):
+            o = clf.f_train(X_, Y_[tr_], Y_[dv_], A_, tr_, dv_)
+            res.append(([float(v) for v in o[:4]], clf.gather_output(o[4]), clf.get_grads()))
+        if ref is None:
+            ref = res
+            continue
+        for step, (got, want) in enumerate(zip(res, ref)):
+            assert np.allclose(got[0], want[0], rtol=2e-5, atol=2e-6), (exchange, step, got[0], want[0])
+            assert np.allclose(got[1], want[1], rtol=2e-4, atol=2e-6), (exchange, step)
+            for i, (g, r) in enumerate(zip(got[2], want[2])):
+                assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (exchange, step, i)
     if dist.get_rank() == 0:
         print('DIST_GPU_OK world=%d backend=%s' % (dist.get_world_size(), type(comm.dist).__name__))
     dist.destroy_process_group()

@@ -73,3 +73,18 @@ def test_comm_entry_points_world1():
     assert lib.geogcn_comm_alltoall(c._h, C.c_void_p(send.data_ptr()), C.c_void_p(send.data_ptr()), 16, None) == -1   # aliased
     assert lib.geogcn_comm_allreduce_sum_f32(None, C.c_void_p(x.data_ptr()), 4, None) == -1
     c.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_real_kernels_under_a_real_partition_on_one_gpu(world):
+    """The combination no 1-GPU box can otherwise reach: the HIP kernels AND a multi-rank partition.  `world` processes
+    share cuda:0; the collectives are staged through the host and gloo (tests/dist_gpu_worker.py StagedGloo).  Same
+    assertions as the RCCL worker: golden vectors through both exchange schemes, the partitioned graph product bitwise equal
+    to the one-GPU kernel on the same rows, the bf16 configuration through both schemes."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GEOGCN_TEST_STAGED_GLOO='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(29521 + world), os.path.join(root, 'tests', 'dist_gpu_worker.py')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'DIST_GPU_OK world=%d' % world in r.stdout
