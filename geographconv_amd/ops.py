@@ -176,6 +176,30 @@ def cast_bf16(X: DMat, out: HMat = None):
     return out
 
 
+# Plans own device memory (hipFree in their destroy call).  A destructor may run at ANY time -- also while a training step
+# is being captured into a hipGraph, where a free invalidates the capture ("operation failed due to a previous error
+# during capture"; found by the random sweeps: an earlier model's CSR collected in the middle of a later model's
+# capture).  So handles released during a capture are parked and destroyed at the next opportunity.
+_parked = []
+
+
+def _capturing():
+    try:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:
+        return False
+
+
+def _release(destroy, handle):
+    if _capturing():
+        _parked.append((destroy, handle))
+        return
+    while _parked:
+        d, h = _parked.pop()
+        d(h)
+    destroy(handle)
+
+
 class Workspace:
     """Grow-only scratch buffer (split-K slabs, long-row partials, reduction partials)."""
 
@@ -257,7 +281,7 @@ class CSR:
     def __del__(self):
         try:
             if self._plan:
-                _ffi.lib().geogcn_spmm_plan_destroy(self._plan)
+                _release(_ffi.lib().geogcn_spmm_plan_destroy, self._plan)
                 self._plan = C.c_void_p(0)
         except Exception:
             pass
@@ -696,7 +720,7 @@ class XtPlan:
     def __del__(self):
         try:
             if self._h:
-                _ffi.lib().geogcn_xt_plan_destroy(self._h)
+                _release(_ffi.lib().geogcn_xt_plan_destroy, self._h)
                 self._h = C.c_void_p(0)
         except Exception:
             pass

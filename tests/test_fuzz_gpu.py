@@ -450,3 +450,8 @@ def test_training_step_random_models_variants(dev, seed, variant):
                 assert np.allclose(a, b, rtol=2e-4, atol=1e-4), (what, 'param', i, np.abs(a - b).max())
         else:
             break                                              # (bf16: one step; Adam would amplify the operand rounding)
+    if graphed:
+        # a captured step keeps a private memory pool alive: drop the model before the next case builds its own
+        import gc
+        del clf
+        gc.collect()
