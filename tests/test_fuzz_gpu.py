@@ -455,3 +455,84 @@ def test_training_step_random_models_variants(dev, seed, variant):
         import gc
         del clf
         gc.collect()
+
+
+@pytest.mark.parametrize("seed", _seeds(4))
+def test_loss_indexing_and_optimizer_random(dev, seed):
+    """Cross-entropy sums / hit counts and the CE gradient on random index sets WITH repeats and gaps (Theano's
+    AdvancedSubtensor1 / AdvancedIncSubtensor1 semantics, gcnmodel.py:376-382), row gather / scatter, the Lasagne Adam
+    update with L1 + L2 (gcnmodel.py:383-387,407; host and device-resident step counter), the penalty value."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(9500 + seed)
+    for case in range(6):
+        N = int(rng.choice([1, 7, 300, 5000]))
+        C = int(rng.choice([2, 5, 129, 256]))
+        n_idx = int(rng.choice([0, 1, 5, 400, 7000]))
+        L = (rng.randn(N, C) * 2).astype(np.float32)
+        e = np.exp(L.astype(np.float64) - L.max(axis=1, keepdims=True))
+        P64 = e / e.sum(axis=1, keepdims=True)
+        dP = _dmat(ops, dev, P64.astype(np.float32), rng)
+        P = dP.numpy().astype(np.float64)
+        idx = rng.randint(0, N, size=n_idx).astype(np.int32)                   # repeats on purpose
+        y = rng.randint(0, C, size=n_idx).astype(np.int32)
+        ti, ty = torch.from_numpy(idx).to(dev), torch.from_numpy(y).to(dev)
+        am = torch.from_numpy(P.argmax(axis=1).astype(np.int32)).to(dev)
+        for a in (None, am):
+            got = ops.ce_metrics(dP, ti, ty, argmax=a).cpu().numpy()
+            ref_loss = float(-np.log(P[idx, y]).sum()) if n_idx else 0.0
+            ref_hits = float((P.argmax(axis=1)[idx] == y).sum()) if n_idx else 0.0
+            assert abs(got[0] - ref_loss) <= 3e-6 * max(1.0, float(np.abs(np.log(P[idx, y])).sum()) if n_idx else 1.0), ('ce loss', seed, case)
+            assert got[1] == ref_hits, ('hits', seed, case)
+        inv_n = 1.0 / max(1, n_idx)
+        ref = np.zeros((N, C))
+        np.add.at(ref, idx, (P[idx] - np.eye(C)[y]) * inv_n)
+        mag = np.zeros((N, C))
+        np.add.at(mag, idx, np.abs(P[idx] - np.eye(C)[y]) * inv_n)
+        reps = np.bincount(idx, minlength=N).astype(np.float64)
+        db = torch.full((ops.pad4(C),), 3.0, device=dev)
+        for with_db in (False, True):
+            out = ops.DMat.empty(N, C, dev, ld=ops.gather_ld(C))
+            out.t.fill_(7.0)
+            got = ops.softmax_ce_bwd(dP, ti, ty, out=out, inv_n=inv_n, **({'db': db} if with_db and C <= 1024 else {}))
+            # fp32 accumulation of k repeats of a row: error <= k * eps * (sum of the magnitudes added), as for Theano's
+            # AdvancedIncSubtensor1 in fp32
+            assert np.all(np.abs(got.numpy() - ref) <= (1.2e-7 * reps[:, None] + 1e-6) * mag + 1e-9), ('ce bwd', seed, case, with_db, N, C, n_idx)
+            if with_db:
+                assert np.all(np.abs(db.cpu().numpy()[:C] - ref.sum(axis=0)) <= 1e-5 * mag.sum(axis=0) + 2e-6), ('ce db', seed, case)
+        if n_idx:
+            g = ops.gather_rows(dP, ti)
+            assert np.array_equal(g.cpu().numpy(), dP.numpy()[idx])
+            uniq = np.unique(idx).astype(np.int32)
+            src = _dmat(ops, dev, rng.randn(len(uniq), C).astype(np.float32), rng)
+            dst = ops.DMat(N, C, dev)
+            ops.scatter_rows(src, torch.from_numpy(uniq).to(dev), dst)
+            full = np.zeros((N, C), np.float32)
+            full[uniq] = src.numpy()
+            assert np.array_equal(dst.numpy(), full)
+        # Adam (lasagne.updates.adam) with the L1 + L2 penalty gradient on the regularisable part
+        n = int(rng.choice([1, 33, 4096, 100003]))
+        p0, g0 = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+        m0, v0 = (rng.randn(n) * 0.1).astype(np.float32), (rng.rand(n) * 0.1).astype(np.float32)
+        mask = (rng.rand(n) < 0.7).astype(np.float32)
+        l1, l2 = float(rng.choice([0.0, 1e-3])), float(rng.choice([0.0, 1e-2]))
+        t = int(rng.randint(1, 50))
+        lr, b1, b2, eps = 2e-3, 0.9, 0.999, 1e-8
+        gg = g0.astype(np.float64) + mask * (l1 * np.sign(p0) + 2 * l2 * p0)
+        m1 = b1 * m0 + (1 - b1) * gg
+        v1 = b2 * v0 + (1 - b2) * gg * gg
+        a_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        p1 = p0 - a_t * m1 / (np.sqrt(v1) + eps)
+        for ctr in (False, True):
+            tp, tg, tm, tv, tk = (torch.from_numpy(a.copy()).to(dev) for a in (p0, g0, m0, v0, mask))
+            if ctr:
+                state = torch.tensor([t - 1, 0], dtype=torch.int64, device=dev)
+                ops.adam_step_ctr(tp, tg, tm, tv, tk, lr, b1, b2, eps, state, l1=l1, l2=l2)
+                assert int(state[0].item()) == t
+            else:
+                ops.adam_step(tp, tg, tm, tv, tk, lr, b1, b2, eps, t, l1=l1, l2=l2)
+            assert np.allclose(tp.cpu().numpy(), p1, rtol=2e-5, atol=2e-7), ('adam p', seed, case, ctr)
+            assert np.allclose(tm.cpu().numpy(), m1, rtol=1e-5, atol=1e-7), ('adam m', seed, case, ctr)
+            assert np.allclose(tv.cpu().numpy(), v1, rtol=1e-5, atol=1e-7), ('adam v', seed, case, ctr)
+        pen = ops.reg_penalty(torch.from_numpy(p0).to(dev), torch.from_numpy(mask).to(dev), l1, l2).cpu().numpy()[0]
+        ref_pen = float((mask * (l1 * np.abs(p0) + l2 * p0.astype(np.float64) ** 2)).sum())
+        assert abs(pen - ref_pen) <= 2e-5 * max(1.0, abs(ref_pen)), ('penalty', seed, case)
