@@ -168,6 +168,14 @@ def test_spmm_random_structures(dev, seed):
         out = _dmat(ops, dev, C0, rng, pad=False)
         got = ops.spmm(dA, dB, out=out, bias=bt, act=act, accumulate=True)
         _close(got.numpy(), _act(pre + C0, act), mag + np.abs(C0), ('spmm acc', seed, case))
+        # bf16 gathered operand (the bf16 configuration): exact product with the ROUNDED operand, fp32 accumulation
+        Bq = torch.from_numpy(B).to(torch.bfloat16).float().numpy()
+        hB = ops.cast_bf16(dB)
+        assert np.array_equal(hB.numpy(), Bq), ('cast_bf16', seed, case)
+        pre_q = np.asarray(a64 @ Bq.astype(np.float64)) + (bias if bias is not None else 0.0)
+        mag_q = np.asarray(abs(a64) @ np.abs(Bq).astype(np.float64)) + (np.abs(bias) if bias is not None else 0.0)
+        got = ops.spmm(dA, hB, bias=bt, act=act)
+        _close(got.numpy(), _act(pre_q, act), mag_q, ('spmm bf16 operand', seed, case, n_rows, n_cols, F))
         # highway epilogue: Hout = T * tanh(A . B + b) + (1 - T) * H
         if F % 4 == 0 or True:
             T = rng.rand(n_rows, F).astype(np.float32)
