@@ -691,7 +691,9 @@ int geogcn_pack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* X,
     GEOGCN_REQUIRE(n_rows >= 0 && R >= n_rows && F > 0 && W > 0 && wp > 0, GEOGCN_E_SIZE, "pack_panels_f32: bad sizes");
     GEOGCN_REQUIRE(wp % 4 == 0 && (int64_t)W * wp >= F && ldx % 4 == 0 && ldx >= (int64_t)((F + 3) / 4) * 4, GEOGCN_E_ALIGN,
                    "pack_panels_f32: need wp %% 4 == 0, W*wp >= F, ldx %% 4 == 0");
-    GEOGCN_REQUIRE(X && out && aligned16(X) && aligned16(out), GEOGCN_E_NULL, "pack_panels_f32: null/misaligned pointer");
+    if (R == 0) return 0;
+    // (a rank that owns no rows still zero-fills its R padded panel rows; its X is an empty matrix whose pointer may be null)
+    GEOGCN_REQUIRE((X || n_rows == 0) && out && aligned16(X) && aligned16(out), GEOGCN_E_NULL, "pack_panels_f32: null/misaligned pointer");
     const int64_t total = (int64_t)W * R * (wp / 4);
     hipLaunchKernelGGL(pack_panels_kernel, dim3(stream_grid(total)), dim3(TPB), 0, (hipStream_t)stream, n_rows, R, (F + 3) / 4,
                        X, ldx, W, wp / 4, (float4*)out);

@@ -342,7 +342,12 @@ int geogcn_softmax_ce_bwd_db_f32(int64_t n, int32_t C, const float* probs, int64
                                  int64_t n_idx, const int32_t* y, float inv_n, float* dlogits, int64_t ldd, float* db,
                                  void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && C >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "softmax_ce_bwd_db_f32: negative size");
-    if (n == 0 || C == 0) return 0;
+    if (C == 0) return 0;
+    if (n == 0) {
+        // a rank that owns no rows: its share of the bias gradient is the zero vector, not last step's (already
+        // all-reduced) value -- found by the random models on 4 and 8 ranks with 5 nodes
+        return db ? zero_fill_async(db, (size_t)((C + 3) / 4 * 4) * sizeof(float), (hipStream_t)stream) : 0;
+    }
     GEOGCN_REQUIRE(dlogits && db, GEOGCN_E_NULL, "softmax_ce_bwd_db_f32: null pointer");
     GEOGCN_REQUIRE(ldd >= C, GEOGCN_E_SIZE, "softmax_ce_bwd_db_f32: ldd < C");
     GEOGCN_REQUIRE(C <= 16 * kWave, GEOGCN_E_ARG, "softmax_ce_bwd_db_f32: C=%d > %d", C, 16 * kWave);

@@ -160,6 +160,46 @@ def main():
             assert np.allclose(got[1], want[1], rtol=2e-4, atol=2e-6), (exchange, step)
             for i, (g, r) in enumerate(zip(got[2], want[2])):
                 assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (exchange, step, i)
+    # random small models (sizes smaller than / not divisible by the world size, odd widths, tiny class counts) against
+    # the CPU restatement -- the same generator as tests/test_dist_cpu.py, here with the HIP kernels
+    for seed in range(int(os.environ.get('GEOGCN_TEST_DIST_SEEDS', '8'))):
+        rng = np.random.RandomState(9000 + seed)
+        N = int(rng.choice([2, 5, 23, 64, 131]))
+        V = int(rng.choice([6, 19, 40]))
+        Cn = int(rng.choice([2, 5, 17]))
+        highway = bool(rng.randint(2))
+        depth = int(rng.choice([1, 2, 3]))
+        w = int(rng.choice([3, 8, 13]))
+        hid = [w] * depth if highway else [int(rng.choice([3, 8, 13])) for _ in range(depth)]
+        p = float(rng.choice([0.0, 0.4]))
+        reg = float(rng.choice([0.0, 1e-3]))
+        A_, X_, Y_ = _synth.small_graph(N, 3.0, V, 5, Cn, seed=seed, empty_rows=int(rng.randint(0, 2)))
+        params = O.random_params(V, hid, Cn, highway, seed=seed + 1, scale=0.5)
+        perm = rng.permutation(N)
+        n_tr = max(1, N // 2)
+        tr_, dv_ = np.sort(perm[:n_tr]).astype(np.int32), np.sort(perm[n_tr:n_tr + max(1, N // 4)]).astype(np.int32)
+        if len(dv_) == 0:
+            dv_ = tr_[:1].copy()
+        mask_ = (rng.rand(N, hid[0]) < (1 - p)).astype(np.uint8) if p > 0 else np.ones((N, hid[0]), np.uint8)
+        for exchange in ('a2a', 'allgather'):
+            comm = TorchDistComm(N, device, exchange=exchange)
+            comm.prepare(A_)
+            clf = GraphConv(V, Cn, hid, reg, p, highway=highway, device=device, comm=comm)
+            clf.build_model(None, seed=77)
+            L.set_all_param_values(clf.l_out, [q.copy() for q in params])
+            clf.inject_dropout_mask(mask_)
+            clf._force_dist = True
+            st = O.AdamState(params)
+            cur = [q.copy() for q in params]
+            for step in range(2):
+                new, outs, grads = O.f_train(cur, st, X_, Y_[tr_], Y_[dv_], A_, tr_, dv_, hid, highway, p, mask_.astype(np.float32), reg)
+                o = clf.f_train(X_, Y_[tr_], Y_[dv_], A_, tr_, dv_)
+                what = (exchange, seed, N, V, Cn, hid, highway, p, reg, step)
+                assert np.allclose([float(v) for v in o[:4]], outs[:4], rtol=2e-5, atol=2e-6), (what, o[:4], outs[:4])
+                assert np.allclose(clf.gather_output(o[4]), outs[4], rtol=2e-4, atol=2e-6), what
+                for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
+                    assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (what, i)
+                cur = new
     if dist.get_rank() == 0:
         print('DIST_GPU_OK world=%d backend=%s' % (dist.get_world_size(), type(comm.dist).__name__))
     dist.destroy_process_group()
