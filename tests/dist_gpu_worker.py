@@ -184,8 +184,10 @@ def main():
         for exchange in ('a2a', 'allgather'):
             comm = TorchDistComm(N, device, exchange=exchange)
             comm.prepare(A_)
-            clf = GraphConv(V, Cn, hid, reg, p, highway=highway, device=device, comm=comm)
-            clf.build_model(None, seed=77)
+            # (every third model also goes through a node reordering: invisible to the caller, partitioned or not)
+            ro_kw = {'reorder': ('degree', 'rcm', 'lpa')[(seed // 3) % 3]} if seed % 3 == 2 and N > 8 else {}
+            clf = GraphConv(V, Cn, hid, reg, p, highway=highway, device=device, comm=comm, **ro_kw)
+            clf.build_model(A_ if ro_kw else None, seed=77)
             L.set_all_param_values(clf.l_out, [q.copy() for q in params])
             clf.inject_dropout_mask(mask_)
             clf._force_dist = True
@@ -200,6 +202,28 @@ def main():
                 for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
                     assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (what, i)
                 cur = new
+        # the bf16 configuration (bf16 operand and wire) on the same model: partitioned vs this process's one-GPU bf16 run
+        if seed % 2 == 0:
+            ref = None
+            for exchange in (None, 'a2a', 'allgather'):
+                comm = None if exchange is None else TorchDistComm(N, device, exchange=exchange)
+                if comm is not None:
+                    comm.prepare(A_)
+                clf = GraphConv(V, Cn, hid, reg, p, highway=highway, device=device, comm=comm, gemm_precision='bf16')
+                clf.build_model(None, seed=77)
+                L.set_all_param_values(clf.l_out, [q.copy() for q in params])
+                clf.inject_dropout_mask(mask_)
+                clf._force_dist = comm is not None
+                o = clf.f_train(X_, Y_[tr_], Y_[dv_], A_, tr_, dv_)
+                got = ([float(v) for v in o[:4]], clf.gather_output(o[4]), clf.get_grads())
+                if ref is None:
+                    ref = got
+                    continue
+                what = ('bf16', exchange, seed, N, V, Cn, hid, highway, p)
+                assert np.allclose(got[0], ref[0], rtol=2e-3, atol=2e-4), (what, got[0], ref[0])
+                assert np.allclose(got[1], ref[1], rtol=2e-2, atol=2e-3), what
+                for i, (g, r) in enumerate(zip(got[2], ref[2])):
+                    assert np.allclose(g, r, rtol=5e-2, atol=5e-3 * np.abs(r).max() + 1e-6), (what, i)
     if dist.get_rank() == 0:
         print('DIST_GPU_OK world=%d backend=%s' % (dist.get_world_size(), type(comm.dist).__name__))
     dist.destroy_process_group()
