@@ -63,3 +63,32 @@ def test_no_product_import_of_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_every_entry_point_rejects_null_and_negative_arguments(built):
+    """Error behaviour at the boundary (include/geogcn.h conventions): with every pointer NULL and positive sizes, and
+    with negative sizes, every int-returning entry point answers < 0 with a message -- before any HIP call, so this runs
+    without a GPU -- and never crashes.  (geogcn_timer_attach_spmm(NULL) is the documented way to detach.)"""
+    import ctypes as C
+    lib = _ffi.lib()
+    skip = {'geogcn_version', 'geogcn_comm_available', 'geogcn_comm_world', 'geogcn_comm_rank', 'geogcn_spmm_hot_capacity',
+            'geogcn_timer_attach_spmm'}
+    checked = 0
+    for name, (res, args) in _ffi.SIGNATURES.items():
+        if res is not _ffi.c_i32 or name in skip:
+            continue
+        for mode in ('null', 'negative'):
+            vals = []
+            for t in args:
+                if t is _ffi.c_ptr or (isinstance(t, type) and issubclass(t, C._Pointer)):
+                    vals.append(None)
+                elif t in (_ffi.c_i32, _ffi.c_i64, _ffi.c_sz, _ffi.c_u64):
+                    vals.append(-3 if (mode == 'negative' and t is not _ffi.c_sz) else 8)
+                elif t is _ffi.c_f32:
+                    vals.append(0.5)
+                else:
+                    vals.append(None)
+            rc = getattr(lib, name)(*vals)
+            assert rc < 0 and lib.geogcn_last_error(), (name, mode, rc)
+            checked += 1
+    assert checked >= 80
