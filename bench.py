@@ -206,6 +206,11 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     ops.require_gpu()
+    # functional check of the N > 1 branches on a ONE-GPU box (never a measurement): all ranks share cuda:0 and the
+    # collectives are staged through the host and gloo, as tests/dist_gpu_worker.py does
+    staged = os.environ.get('GEOGCN_BENCH_STAGED_GLOO') == '1'
+    if staged:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     comm = None
@@ -216,7 +221,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
+        if staged:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     t0 = time.time()
     A, X, Y, (tr, dev, te), C = synth.make_graph(args.shape)
@@ -226,6 +234,9 @@ def main():
     if world > 1 or force_dist:
         from geographconv_amd.dist import TorchDistComm
         comm = TorchDistComm(N, device)
+        if staged:
+            from tests.dist_gpu_worker import StagedGloo
+            comm.dist = StagedGloo()
 
     clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm,
                     gemm_precision=args.gemm_precision, reorder=args.reorder)
@@ -267,7 +278,7 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     if world > 1:
-        tt = torch.tensor([t], dtype=torch.float64, device=device)
+        tt = torch.tensor([t], dtype=torch.float64, device='cpu' if staged else device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         t = float(tt.item())
     n_conv = len(args.hid)
@@ -296,7 +307,8 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> + spmm_long_reduce_kernel (A_hat^T . dS, F=%d%s)" % (
-                        (F + 63) // 64, F, "" if world == 1 else ", rank 0's feature panel of all rows"),
+                        (F + 63) // 64, F, "" if comm is None else (", rank 0's feature panel of all rows" if comm.exchange == 'a2a'
+                                                                    else ", rank 0's row block against the gathered operand")),
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": len(kern_ms),
@@ -326,7 +338,7 @@ def main():
                        "edges_per_step": n_conv * nnz,
                        "edges_traversed_per_step": 2 * (n_conv - 1) * nnz + nnz + nnz_bwd_out,
                        "parallelism": "rows%d" % world if world > 1 else "single",
-                       "world_size": world, "collectives": None if comm is None else "RCCL (torch.distributed nccl), exchange = %s" % comm.exchange,
+                       "world_size": world, "collectives": None if comm is None else ("%s, exchange = %s" % ("STAGED through the host + gloo (functional check, NOT a measurement)" if staged else "RCCL (torch.distributed nccl)", comm.exchange)),
                        "reorder": args.reorder,
                        "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
                                 "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
