@@ -206,25 +206,21 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     ops.require_gpu()
-    # functional check of the N > 1 branches on a ONE-GPU box (never a measurement): all ranks share cuda:0 and the
-    # collectives are staged through the host and gloo, as tests/dist_gpu_worker.py does
-    staged = os.environ.get('GEOGCN_BENCH_STAGED_GLOO') == '1'
-    if staged:
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    # GEOGCN_DIST_BACKEND=staged-gloo: functional check of the N > 1 branches on a ONE-GPU box (never a measurement): all
+    # ranks share cuda:0 and the collectives are staged through the host and gloo (geographconv_amd/dist.py)
+    from geographconv_amd import dist as gdist
+    staged = gdist.backend_name() == 'staged-gloo'
     comm = None
     force_dist = os.environ.get('GEOGCN_BENCH_FORCE_DIST') == '1'      # exercise the partitioned path at world 1
     if world > 1 or force_dist:
-        import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        if staged:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=device)
+        device = gdist.init_process_group(local)
+    else:
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
 
     t0 = time.time()
     A, X, Y, (tr, dev, te), C = synth.make_graph(args.shape)
@@ -234,9 +230,6 @@ def main():
     if world > 1 or force_dist:
         from geographconv_amd.dist import TorchDistComm
         comm = TorchDistComm(N, device)
-        if staged:
-            from tests.dist_gpu_worker import StagedGloo
-            comm.dist = StagedGloo()
 
     clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm,
                     gemm_precision=args.gemm_precision, reorder=args.reorder)

@@ -290,9 +290,76 @@ class NativeRccl:
             async_op, (out, inp))
 
 
+class HostStagedGloo:
+    """torch.distributed look-alike for ONE-GPU boxes (`GEOGCN_DIST_BACKEND=staged-gloo`): several ranks share cuda:0 --
+    RCCL refuses that -- and every collective goes through a host copy and the gloo backend.  Slow and synchronous; it
+    exists so that the REAL kernels can run under a REAL multi-rank partition (panels, narrow SpMM, slot layout, bf16 wire,
+    ranks without rows) where no second GPU is available: a functional check, never a measurement."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    @staticmethod
+    def _bytes(t):
+        return t.detach().contiguous().view(-1).view(torch.uint8).cpu()
+
+    def _gather_bytes(self, t):
+        ci = self._bytes(t)
+        parts = [torch.empty_like(ci) for _ in range(self._d.get_world_size())]
+        self._d.all_gather(parts, ci)
+        return parts
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.detach().cpu()
+        self._d.all_reduce(c, op=self._d.ReduceOp.SUM)
+        t.copy_(c)
+        return self._Done()
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        out.view(-1).view(torch.uint8).copy_(torch.cat(self._gather_bytes(inp)))
+        return self._Done()
+
+    def all_to_all_single(self, out, inp, group=None, async_op=False):
+        # (gloo's own all-to-all rejects some dtypes: every rank gathers every send buffer and keeps its own panel of each)
+        w, r = self._d.get_world_size(), self._d.get_rank()
+        parts = self._gather_bytes(inp)
+        n = parts[0].numel() // w
+        out.view(-1).view(torch.uint8).copy_(torch.cat([p[r * n:(r + 1) * n] for p in parts]))
+        return self._Done()
+
+
+def backend_name():
+    """GEOGCN_DIST_BACKEND: 'torch' (default: torch.distributed's nccl = RCCL), 'native' (the library's geogcn_comm_* entry
+    points for the data path), 'staged-gloo' (one-GPU functional check, see HostStagedGloo)."""
+    return os.environ.get('GEOGCN_DIST_BACKEND', 'torch')
+
+
+def init_process_group(local_rank):
+    """Join the job torchrun started (RANK / WORLD_SIZE / MASTER_* in the environment) -> this rank's device."""
+    import torch.distributed as dist
+    if backend_name() == 'staged-gloo':
+        device = torch.device('cuda', 0)                     # all ranks share the one GPU
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            dist.init_process_group('gloo')
+        return device
+    device = torch.device('cuda', int(local_rank))
+    torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', device_id=device)
+    return device
+
+
 class TorchDistComm(Comm):
     """One process per GPU; RCCL (or gloo) through torch.distributed -- or, with GEOGCN_DIST_BACKEND=native, rendezvous
-    through torch.distributed and the data path through the library's own RCCL entry points (NativeRccl)."""
+    through torch.distributed and the data path through the library's own RCCL entry points (NativeRccl); or
+    GEOGCN_DIST_BACKEND=staged-gloo for the one-GPU functional check (HostStagedGloo)."""
 
     def __init__(self, N, device, group=None, exchange=None):
         import torch.distributed as dist
@@ -300,7 +367,9 @@ class TorchDistComm(Comm):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        if os.environ.get('GEOGCN_DIST_BACKEND', 'torch') == 'native' and torch.device(device).type == 'cuda':
+        if backend_name() == 'staged-gloo' and torch.device(device).type == 'cuda':
+            self.dist = HostStagedGloo()
+        elif backend_name() == 'native' and torch.device(device).type == 'cuda':
             box = [NativeRccl.unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
             self.dist = NativeRccl(self.world, self.rank, box[0], device)

@@ -115,12 +115,8 @@ def setup_distributed(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1:
         return torch.device('cuda', 0), None
-    import torch.distributed as dist
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local)
-    if not dist.is_initialized():
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    return torch.device('cuda', local), 'dist'
+    from . import dist as gdist
+    return gdist.init_process_group(int(os.environ.get('LOCAL_RANK', '0'))), 'dist'
 
 
 class Splits:

@@ -13,63 +13,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-class _Done:
-    def wait(self):
-        return True
-
-
-class StagedGloo:
-    """torch.distributed look-alike for ONE-GPU boxes: several ranks share cuda:0 (RCCL refuses that), the collectives go
-    through host copies and the gloo backend.  Slow and synchronous -- it exists so that the REAL kernels can be run under
-    a REAL multi-rank partition (panels, narrow SpMM, slot layout, bf16 wire) where no second GPU is available."""
-    ReduceOp = dist.ReduceOp
-
-    @staticmethod
-    def _bytes(t):
-        return t.detach().contiguous().view(-1).view(torch.uint8).cpu()
-
-    def _gather_bytes(self, t):
-        ci = self._bytes(t)
-        parts = [torch.empty_like(ci) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, ci)
-        return parts
-
-    def all_reduce(self, t, op=None, group=None, async_op=False):
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        t.copy_(c)
-        return _Done()
-
-    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
-        parts = self._gather_bytes(inp)
-        out.view(-1).view(torch.uint8).copy_(torch.cat(parts))
-        return _Done()
-
-    def all_to_all_single(self, out, inp, group=None, async_op=False):
-        # (gloo's own all-to-all rejects some dtypes: every rank gathers every send buffer and keeps its own panel of each)
-        w, r = dist.get_world_size(), dist.get_rank()
-        parts = self._gather_bytes(inp)
-        n = parts[0].numel() // w
-        out.view(-1).view(torch.uint8).copy_(torch.cat([p[r * n:(r + 1) * n] for p in parts]))
-        return _Done()
-
-
 def main():
-    staged = os.environ.get('GEOGCN_TEST_STAGED_GLOO') == '1'
-    local = 0 if staged else int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
-    if staged:
-        dist.init_process_group('gloo')
-    else:
-        dist.init_process_group('nccl', device_id=device)
-    from geographconv_amd.dist import TorchDistComm as _TorchDistComm
-
-    def TorchDistComm(N, dev, exchange=None):
-        comm = _TorchDistComm(N, dev, exchange=exchange)
-        if staged:
-            comm.dist = StagedGloo()
-        return comm
+    from geographconv_amd import dist as gdist
+    device = gdist.init_process_group(int(os.environ.get('LOCAL_RANK', '0')))      # nccl, or staged-gloo on cuda:0
+    from geographconv_amd.dist import TorchDistComm
     from geographconv_amd.nn import layers as L
     from tests.helpers import load_case, make_clf
     for name, exchange in [('tiny_highway', 'a2a'), ('tiny_plain_reg', 'a2a'), ('tiny_odd_widths', 'a2a'),

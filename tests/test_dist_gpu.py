@@ -2,7 +2,7 @@
 points) runs on however many GPUs are visible -- one on the test box, which still exercises process-group setup, the
 in-place all_gather_into_tensor on device buffers, the flat gradient all-reduce and the partition plumbing (`_force_dist`).
 The multi-rank logic WITH the HIP kernels is covered by letting 2 / 3 / 4 / 8 ranks share cuda:0 with the collectives staged
-through the host and gloo (StagedGloo in dist_gpu_worker.py); with the NumPy double under gloo it is covered on CPU
+through the host and gloo (`GEOGCN_DIST_BACKEND=staged-gloo`, dist.HostStagedGloo); with the NumPy double under gloo it is covered on CPU
 (test_dist_cpu.py)."""
 import os
 import subprocess
@@ -81,11 +81,11 @@ def test_comm_entry_points_world1():
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_real_kernels_under_a_real_partition_on_one_gpu(world):
     """The combination no 1-GPU box can otherwise reach: the HIP kernels AND a multi-rank partition.  `world` processes
-    share cuda:0; the collectives are staged through the host and gloo (tests/dist_gpu_worker.py StagedGloo).  Same
+    share cuda:0; the collectives are staged through the host and gloo (dist.HostStagedGloo).  Same
     assertions as the RCCL worker: golden vectors through both exchange schemes, the partitioned graph product bitwise equal
     to the one-GPU kernel on the same rows, the bf16 configuration through both schemes."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GEOGCN_TEST_STAGED_GLOO='1')
+    env = dict(os.environ, GEOGCN_DIST_BACKEND='staged-gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(29521 + world), os.path.join(root, 'tests', 'dist_gpu_worker.py')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -99,7 +99,7 @@ def test_bench_multi_rank_branches_on_one_gpu():
     never a measurement (the line says so)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GEOGCN_BENCH_STAGED_GLOO='1')
+    env = dict(os.environ, GEOGCN_DIST_BACKEND='staged-gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--shape', 'cmu', '--steps', '3', '--warmup', '1']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -110,3 +110,29 @@ def test_bench_multi_rank_branches_on_one_gpu():
     assert d['n_gpus'] == 2 and d['config']['world_size'] == 2 and d['config']['parallelism'] == 'rows2'
     assert 'NOT a measurement' in d['config']['collectives'] and d['value'] > 0 and d['scaling'] == 'strong'
     assert d['roofline']['kernel'] and np.isfinite(d['config']['train_loss_last'])
+
+
+def test_gcnmain_row_partitioned_on_one_gpu(tmp_path):
+    """The reference's entry point under torch.distributed.run with 3 ranks (sharing cuda:0, staged collectives): fit with
+    early stopping decided identically on every rank, predict + geo_eval through the row partition -- same dev accuracy and
+    distances as the single-process run with the same flags (p = 0: no dropout stream to keep in step)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = '-hid 48 48 -reg 0.0 -dropout 0.0 -highway -silent --synthetic cmu --epochs 6 -maxdown 2'.split()
+    probe = ("import sys, json; sys.path.insert(0, %r); from geographconv_amd import gcnmain; "
+             "clf, res = gcnmain.run(sys.argv[1:]); "
+             "import os; print('RESULT ' + json.dumps(res[0]['dev'])) if int(os.environ.get('RANK', '0')) == 0 else None") % root
+    env1 = dict(os.environ)
+    env1.pop('WORLD_SIZE', None)
+    r1 = subprocess.run([sys.executable, '-c', probe] + flags, capture_output=True, text=True, timeout=900, env=env1, cwd=str(tmp_path))
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    single = json.loads([l for l in r1.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+    env = dict(os.environ, GEOGCN_DIST_BACKEND='staged-gloo')
+    (tmp_path / 'probe.py').write_text(probe)                  # (torch.distributed.run wants a script path)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
+           '--master-port', '29573', str(tmp_path / 'probe.py')] + flags
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    part = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+    assert abs(part[2] - single[2]) <= 0.2, (part, single)                      # dev acc@161 (%)
+    assert abs(part[0] - single[0]) <= 0.02 * max(1.0, single[0]) and abs(part[1] - single[1]) <= 0.05 * max(1.0, single[1]), (part, single)

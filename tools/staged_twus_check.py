@@ -14,7 +14,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from tests.dist_gpu_worker import StagedGloo  # noqa: E402
 
 
 def main():
@@ -22,9 +21,9 @@ def main():
     cfg5 = len(sys.argv) > 2 and sys.argv[2] == 'cfg5'
     hid = [600] * 6 if cfg5 else [300, 300, 300]
     prec = 'bf16' if cfg5 else None
-    torch.cuda.set_device(0)
-    device = torch.device('cuda', 0)
-    dist.init_process_group('gloo')
+    os.environ['GEOGCN_DIST_BACKEND'] = 'staged-gloo'
+    from geographconv_amd import dist as gdist
+    device = gdist.init_process_group(0)
     from geographconv_amd import synth
     from geographconv_amd.dist import TorchDistComm
     from geographconv_amd.gcnmodel import GraphConv
@@ -32,7 +31,6 @@ def main():
     N = A.shape[0]
     mask = (np.random.RandomState(3).rand(N, hid[0]) < 0.5).astype(np.uint8)
     comm = TorchDistComm(N, device, exchange=exchange)
-    comm.dist = StagedGloo()
 
     def run(c):
         clf = GraphConv(X.shape[1], C, hid, 0.0, 0.5, highway=True, device=device, comm=c, gemm_precision=prec)
