@@ -123,7 +123,7 @@ def _worker(rank, world, port, q, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3), ("a2a", 8), ("allgather", 4)])
 def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     import torch.multiprocessing as mp
@@ -134,9 +134,9 @@ def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=240)
+    out = q.get(timeout=800)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     for name, (res, pred, probs, early) in out.items():
         z, A, X, params, cfg = load_case(name)
@@ -199,7 +199,7 @@ def _asym_worker(rank, world, port, q, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 2)])
 def test_multi_rank_asymmetric_adjacency(exchange, world):
     import torch.multiprocessing as mp
@@ -211,9 +211,9 @@ def test_multi_rank_asymmetric_adjacency(exchange, world):
     procs = [ctx.Process(target=_asym_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
-    sc, P, grads = q.get(timeout=240)
+    sc, P, grads = q.get(timeout=800)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     A, X, Y, tr, dev, te, cfg = _asym_case()
     params = O.random_params(cfg['V'], cfg['hid'], cfg['C'], True, seed=9)
@@ -288,7 +288,7 @@ def _random_worker(rank, world, port, q, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 3), ("a2a", 4)])
 def test_multi_rank_gloo_random_models(exchange, world):
     import torch.multiprocessing as mp
@@ -299,10 +299,10 @@ def test_multi_rank_gloo_random_models(exchange, world):
     for p in procs:
         p.start()
     try:
-        res = q.get(timeout=240)
+        res = q.get(timeout=800)
     finally:
         for p in procs:
-            p.join(timeout=60)
+            p.join(timeout=120)
             if p.is_alive():
                 p.terminate()
     assert res == 'ok', res
