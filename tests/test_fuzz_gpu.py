@@ -544,3 +544,48 @@ def test_loss_indexing_and_optimizer_random(dev, seed):
         pen = ops.reg_penalty(torch.from_numpy(p0).to(dev), torch.from_numpy(mask).to(dev), l1, l2).cpu().numpy()[0]
         ref_pen = float((mask * (l1 * np.abs(p0) + l2 * p0.astype(np.float64) ** 2)).sum())
         assert abs(pen - ref_pen) <= 2e-5 * max(1.0, abs(ref_pen)), ('penalty', seed, case)
+
+
+@pytest.mark.parametrize("seed", _seeds(3))
+def test_medium_sizes_random(dev, seed):
+    """The same sweeps at sizes where the launch geometry changes: GEMM rows from a few tiles to thousands (64-row tiles when
+    there are fewer tiles than CUs, persistent blocks beyond, split-K slab counts for the transposed products), graph
+    products with 10^5 rows (per-XCD row ranges, long-row chunks + ordered combine), the document-blocked X^T . G with
+    several batches, X . W0 with the hot rows in LDS."""
+    from geographconv_amd import ops, synth
+    rng = np.random.RandomState(11000 + seed)
+    for case in range(3):
+        M = int(rng.choice([4000, 33001, 120000]))
+        N, K = int(rng.choice([40, 256, 300])), int(rng.choice([129, 300, 600]))
+        A = rng.randn(M, K).astype(np.float32)
+        B = (rng.randn(K, N) * 0.1).astype(np.float32)
+        G = rng.randn(M, N).astype(np.float32)
+        dA, dB, dG = _dmat(ops, dev, A, rng), _dmat(ops, dev, B, rng), _dmat(ops, dev, G, rng)
+        a64 = A.astype(np.float64)
+        _close(ops.gemm(dA, dB).numpy(), a64 @ B, np.abs(a64) @ np.abs(B), ('gemm nn', seed, case, M, N, K))
+        _close(ops.gemm(dG, dB, transB=True).numpy(), G.astype(np.float64) @ B.T, np.abs(G) @ np.abs(B.T), ('gemm nt', seed, case))
+        _close(ops.gemm(dA, dG, transA=True).numpy(), a64.T @ G, np.abs(a64.T) @ np.abs(G), ('gemm tn', seed, case, M, N, K), slack=8e-6)
+    n = int(rng.choice([60000, 150000]))
+    Ah = synth.powerlaw_ahat(n, n * 12, seed=seed)
+    F = int(rng.choice([40, 256, 300]))
+    Z = rng.randn(n, F).astype(np.float32)
+    bias = rng.randn(F).astype(np.float32)
+    bt = torch.zeros(ops.pad4(F), device=dev)
+    bt[:F] = torch.from_numpy(bias)
+    dA = ops.CSR(Ah, dev, long_row_nnz=int(rng.choice([64, 256])), chunk_nnz=int(rng.choice([32, 128])))
+    assert dA.n_long_rows > 0
+    a64 = Ah.astype(np.float64)
+    got = ops.spmm(dA, _dmat(ops, dev, Z, rng), bias=bt, act=1)
+    _close(got.numpy(), np.tanh(np.asarray(a64 @ Z.astype(np.float64)) + bias), np.asarray(abs(a64) @ np.abs(Z)) + np.abs(bias),
+           ('spmm medium', seed, n, F))
+    nd, nw = int(rng.choice([80000, 200000])), int(rng.choice([3000, 9000]))
+    X = sps.csr_matrix(synth.bow_x(nd, nw, 40, seed=seed + 3))
+    x = ops.SparseOperand.from_scipy(X, dev)
+    Fx = int(rng.choice([64, 300]))
+    W = (rng.randn(nw, Fx) * 0.1).astype(np.float32)
+    Gx = rng.randn(nd, Fx).astype(np.float32)
+    x64 = X.astype(np.float64)
+    _close(ops.spmm_x(x, _dmat(ops, dev, W, rng)).numpy(), np.asarray(x64 @ W.astype(np.float64)), np.asarray(abs(x64) @ np.abs(W)),
+           ('X.W0 medium', seed, nd, nw, Fx))
+    _close(ops.spmm_t(x, _dmat(ops, dev, Gx, rng)).numpy(), np.asarray(x64.T @ Gx.astype(np.float64)), np.asarray(abs(x64).T @ np.abs(Gx)),
+           ('X^T.G medium', seed, nd, nw, Fx), slack=8e-6)
