@@ -240,3 +240,62 @@ def test_config5_shape_bf16_six_layers_600_hidden_full_size(twus):
     assert np.array_equal(pred[clear], ref.argmax(-1)[clear]) or (pred[clear] != ref.argmax(-1)[clear]).mean() < 1e-3
     pred2, probs2 = clf.predict(t['X'], t['A'], idx)
     assert np.array_equal(pred, pred2) and np.array_equal(probs, probs2)
+
+
+def test_operands_beyond_4gb_use_64bit_offsets():
+    """N x F matrices of 4.9 GB (1.2 M rows x 1,024 columns: the reference's WORLD configuration runs 900 hidden units over
+    ~1.4 M users, README.md:180): every kernel family must address rows beyond the 2^32-byte mark correctly.  Operands are
+    generated on the device; rows sampled from the whole range -- above all from the far end -- are checked on the host."""
+    from geographconv_amd import ops, synth
+    ops.require_gpu()
+    dev = torch.device('cuda:0')
+    N, F, K = 1_200_000, 1024, 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    Z = ops.DMat.empty(N, F, dev)
+    Z.t.normal_(generator=g)
+    assert Z.t.numel() * 4 > 2 ** 32
+    rows = np.unique(np.r_[0, 1, N // 2, np.arange(N - 40, N), np.random.RandomState(0).randint(0, N, 60)])
+    # graph product: a sparse matrix whose far rows reference far rows
+    A = synth.powerlaw_ahat(N, 3 * N, seed=2)
+    dA = ops.CSR(A, dev)
+    S = ops.spmm(dA, Z)
+    Zh = {}
+    need = np.unique(np.concatenate([A.indices[A.indptr[r]:A.indptr[r + 1]] for r in rows]))
+    Zsub = Z.t[torch.from_numpy(need).to(dev)].cpu().numpy().astype(np.float64)
+    pos = {int(c): i for i, c in enumerate(need)}
+    Sg = S.t[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    for i, r in enumerate(rows):
+        cols, vals = A.indices[A.indptr[r]:A.indptr[r + 1]], A.data[A.indptr[r]:A.indptr[r + 1]].astype(np.float64)
+        ref = (vals[:, None] * Zsub[[pos[int(c)] for c in cols]]).sum(axis=0)
+        mag = (np.abs(vals)[:, None] * np.abs(Zsub[[pos[int(c)] for c in cols]])).sum(axis=0)
+        assert np.all(np.abs(Sg[i] - ref) <= 4e-6 * mag + 1e-6), ('spmm', int(r))
+    del S
+    # GEMM: (N x K) . (K x F) -> N x F beyond 4 GB, and the transposed product reducing over all N rows
+    H = ops.DMat.empty(N, K, dev)
+    H.t.normal_(generator=g)
+    W = ops.DMat.empty(K, F, dev)
+    W.t.normal_(generator=g)
+    C = ops.gemm(H, W, act=ops.ACT_TANH)
+    Hr = H.t[torch.from_numpy(rows).to(dev)].cpu().numpy().astype(np.float64)
+    Wn = W.numpy().astype(np.float64)
+    Cg = C.t[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    assert np.all(np.abs(Cg - np.tanh(Hr @ Wn)) <= 4e-6 * (np.abs(Hr) @ np.abs(Wn)) + 1e-6)
+    dW = ops.gemm(H, C, transA=True)                                   # K x F, reduction over 1.2 M rows of a 4.9 GB operand
+    ref = (H.t.double().T @ C.t.double()).cpu().numpy()
+    mag = (H.t.double().abs().T @ C.t.double().abs()).cpu().numpy()
+    assert np.all(np.abs(dW.numpy() - ref) <= 8e-6 * mag + 1e-5)
+    # elementwise family: highway mix and its backward with the column sums on the same 4.9 GB operands
+    T = ops.DMat.empty(N, F, dev)
+    T.t.uniform_(generator=g)
+    out = ops.highway_fwd(T, C, Z)
+    sel = torch.from_numpy(rows).to(dev)
+    t_, c_, z_ = (m.t[sel].double().cpu().numpy() for m in (T, C, Z))
+    assert np.allclose(out.t[sel].cpu().numpy(), t_ * c_ + (1 - t_) * z_, rtol=2e-6, atol=1e-6)
+    dbS, dbU = torch.zeros(F, device=dev), torch.zeros(F, device=dev)
+    dS, dU, dC = ops.highway_bwd(out, T, C, Z, dbS=dbS, dbU=dbU)
+    g_ = out.t[sel].double().cpu().numpy()
+    assert np.allclose(dS.t[sel][:, :F].cpu().numpy(), g_ * t_ * (1 - c_ * c_), rtol=3e-6, atol=1e-6)
+    assert np.allclose(dC.t[sel].cpu().numpy(), g_ * (1 - t_), rtol=3e-6, atol=1e-6)
+    ref_db = (out.t.double() * T.t.double() * (1 - C.t.double() ** 2)).sum(dim=0).cpu().numpy()
+    assert np.allclose(dbS.cpu().numpy(), ref_db, rtol=2e-4, atol=2e-2)
