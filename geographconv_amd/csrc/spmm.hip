@@ -25,6 +25,10 @@ namespace {
 
 constexpr int kGroup = 16;                // lanes per row (wide operands); narrow ones use 8
 constexpr int kBlock = 256;               // 4 waves = 16 groups
+// threads per row-kernel workgroup: 512 (32 rows of 16 lanes) measured 1.7 % faster than 256, 128 slower
+// (pinned graph 1.851 / 1.883 / 1.890 ms, community graph 1.080 / 1.100 / 1.118); the long-row combine keeps kBlock
+constexpr int kRowBlock = 512;
+constexpr int kRowAlign = kRowBlock / 8;     // rows per workgroup of the narrowest (8-lane) variant: XCD ranges are multiples of it
 
 
 struct F4 {
@@ -218,7 +222,7 @@ struct XcdRows {
 // 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
 // that it overlaps the bulk instead of running as an under-occupied launch of its own.
 template <int K4, int ACT, int NTT, int G, int BF, int HW = 0>
-__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
+__global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
 #pragma unroll
     for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((int)blockIdx.x < n_chunk_blocks) {
-        const int ch = blockIdx.x * (kBlock / G) + (threadIdx.x / G);
+        const int ch = blockIdx.x * (kRowBlock / G) + (threadIdx.x / G);
         if (ch >= n_chunks) return;
         const int cs = chunk_start[ch], ce = chunk_end[ch];
         const int ch_h = chunk_split ? chunk_split[ch] : ce;       // [cs, ch_h) hubs, [ch_h, ce) streamed
@@ -254,13 +258,13 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     int rb = blockIdx.x - n_chunk_blocks;
     int row_lo = 0, row_end = n_rows;
     if (per_xcd > 0) {
-        // XCD x owns rows [xr.lo[x], xr.lo[x + 1]) (multiples of 32: balanced by stored entries on the host)
+        // XCD x owns rows [xr.lo[x], xr.lo[x + 1]) (multiples of kRowAlign: balanced by stored entries on the host)
         const int x = rb % kNumXCD;
-        rb = xr.lo[x] / (kBlock / G) + rb / kNumXCD;
+        rb = xr.lo[x] / (kRowBlock / G) + rb / kNumXCD;
         row_lo = xr.lo[x];
         row_end = xr.lo[x + 1];
     }
-    const int row = rb * (kBlock / G) + (threadIdx.x / G);
+    const int row = rb * (kRowBlock / G) + (threadIdx.x / G);
     // (a boundary clamped to n_rows need not be a multiple of the block's rows: the division above then starts the block
     //  BELOW row_lo, inside the previous XCD's range -- harmless for a plain product, which would just be written twice,
     //  but the accumulate form reads what it writes)
@@ -382,7 +386,7 @@ struct geogcn_spmm_plan {
     int* d_chunk_end = nullptr;    // [n_chunks]
     int* d_rowsplit = nullptr;     // [n_rows]   cache hint (nullable)
     int* d_chunk_split = nullptr;  // [n_chunks] rowsplit clamped into each chunk
-    int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per-XCD row ranges (multiples of 32), equal stored entries
+    int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per-XCD row ranges (multiples of 64 = kRowAlign), equal stored entries
 };
 
 struct geogcn_timer {
@@ -401,7 +405,7 @@ template <int K4, int G, int BF>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
               const float* val, const void* B, int64_t ldb, float* C, int64_t ldc, int F,
               const float* bias, int act, float* ws, hipStream_t st, int64_t nnz, const HwArgs& hw) {
-    constexpr int kGroupsPerBlock = kBlock / G;
+    constexpr int kGroupsPerBlock = kRowBlock / G;
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
     static const int xcd_rows = [] {
@@ -418,7 +422,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = plan->xcd_lo[x];
         for (int x = 0; x < kNumXCD; ++x) per_xcd = std::max(per_xcd, (int)cdiv(xr.lo[x + 1] - xr.lo[x], kGroupsPerBlock));
     } else if (xcd_rows) {
-        per_xcd = (int)cdiv(cdiv(n_row_blocks, kNumXCD) * kGroupsPerBlock, 32) * 32 / kGroupsPerBlock;
+        per_xcd = (int)cdiv(cdiv(n_row_blocks, kNumXCD) * kGroupsPerBlock, kRowAlign) * kRowAlign / kGroupsPerBlock;
         for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = (int)std::min<int64_t>(n_rows, (int64_t)x * per_xcd * kGroupsPerBlock);
     }
     const dim3 grid((unsigned)(n_chunk_blocks + (per_xcd ? per_xcd * kNumXCD : n_row_blocks)));
@@ -440,7 +444,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         GEOGCN_ROWS_(ACT, 0)
 #define GEOGCN_ROWS_(ACT, NTT) GEOGCN_ROWS__(ACT, NTT, 0)
 #define GEOGCN_ROWS__(ACT, NTT, HW_)                                                             \
-    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF, HW_>), grid, dim3(kBlock), 0, st, n_rows, rowptr,   \
+    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF, HW_>), grid, dim3(kRowBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
                        plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw, per_xcd, xr)
@@ -684,7 +688,7 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const in
         for (int r = 0; r < n_rows && x < 8; ++r) {
             run += cost(r);
             while (x < 8 && run * 8 >= total * x) {
-                plan->xcd_lo[x] = std::min(n_rows, (r + 1 + 31) / 32 * 32);
+                plan->xcd_lo[x] = std::min(n_rows, (r + 1 + 63) / 64 * 64);
                 ++x;
             }
         }
