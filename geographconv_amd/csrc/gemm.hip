@@ -637,8 +637,9 @@ int dispatch_tiles(int bm, int bn, const GemmCall& c, void* ws, size_t ws_bytes,
         GEOGCN_T(64, 128)           // few rows (CMU shape): twice the tiles, so that more than half the CUs get one
         GEOGCN_T(64, 160)
     }
-    if constexpr (BT) {
-        GEOGCN_T(96, 160)           // two k-contiguous images of 128+160 rows would not fit twice in 160 KB
+    if constexpr (!AT) {
+        GEOGCN_T(96, 160)           // A . B^T: two k-contiguous images of 128+160 rows would not fit twice in 160 KB;
+                                    // A . B: mid-size operands (choose_tiles)
     }
     if constexpr (AT) {
         GEOGCN_T(160, 128)
@@ -665,6 +666,15 @@ inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int 
     // short operands: with 128-row tiles fewer tiles than CUs -> 64-row tiles (M = 9,475: 150 -> 298 tiles)
     const bool few = cdiv(M, 128) * cdiv(maxN, bn) * n_nseg < kNumCU;
     bm = few ? 64 : ((transB && bn == 160) ? 96 : 128);
+    // in between (one to two rounds of the 512 resident blocks: the CMU shape's fused forward pair is 75 x 4 tiles of
+    // 128 rows) a 96-row tile that fits ONE round beats both: rounds x rows per tile is what the launch takes
+    if (!few && !transB && bn == 160) {
+        const int64_t slots = 2 * kNumCU, nt = cdiv(maxN, bn) * n_nseg;
+        const int64_t c128 = cdiv(cdiv(M, 128) * nt, slots) * 128, c96 = cdiv(cdiv(M, 96) * nt, slots) * 96;
+        // (only there: over many rounds the larger tile's lower operand traffic wins -- 440,000 x 300 x 300: 0.81 ms with
+        //  128 rows, 0.85 with 96)
+        if (c96 < c128 && cdiv(M, 128) * nt <= 2 * slots) bm = 96;
+    }
 }
 
 int run_call(bool transA, bool transB, const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
