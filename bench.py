@@ -178,6 +178,79 @@ def other_kernels(clf, g, hid, N, C, precision):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+    torch.distributed.run command the driver contract names) and hand their output through; rank 0 prints the line."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log('[bench] --gpus %d without WORLD_SIZE: launching %s' % (n, ' '.join(cmd[1:9])))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def timed_region(clf, step, steps, warmup, barrier, F_spmm, g):
+    """W untimed steps, then exactly K steps between barrier + synchronize pairs; the SpMM timer (hipEvent pairs recorded
+    by the library on the launch stream) samples the plain F_spmm-wide graph products inside the region."""
+    import torch
+    from geographconv_amd import ops
+    for _ in range(warmup):
+        step()
+    timer = ops.SpmmTimer(capacity=max(16, 8 * steps))
+    timer.attach(g['A'].fwd, only_F=F_spmm)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    marks[0].record()
+    for i in range(steps):
+        last = step()
+        marks[i + 1].record()
+    barrier()
+    t = time.perf_counter() - t0
+    timer.detach()
+    kern_ms = timer.read_ms()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    return t, step_ms, kern_ms, last
+
+
+def partition_check(make_clf, comms, X, A, Y, tr, dev, rank, n_steps=2):
+    """Parity evidence carried by an N > 1 line: `n_steps` training steps with dropout 0 through every exchange scheme,
+    compared on rank 0 with the SAME process's un-partitioned steps (same seed => same initial parameters): losses, hit
+    counts, the gathered probabilities, argmax agreement."""
+    import torch.distributed as dist
+
+    def run(comm):
+        clf = make_clf(comm, 0.0)
+        out = []
+        for _ in range(n_steps):
+            o = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+            out.append(([float(v) for v in o[:4]], clf.gather_output(o[4])))
+        return out
+    got = {name: run(c) for name, c in comms.items()}
+    dist.barrier()
+    res = None
+    if rank == 0:
+        want = run(None)
+        res = {"how": "%d f_train steps, dropout 0, every scheme vs this process's un-partitioned steps on rank 0 (same seed)" % n_steps}
+        for name, g in got.items():
+            dl = max(abs(a - b) for (gs, _), (ws, _) in zip(g, want) for a, b in ((gs[0], ws[0]), (gs[2], ws[2])))
+            dacc = max(abs(a - b) for (gs, _), (ws, _) in zip(g, want) for a, b in ((gs[1], ws[1]), (gs[3], ws[3])))
+            dP = max(float(np.abs(gp - wp).max()) for (_, gp), (_, wp) in zip(g, want))
+            agree = min(float((gp.argmax(1) == wp.argmax(1)).mean()) for (_, gp), (_, wp) in zip(g, want))
+            res[name] = {"max_abs_dloss": dl, "max_abs_dacc": dacc, "max_abs_dP": dP, "argmax_agreement": agree,
+                         "losses_partitioned": [gs[0] for gs, _ in g], "losses_single": [ws[0] for ws, _ in want]}
+    dist.barrier()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -191,7 +264,15 @@ def main():
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32 = exact fp32 MFMA (the headline configuration)')
     ap.add_argument('--cpu-sample', default='step', choices=['step', 'layer', 'none'])
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'a2a', 'allgather'],
+                    help='N > 1: exchange scheme whose time is `value` (auto: all-gather at 2 ranks, a2a from 3); the other '
+                         'scheme is timed too and reported under `alt`')
+    ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the `value` scheme')
+    ap.add_argument('--no-check', action='store_true', help='N > 1: skip the partition_check block')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
 
     import torch
     from geographconv_amd import ops, synth
@@ -201,9 +282,6 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     ops.require_gpu()
     # GEOGCN_DIST_BACKEND=staged-gloo: functional check of the N > 1 branches on a ONE-GPU box (never a measurement): all
@@ -227,55 +305,65 @@ def main():
     N, nnz = A.shape[0], int(A.nnz)
     if rank == 0:
         log('[bench] %s graph generated in %.1fs: N=%d nnz(A)=%d nnz(X)=%d' % (args.shape, time.time() - t0, N, nnz, X.nnz))
+    alt_comm = None
     if world > 1 or force_dist:
         from geographconv_amd.dist import TorchDistComm
-        comm = TorchDistComm(N, device)
+        comm = TorchDistComm(N, device, exchange=None if args.exchange == 'auto' else args.exchange)
+        if world > 1 and not args.no_alt:
+            alt_comm = TorchDistComm(N, device, exchange='allgather' if comm.exchange == 'a2a' else 'a2a')
 
-    clf = GraphConv(X.shape[1], C, args.hid, 0.0, args.dropout, highway=True, device=device, comm=comm,
-                    gemm_precision=args.gemm_precision, reorder=args.reorder)
-    clf.build_model(A, seed=77)
-    clf._force_dist = force_dist
+    def make_clf(c, dropout):
+        m = GraphConv(X.shape[1], C, args.hid, 0.0, dropout, highway=True, device=device, comm=c,
+                      gemm_precision=args.gemm_precision, reorder=args.reorder)
+        m.build_model(A, seed=77)
+        m._force_dist = force_dist and c is not None
+        return m
+
     y_tr, y_dev = Y[tr], Y[dev]
-
-    def step():
-        return clf.f_train(X, y_tr, y_dev, A, tr, dev)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    # roofline leg: library-side hipEvent pairs around the F=hid SpMM products, on the launch stream
-    timer = ops.SpmmTimer(capacity=max(16, 8 * args.steps))
-    # the dense operand of the timed SpMM: F = hid at one GPU; one feature panel per rank under the a2a scheme
-    F_spmm = args.hid[-1]
-    bf16_operand = args.gemm_precision == 'bf16'
-    if comm is not None and comm.exchange == 'a2a':
-        F_spmm = comm.panel_width(args.hid[-1], bf16_operand)
-    g0 = clf._device_graph(X, A)
-    timer.attach(only_F=F_spmm, only_nnz=g0['A'].fwd.nnz)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    marks[0].record()
-    for i in range(args.steps):
-        last = step()
-        marks[i + 1].record()
-    barrier()
-    t = time.perf_counter() - t0
-    timer.detach()
-    kern_ms = timer.read_ms()
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    def reduce_max(t):
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64, device='cpu' if staged else device)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
 
-    if world > 1:
-        tt = torch.tensor([t], dtype=torch.float64, device='cpu' if staged else device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        t = float(tt.item())
+    bf16_operand = args.gemm_precision == 'bf16'
+
+    def run_scheme(c):
+        m = make_clf(c, args.dropout)
+        # the dense operand of the timed SpMM: F = hid at one GPU; one feature panel per rank under the a2a scheme
+        F = args.hid[-1]
+        if c is not None and c.exchange == 'a2a':
+            F = c.panel_width(args.hid[-1], bf16_operand)
+        g = m._device_graph(X, A)
+        t, step_ms, kern_ms, last = timed_region(m, lambda: m.f_train(X, y_tr, y_dev, A, tr, dev), args.steps, args.warmup, barrier, F, g)
+        return m, g, F, reduce_max(t), step_ms, kern_ms, last
+
+    clf, g0, F_spmm, t, step_ms, kern_ms, last = run_scheme(comm)
     n_conv = len(args.hid)
     value = n_conv * nnz * args.steps / t
+    alt = None
+    if alt_comm is not None:
+        _m, _g, _F, t_alt, step_ms_alt, _k, last_alt = run_scheme(alt_comm)
+        alt = {"exchange": alt_comm.exchange, "value": n_conv * nnz * args.steps / t_alt, "unit": "edges/s",
+               "ms_per_step": t_alt / args.steps * 1e3, "step_ms_median": step_ms_alt[len(step_ms_alt) // 2],
+               "train_loss_last": float(last_alt[0]),
+               "note": "same job, same K/W, the other exchange scheme (%s)" % (
+                   "the north_star's 1-D row split of A_hat + all-gather of H" if alt_comm.exchange == 'allgather'
+                   else "feature repartition with two all-to-alls")}
+        del _m, _g
+    check = None
+    if world > 1 and not args.no_check:
+        comms = {comm.exchange: comm}
+        if alt_comm is not None:
+            comms[alt_comm.exchange] = alt_comm
+        check = partition_check(make_clf, comms, X, A, Y, tr, dev, rank)
 
     if rank == 0:
         g = g0
@@ -315,6 +403,12 @@ def main():
             except Exception as e:                       # evidence only: never fail the headline line over it
                 roofline["others_error"] = repr(e)
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
+        dist_info = None
+        if world > 1 or force_dist:
+            import torch.distributed as tdist
+            dist_info = {"world_size_seen": tdist.get_world_size(), "torch_backend": tdist.get_backend(),
+                         "data_path": type(comm.dist).__name__ if hasattr(comm, 'dist') and not isinstance(comm.dist, type(tdist)) else "torch.distributed",
+                         "exchange": comm.exchange, "staged": staged}
         out = {
             "metric": "GCN-layer fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3,
@@ -332,12 +426,19 @@ def main():
                        "edges_traversed_per_step": 2 * (n_conv - 1) * nnz + nnz + nnz_bwd_out,
                        "parallelism": "rows%d" % world if world > 1 else "single",
                        "world_size": world, "collectives": None if comm is None else ("%s, exchange = %s" % ("STAGED through the host + gloo (functional check, NOT a measurement)" if staged else "RCCL (torch.distributed nccl)", comm.exchange)),
+                       "dist": dist_info,
                        "reorder": args.reorder,
-                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
+                       "dropout_stream": "Philox keyed by device row: with --reorder the dropped entries differ from the "
+                                         "un-reordered run of the same seed (statistically equivalent, not bitwise)" if args.reorder else "Philox",
+                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
                                 "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
                        "train_loss_last": float(last[0])},
             "roofline": roofline,
         }
+        if alt is not None:
+            out["alt"] = alt
+        if check is not None:
+            out["partition_check"] = check
         if world == 1 and args.cpu_sample != 'none':
             log('[bench] timing the CPU oracle (%s sample)...' % args.cpu_sample)
             out["cpu_baseline"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample)

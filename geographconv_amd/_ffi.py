@@ -22,7 +22,7 @@ COMM_ID_BYTES = 128        # GEOGCN_COMM_ID_BYTES
 SIGNATURES = {
     'geogcn_version': (c_i32, []),
     'geogcn_last_error': (C.c_char_p, []),
-    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
+    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
     'geogcn_spmm_plan_destroy': (None, [c_ptr]),
     'geogcn_spmm_plan_num_long_rows': (c_i64, [c_ptr]),
     'geogcn_spmm_plan_num_chunks': (c_i64, [c_ptr]),
@@ -45,7 +45,7 @@ SIGNATURES = {
                                             c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_timer_create': (c_i32, [c_i32, C.POINTER(c_ptr)]),
     'geogcn_timer_destroy': (None, [c_ptr]),
-    'geogcn_timer_attach_spmm': (c_i32, [c_ptr, c_i32, c_i64]),
+    'geogcn_spmm_plan_attach_timer': (c_i32, [c_ptr, c_ptr, c_i32]),
     'geogcn_timer_read_ms': (c_i32, [c_ptr, c_ptr, c_i32, C.POINTER(c_i32)]),
     'geogcn_gemm_workspace_bytes': (c_sz, [c_i32, c_i32, c_i64, c_i64, c_i64, c_i32]),
     'geogcn_gemm_f32': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,

@@ -515,8 +515,8 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
 }
 
 static int64_t hw_parts(int64_t n) {
-    static const int64_t cap = [] { const char* e = getenv("GEOGCN_HW_PARTS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : 768; }();
-    return std::max<int64_t>(1, std::min<int64_t>(cap, cdiv(n, 64)));
+    constexpr int64_t kCap = 768;      // row slices of the fused column sums (3 per CU)
+    return std::max<int64_t>(1, std::min<int64_t>(kCap, cdiv(n, 64)));
 }
 
 size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F) {

@@ -612,14 +612,8 @@ inline int pick_tile(int64_t n) {
 // 8-wave "wide" tiles for transA (dW = H^T.dZ): one tile spans all of N (161..320 columns), 2 x 4 waves, one
 // block per CU.  Both streamed operands are staged once instead of once per N tile, and the 160x160 tile of the
 // 4-wave kernel only fits one block (= one wave per SIMD) per CU: 0.83 -> 0.755 ms at 440000x300x300.  For
-// NN / NT the 4-wave tiles with two blocks per CU measured 3 % faster, so those keep them.  GEOGCN_GEMM_WIDE=0
-// disables (A/B switch).
+// NN / NT the 4-wave tiles with two blocks per CU measured 3 % faster, so those keep them.
 inline int wide_bn(int64_t N) {
-    static const int enabled = [] {
-        const char* e = getenv("GEOGCN_GEMM_WIDE");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    if (!enabled) return 0;
     if (N > 256 && N <= 320) return 320;
     if (N > 160 && N <= 256) return 256;
     return 0;

@@ -44,14 +44,10 @@ __device__ __forceinline__ void fma4(float4& acc, float a, const float4& b) {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// NT = 1: non-temporal gather (global_load ... nt): the line is streamed through the L2 without
-// displacing the lines loaded with the default policy (measured: tools/micro/nt_retention.hip).
-template <int NT>
+// (a hub hint -- hub columns first with default loads, the rest with non-temporal loads so that they do not evict the
+//  hubs -- was built and measured in rounds 1-2: 2.0 -> 2.6-2.8 ms, removed in round 3)
 __device__ __forceinline__ float4 gather4(const void* row, int q) {
-    const f32x4v* p = reinterpret_cast<const f32x4v*>(row) + q;
-    f32x4v v;
-    if constexpr (NT) v = __builtin_nontemporal_load(p);
-    else v = *p;
+    const f32x4v v = *(reinterpret_cast<const f32x4v*>(row) + q);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 // BF = 1: the gathered operand is stored as bfloat16.  A lane still loads 16 bytes per pass -- now 8
@@ -59,11 +55,8 @@ __device__ __forceinline__ float4 gather4(const void* row, int q) {
 // instructions in flight, not bytes: a first version with 8-byte loads (4 features per lane and pass) moved
 // half the bytes per instruction and ran no faster than fp32 (1.93 vs 1.98 ms at F = 300).
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-template <int NT>
 __device__ __forceinline__ u32x4v gather8_bf16(const void* row, int q8) {
-    const u32x4v* p = reinterpret_cast<const u32x4v*>(row) + q8;
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
+    return *(reinterpret_cast<const u32x4v*>(row) + q8);
 }
 // a * (8 bf16 features) accumulated into two float4s; the raw 16 bytes stay packed until here, so that the
 // loads in flight cost 4 VGPRs each, not 8
@@ -87,7 +80,7 @@ __device__ __forceinline__ const void* row_ptr(const void* B, int64_t ldb, int c
 }
 
 // One group walks nonzeros [s, e) and accumulates into acc[K4].
-template <int K4, int NT, int G, int BF>
+template <int K4, int G, int BF>
 __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int nF4,
                                                  const int* __restrict__ colidx,
                                                  const float* __restrict__ val,
@@ -125,8 +118,8 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
                 for (int j = 0; j < K4 / 2; ++j) {
                     const int q8 = lane16 + G * j;
                     if (2 * q8 < nF4) {
-                        r0[j] = gather8_bf16<NT>(b0, q8);
-                        r1[j] = gather8_bf16<NT>(b1, q8);
+                        r0[j] = gather8_bf16(b0, q8);
+                        r1[j] = gather8_bf16(b1, q8);
                     }
                 }
 #pragma unroll
@@ -143,8 +136,8 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
                 for (int k = 0; k < K4; ++k) {
                     const int q = lane16 + G * k;
                     if (q < nF4) {
-                        v0[k] = gather4<NT>(b0, q);
-                        v1[k] = gather4<NT>(b1, q);
+                        v0[k] = gather4(b0, q);
+                        v1[k] = gather4(b1, q);
                     }
                 }
 #pragma unroll
@@ -165,13 +158,13 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
 #pragma unroll
                 for (int k = 0; k < K4; k += 2) {
                     const int q8 = lane16 + G * (k >> 1);
-                    if (2 * q8 < nF4) fma8_bf16(acc[k], acc[k + 1], a0, gather8_bf16<NT>(b0, q8));
+                    if (2 * q8 < nF4) fma8_bf16(acc[k], acc[k + 1], a0, gather8_bf16(b0, q8));
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < K4; ++k) {
                     const int q = lane16 + G * k;
-                    if (q < nF4) fma4(acc[k], a0, gather4<NT>(b0, q));
+                    if (q < nF4) fma4(acc[k], a0, gather4(b0, q));
                 }
             }
         }
@@ -221,14 +214,13 @@ struct XcdRows {
 // of the long rows (raw partial sums into the workspace P), the remaining blocks take one CSR row per
 // 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
 // that it overlaps the bulk instead of running as an under-occupied launch of its own.
-template <int K4, int ACT, int NTT, int G, int BF, int HW = 0>
+template <int K4, int ACT, int G, int BF, int HW = 0>
 __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
-    const int* __restrict__ rowsplit, const int* __restrict__ chunk_split, const HwArgs hw, const int per_xcd,
-    const XcdRows xr) {
+    const HwArgs hw, const int per_xcd, const XcdRows xr) {
     const int lane16 = threadIdx.x % G;
     const int nF4 = (F + 3) >> 2;
     float4 acc[K4];
@@ -238,9 +230,7 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
         const int ch = blockIdx.x * (kRowBlock / G) + (threadIdx.x / G);
         if (ch >= n_chunks) return;
         const int cs = chunk_start[ch], ce = chunk_end[ch];
-        const int ch_h = chunk_split ? chunk_split[ch] : ce;       // [cs, ch_h) hubs, [ch_h, ce) streamed
-        group_accumulate<K4, 0, G, BF>(cs, ch_h, lane16, nF4, colidx, val, B, ldb, acc);
-        group_accumulate<K4, NTT, G, BF>(ch_h, ce, lane16, nF4, colidx, val, B, ldb, acc);
+        group_accumulate<K4, G, BF>(cs, ce, lane16, nF4, colidx, val, B, ldb, acc);
         float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
 #pragma unroll
         for (int k = 0; k < K4; ++k) {
@@ -272,7 +262,6 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     const int s = rowptr[row];
     const int e = rowptr[row + 1];
     if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks
-    const int h = rowsplit ? rowsplit[row] : e;
     if (hw.init) {
         const float4* irow = reinterpret_cast<const float4*>(hw.init + (int64_t)row * hw.ld_init);
 #pragma unroll
@@ -281,8 +270,7 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
             if (q < nF4) acc[k] = irow[q];
         }
     }
-    group_accumulate<K4, 0, G, BF>(s, h, lane16, nF4, colidx, val, B, ldb, acc);
-    group_accumulate<K4, NTT, G, BF>(h, e, lane16, nF4, colidx, val, B, ldb, acc);
+    group_accumulate<K4, G, BF>(s, e, lane16, nF4, colidx, val, B, ldb, acc);
     float4* out = reinterpret_cast<float4*>(C + (int64_t)row * ldc);
 #pragma unroll
     for (int k = 0; k < K4; ++k) {
@@ -374,6 +362,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
 }  // namespace
 }  // namespace geogcn
 
+struct geogcn_timer;
 struct geogcn_spmm_plan {
     int32_t n_rows = 0;
     int32_t long_row_nnz = 0;
@@ -384,9 +373,10 @@ struct geogcn_spmm_plan {
     int* d_long_first = nullptr;   // [n_long + 1] first chunk of each long row
     int* d_chunk_start = nullptr;  // [n_chunks]
     int* d_chunk_end = nullptr;    // [n_chunks]
-    int* d_rowsplit = nullptr;     // [n_rows]   cache hint (nullable)
-    int* d_chunk_split = nullptr;  // [n_chunks] rowsplit clamped into each chunk
     int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per-XCD row ranges (multiples of 64 = kRowAlign), equal stored entries
+    // profiling aid (geogcn_spmm_plan_attach_timer): the caller's event pool, sampled by the products that run on THIS plan
+    geogcn_timer* timer = nullptr;
+    int32_t timer_F = 0;
 };
 
 struct geogcn_timer {
@@ -397,10 +387,6 @@ struct geogcn_timer {
 namespace geogcn {
 namespace {
 
-geogcn_timer* g_spmm_timer = nullptr;
-int g_spmm_timer_F = 0;
-int64_t g_spmm_timer_nnz = 0;
-
 template <int K4, int G, int BF>
 int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const int* colidx,
               const float* val, const void* B, int64_t ldb, float* C, int64_t ldc, int F,
@@ -408,10 +394,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     constexpr int kGroupsPerBlock = kRowBlock / G;
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
-    static const int xcd_rows = [] {
-        const char* e = getenv("GEOGCN_SPMM_XCD_ROWS");       // 0 = plain block -> row-block map (A/B switch)
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
+    constexpr int xcd_rows = 1;      // (0 = plain block -> row-block map: the A/B of DESIGN.md section 4.1)
     // (chunk blocks padded to a multiple of 8 so that the row blocks start on XCD 0; surplus blocks exit at once)
     const int n_chunk_blocks = (int)(cdiv(cdiv(n_chunks, kGroupsPerBlock), kNumXCD) * kNumXCD);
     const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
@@ -426,37 +409,24 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
         for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = (int)std::min<int64_t>(n_rows, (int64_t)x * per_xcd * kGroupsPerBlock);
     }
     const dim3 grid((unsigned)(n_chunk_blocks + (per_xcd ? per_xcd * kNumXCD : n_row_blocks)));
-    geogcn_timer* tm = g_spmm_timer;
-    const bool timed = tm && (g_spmm_timer_F == 0 || g_spmm_timer_F == F) &&
-                       (g_spmm_timer_nnz == 0 || g_spmm_timer_nnz == nnz) && tm->used < (int)tm->begin.size() &&
-                       n_rows > 0 && !hw.T;        // (the fused highway launches move other bytes: not the kernel bench.py prices)
+    // the timer rides on the PLAN handle the caller passes (no library-global state): sampled are the products on this plan
+    // whose width matches, except the fused highway launches (they move other bytes: not the kernel bench.py prices)
+    geogcn_timer* tm = plan ? plan->timer : nullptr;
+    const bool timed = tm && (plan->timer_F == 0 || plan->timer_F == F) && tm->used < (int)tm->begin.size() && n_rows > 0 && !hw.T;
     if (timed) GEOGCN_HIP(hipEventRecord(tm->begin[tm->used], st));
-    static const int nt_tail = [] {
-        const char* e = getenv("GEOGCN_SPMM_NT");      // experiment switch: 0 = plain loads for the tail too
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-#define GEOGCN_ROWS(ACT)                                                                         \
-    if constexpr (BF) {          /* no cache-hint variant for the bf16 operand */               \
-        GEOGCN_ROWS_(ACT, 0);                                                                    \
-    } else if (nt_tail)                                                                          \
-        GEOGCN_ROWS_(ACT, 1);                                                                    \
-    else                                                                                         \
-        GEOGCN_ROWS_(ACT, 0)
-#define GEOGCN_ROWS_(ACT, NTT) GEOGCN_ROWS__(ACT, NTT, 0)
-#define GEOGCN_ROWS__(ACT, NTT, HW_)                                                             \
-    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, NTT, G, BF, HW_>), grid, dim3(kRowBlock), 0, st, n_rows, rowptr,   \
+#define GEOGCN_ROWS(ACT) GEOGCN_ROWS__(ACT, 0)
+#define GEOGCN_ROWS__(ACT, HW_)                                                                  \
+    hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, G, BF, HW_>), grid, dim3(kRowBlock), 0, st, n_rows, rowptr,   \
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
-                       n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, \
-                       plan ? plan->d_rowsplit : nullptr, (n_chunks && plan->d_rowsplit) ? plan->d_chunk_split : nullptr, hw, per_xcd, xr)
+                       n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, hw, per_xcd, xr)
     if (n_rows > 0) {
-        if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 0, 1); }        // highway epilogue: tanh branch only (checked by the caller)
+        if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 1); }        // highway epilogue: tanh branch only (checked by the caller)
         else if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }
         else if (act == GEOGCN_ACT_SIGMOID) { GEOGCN_ROWS(GEOGCN_ACT_SIGMOID); }
         else { GEOGCN_ROWS(GEOGCN_ACT_NONE); }
         GEOGCN_LAUNCH_CHECK("spmm_rows_kernel");
     }
 #undef GEOGCN_ROWS
-#undef GEOGCN_ROWS_
 #undef GEOGCN_ROWS__
     if (n_chunks > 0) {
         const int Fpad = (int)std::min<int64_t>(ldc, ldp);
@@ -624,16 +594,15 @@ int geogcn_timer_create(int32_t capacity, geogcn_timer** out) {
 
 void geogcn_timer_destroy(geogcn_timer* t) {
     if (!t) return;
-    if (g_spmm_timer == t) g_spmm_timer = nullptr;
     for (auto& e : t->begin) (void)hipEventDestroy(e);
     for (auto& e : t->end) (void)hipEventDestroy(e);
     delete t;
 }
 
-int geogcn_timer_attach_spmm(geogcn_timer* t, int32_t only_F, int64_t only_nnz) {
-    g_spmm_timer = t;
-    g_spmm_timer_F = only_F;
-    g_spmm_timer_nnz = only_nnz;
+int geogcn_spmm_plan_attach_timer(geogcn_spmm_plan* plan, geogcn_timer* t, int32_t only_F) {
+    GEOGCN_REQUIRE(plan, GEOGCN_E_NULL, "spmm_plan_attach_timer: null plan");
+    plan->timer = t;
+    plan->timer_F = only_F;
     if (t) t->used = 0;
     return 0;
 }
@@ -649,18 +618,16 @@ int geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32_
     return 0;
 }
 
-int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const int32_t* rowsplit_host,
-                            int32_t long_row_nnz, int32_t chunk_nnz, geogcn_spmm_plan** out) {
+int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz, int32_t chunk_nnz,
+                            geogcn_spmm_plan** out) {
     GEOGCN_REQUIRE(rowptr_host && out, GEOGCN_E_NULL, "spmm_plan_create: null pointer");
     GEOGCN_REQUIRE(n_rows >= 0 && long_row_nnz > 0 && chunk_nnz > 0, GEOGCN_E_SIZE,
                    "spmm_plan_create: bad sizes n_rows=%d long=%d chunk=%d", n_rows, long_row_nnz,
                    chunk_nnz);
-    std::vector<int> long_rows, long_first, cs, ce, csplit;
+    std::vector<int> long_rows, long_first, cs, ce;
     for (int r = 0; r < n_rows; ++r) {
         const int s = rowptr_host[r], e = rowptr_host[r + 1];
         GEOGCN_REQUIRE(e >= s, GEOGCN_E_SIZE, "spmm_plan_create: rowptr not monotone at row %d", r);
-        GEOGCN_REQUIRE(!rowsplit_host || (rowsplit_host[r] >= s && rowsplit_host[r] <= e), GEOGCN_E_SIZE,
-                       "spmm_plan_create: rowsplit[%d] outside its row", r);
         if (e - s > long_row_nnz) {
             long_rows.push_back(r);
             long_first.push_back((int)cs.size());
@@ -668,7 +635,6 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const in
                 const int pe = std::min(e, p + chunk_nnz);
                 cs.push_back(p);
                 ce.push_back(pe);
-                if (rowsplit_host) csplit.push_back(std::min(pe, std::max(p, rowsplit_host[r])));
             }
         }
     }
@@ -712,15 +678,6 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const in
         if (e == hipSuccess) e = upload(long_first, &plan->d_long_first);
         if (e == hipSuccess) e = upload(cs, &plan->d_chunk_start);
         if (e == hipSuccess) e = upload(ce, &plan->d_chunk_end);
-        if (e == hipSuccess && rowsplit_host) e = upload(csplit, &plan->d_chunk_split);
-        if (e != hipSuccess) {
-            set_error("spmm_plan_create: %s", hipGetErrorString(e));
-            geogcn_spmm_plan_destroy(plan);
-            return (int)e;
-        }
-    }
-    if (rowsplit_host && n_rows > 0) {
-        hipError_t e = upload(std::vector<int>(rowsplit_host, rowsplit_host + n_rows), &plan->d_rowsplit);
         if (e != hipSuccess) {
             set_error("spmm_plan_create: %s", hipGetErrorString(e));
             geogcn_spmm_plan_destroy(plan);
@@ -737,8 +694,6 @@ void geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan) {
     if (plan->d_long_first) (void)hipFree(plan->d_long_first);
     if (plan->d_chunk_start) (void)hipFree(plan->d_chunk_start);
     if (plan->d_chunk_end) (void)hipFree(plan->d_chunk_end);
-    if (plan->d_rowsplit) (void)hipFree(plan->d_rowsplit);
-    if (plan->d_chunk_split) (void)hipFree(plan->d_chunk_split);
     delete plan;
 }
 

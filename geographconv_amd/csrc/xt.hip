@@ -39,23 +39,12 @@ constexpr int kSlots = 32;               // workgroups per virtual XCD (one per 
 constexpr int kUnitsPerGroup = 2;
 // narrow rows (K4 <= 5: 2 x K4 float4 accumulators fit 128 VGPRs) run 1024-thread workgroups, wide ones 512 / 256
 constexpr int wg_threads(int K4) { return K4 <= 5 ? 1024 : (K4 <= 10 ? 512 : 256); }
-inline int doc_block_rows() {
-    static const int v = [] {
-        const char* e = getenv("GEOGCN_XT_DOC_BLOCK");
-        const int b = e ? atoi(e) : 0;
-        return b > 0 ? b : 2048;
-    }();
-    return v;
-}
-
-inline double unit_cap() {
-    static const double v = [] {
-        const char* e = getenv("GEOGCN_XT_UNIT_CAP");
-        const double c = e ? atof(e) : 0.0;
-        return c > 0.0 ? c : 2.0;
-    }();
-    return v;
-}
+// documents per sweep block: 2048 rows of dS0 = 2.6 MB at F = 300, inside one XCD's 4 MB L2 (512 / 1024 / 3072-8192 rows
+// measured slower, profiles/r02_xt_sweep.txt)
+constexpr int kDocBlock = 2048;
+// how many average group shares one unit may weigh: 1 = best balance but 4 batches at the TwitterUS shape, 2 = 3 batches
+// (measured 1.50 against 1.59 ms)
+constexpr double kUnitCap = 2.0;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -82,11 +71,6 @@ struct XtArgs {
     int n_words, n_batches, doc_block;
     float* partial; int64_t ldp;        // [8][n_slots][ldp],  n_slots = n_batches * kSlots * groups * kUnitsPerGroup
     int64_t n_slots;
-    // soft per-XCD rendezvous (nullable): arrive[(x * n_batches + r) * max_blocks + blk] counts the workgroups of
-    // virtual XCD x that have ENTERED block blk of batch r.  A workgroup enters block blk + 2 only once all of them
-    // have entered block blk -- with a bounded wait: results never depend on it.
-    unsigned* arrive;
-    int max_blocks, spin_limit, prefetch;
 };
 
 template <int K4>
@@ -134,33 +118,10 @@ __global__ __launch_bounds__(wg_threads(K4), 1) void xt_tail_kernel(const XtArgs
         int blk = 0;
         for (int b0 = d0; b0 < d1; b0 += a.doc_block, ++blk) {
             const int be = min(d1, b0 + a.doc_block);
-            if (a.arrive) {
-                if (threadIdx.x == 0) {
-                    unsigned* base = a.arrive + ((int64_t)x * a.n_batches + r) * a.max_blocks;
-                    __hip_atomic_fetch_add(base + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (blk >= 2) {
-                        int spins = 0;
-                        while (__hip_atomic_load(base + blk - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kSlots &&
-                               ++spins < a.spin_limit)
-                            __builtin_amdgcn_s_sleep(8);
-                    }
-                }
-            }
-            __syncthreads();          // the groups of a workgroup move through the document blocks together
-            // L2 prefetch of the NEXT block: this workgroup touches one dword of every 128-byte line of its 1/32 slice
-            // of the block's rows (the other 31 workgroups of the XCD touch theirs), so that by the time the sweep
-            // gets there the gathers hit L2 instead of waiting ~2 us each for HBM.  The value is consumed (discarded)
-            // at the end of this step: the load stays in flight under the gathers.
-            float pf = 0.f;
-            if (a.prefetch) {
-                const int n0 = be, n1 = min(d1, be + a.doc_block);
-                const int per = (n1 - n0 + kSlots - 1) / kSlots;
-                const int lines_per_row = (int)((a.ldg * 4 + 127) / 128);
-                const int i = threadIdx.x;
-                const int row = n0 + c * per + i / lines_per_row;
-                if (i < per * lines_per_row && row < min(n1, n0 + (c + 1) * per))
-                    pf = a.G[(int64_t)row * a.ldg + (i % lines_per_row) * 32];
-            }
+            // the groups of a workgroup move through the document blocks together.  (Measured and removed in round 3: a
+            // soft per-XCD rendezvous across workgroups -- no gain once the loads are balanced -- and an L2 prefetch of the
+            // next block by dword touches -- 1.84-1.96 ms against 1.50: the touching wave itself waits ~2 us for HBM.)
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (cur[u] >= endp[u]) continue;
@@ -210,7 +171,6 @@ __global__ __launch_bounds__(wg_threads(K4), 1) void xt_tail_kernel(const XtArgs
                     if (cnt < kGroup) break;
                 }
             }
-            asm volatile("" ::"v"(pf));
         }
         // this batch's accumulators -> partial[x][slot]
 #pragma unroll
@@ -282,7 +242,7 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
     plan->F = F;
     plan->K4 = (int)cdiv(cdiv(F, 4), kGroup);
     plan->nnz = rowptr_t_host[n_words];
-    plan->doc_block = doc_block_rows();
+    plan->doc_block = kDocBlock;
     plan->groups = wg_threads(plan->K4) / kGroup;
     const int64_t slots_per_batch = (int64_t)kSlots * plan->groups * kUnitsPerGroup;      // per virtual XCD
     std::vector<int> words;
@@ -296,9 +256,7 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
     std::vector<Unit> units;
     int n_batches = (int)std::max<int64_t>(1, cdiv((int64_t)words.size(), slots_per_batch));
     for (int it = 0; it < 8; ++it) {
-        // (unit_cap = how many average group shares one unit may weigh: 1 = best balance but 4 batches at the TwitterUS
-        //  shape, 2 = 3 batches: measured 1.50 against 1.59 ms)
-        const double share = unit_cap() * std::max(16.0, (double)plan->nnz / ((double)n_batches * kSlots * plan->groups));
+        const double share = kUnitCap * std::max(16.0, (double)plan->nnz / ((double)n_batches * kSlots * plan->groups));
         units.clear();
         for (int w : words) {
             const int64_t nz = rowptr_t_host[w + 1] - rowptr_t_host[w];
@@ -379,13 +337,9 @@ void geogcn_xt_plan_destroy(geogcn_xt_plan* plan) {
     delete plan;
 }
 
-static size_t xt_arrive_bytes(const geogcn_xt_plan* plan) {
-    return (((size_t)kNumXCD * plan->n_batches * plan->max_blocks * sizeof(unsigned)) + 255) & ~(size_t)255;
-}
-
 size_t geogcn_xt_workspace_bytes(const geogcn_xt_plan* plan) {
     if (!plan || plan->n_units == 0) return 0;
-    return xt_arrive_bytes(plan) + (size_t)kNumXCD * (size_t)plan->n_slots * (size_t)(plan->K4 * kGroup * 4) * sizeof(float);
+    return (size_t)kNumXCD * (size_t)plan->n_slots * (size_t)(plan->K4 * kGroup * 4) * sizeof(float);
 }
 
 int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const float* val_t, const float* G, int64_t ldg,
@@ -403,26 +357,9 @@ int geogcn_xt_dot_f32(const geogcn_xt_plan* plan, const int32_t* docidx_t, const
         const size_t need = geogcn_xt_workspace_bytes(plan);
         GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "xt_dot_f32: workspace too small (%zu < %zu)",
                        ws_bytes, need);
-        static const int rendezvous = [] {
-            const char* e = getenv("GEOGCN_XT_RENDEZVOUS");       // 1 = soft per-XCD rendezvous (experiment switch)
-            return (e && e[0] == '1') ? 1 : 0;
-        }();
-        static const int prefetch = [] {
-            // 1 = every workgroup touches its slice of the NEXT block's lines while the current block is swept.
-            // Measured (profiles/r02_xt_sweep.txt): slower -- 1.84-1.96 ms against 1.50-1.54 -- the touching wave itself
-            // waits ~2 us for HBM at the end of the step; off
-            const char* e = getenv("GEOGCN_XT_PREFETCH");
-            return (e && e[0] == '1') ? 1 : 0;
-        }();
-        unsigned* arrive = rendezvous ? (unsigned*)ws : nullptr;
-        if (arrive) {
-            const int zrc = zero_fill_async(arrive, xt_arrive_bytes(plan), st);
-            if (zrc) return zrc;
-        }
-        partial = (float*)((char*)ws + xt_arrive_bytes(plan));
+        partial = (float*)ws;
         XtArgs a{docidx_t, val_t, G, ldg, F, plan->d_unit_word, plan->d_unit_part, plan->d_wptr, plan->d_doc_lo,
-                 plan->n_words, plan->n_batches, plan->doc_block, partial, ldp, plan->n_slots, arrive, plan->max_blocks, 4000,
-                 prefetch};
+                 plan->n_words, plan->n_batches, plan->doc_block, partial, ldp, plan->n_slots};
         const dim3 grid((unsigned)(kNumXCD * kSlots));
         switch (plan->K4) {
 #define GEOGCN_XT(K)                                                                \

@@ -26,18 +26,15 @@ the CPU tests).  GEOGCN_DIST_EXCHANGE=a2a|allgather overrides the default (all-g
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import scipy.sparse as sps
 import torch
 
-from . import backend
+from . import backend, tuning
 
-# cost of one row in stored-edge equivalents when balancing the all-gather scheme's row split: the dense work of a row
-# (15 GEMMs + elementwise + its share of the X path: ~44 ns at the TwitterUS shape) over the SpMM cost of one stored edge
-# (6 products, ~0.97 ns) -- DESIGN.md section 5
-ROW_COST_IN_EDGES = 45.0
+# cost of one row in stored-edge equivalents when balancing the all-gather scheme's row split (tuning.py)
+ROW_COST_IN_EDGES = tuning.ROW_COST_IN_EDGES
 
 
 def balanced_bounds(indptr, world, row_cost=ROW_COST_IN_EDGES):
@@ -136,9 +133,9 @@ class Comm:
     def prepare(self, A_host):
         """Hook called with the host adjacency before anything is partitioned (row-split balancing)."""
 
-    def graph_operand(self, A_host, hub_row_bytes=None):
+    def graph_operand(self, A_host):
         K = backend.active()
-        return K.SparseOperand.from_scipy(A_host, self.device, dense_head=False, hub_row_bytes=hub_row_bytes)
+        return K.SparseOperand.from_scipy(A_host, self.device, dense_head=False)
 
     def matmul_target(self, F, tag=None, precision=None, direct=True):
         """Where the GEMM that produces the SpMM's dense operand should write (n_local x F)."""
@@ -169,40 +166,6 @@ class Comm:
 
     def all_reduce_sum_(self, t: torch.Tensor):
         return t
-
-
-class StreamOverlapComm(Comm):
-    """Single GPU: the graph SpMM runs on a SIDE HIP stream between graph_spmm_begin and _end, so that the work the
-    layer sweep enqueues in between (the highway gate's GEMMs) shares the device with it.  The SpMM is bound by
-    gather traffic from beyond the L2 and leaves MFMA pipes and most issue slots idle; the fp32 GEMM is
-    MFMA-bound -- measured with tools/cu_mask_probe.py: (SpMM, gate GEMM) 2.70 -> 2.50 ms, (SpMM^T, dWt, dH)
-    3.59 -> 3.34 ms.  Same kernels, same arithmetic; only the launch streams differ."""
-    exchange = 'stream'
-
-    def __init__(self, N, device):
-        super().__init__(N, device)
-        self.side = torch.cuda.Stream(device=device)
-
-    def graph_spmm_begin(self, A_csr, z, bias, act, F, tag=None):
-        K = backend.active()
-        main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        self.side.wait_event(ready)                  # the operand was produced on the main stream
-        with torch.cuda.stream(self.side):
-            out = K.spmm(A_csr, z, bias=bias, act=act, F=F)
-            done = torch.cuda.Event()
-            done.record(self.side)
-        # caching-allocator bookkeeping: both tensors are used on a stream other than the one that allocated them
-        z.t.record_stream(self.side)
-        out.t.record_stream(main)
-        if bias is not None:
-            bias.record_stream(self.side)
-        return dict(out=out, done=done, work=None)
-
-    def graph_spmm_end(self, h):
-        torch.cuda.current_stream(self.device).wait_event(h['done'])
-        return h['out']
 
 
 class _StreamWork:
@@ -337,7 +300,7 @@ class HostStagedGloo:
 def backend_name():
     """GEOGCN_DIST_BACKEND: 'torch' (default: torch.distributed's nccl = RCCL), 'native' (the library's geogcn_comm_* entry
     points for the data path), 'staged-gloo' (one-GPU functional check, see HostStagedGloo)."""
-    return os.environ.get('GEOGCN_DIST_BACKEND', 'torch')
+    return tuning.dist_backend()
 
 
 def init_process_group(local_rank):
@@ -361,7 +324,7 @@ class TorchDistComm(Comm):
     through torch.distributed and the data path through the library's own RCCL entry points (NativeRccl); or
     GEOGCN_DIST_BACKEND=staged-gloo for the one-GPU functional check (HostStagedGloo)."""
 
-    def __init__(self, N, device, group=None, exchange=None):
+    def __init__(self, N, device, group=None, exchange=None, balance=True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -375,14 +338,14 @@ class TorchDistComm(Comm):
             self.dist = NativeRccl(self.world, self.rank, box[0], device)
         self.part = RowPartition(N, self.world, self.rank)
         self.device = device
-        self.exchange = exchange or os.environ.get('GEOGCN_DIST_EXCHANGE', 'auto')
+        self.exchange = exchange or tuning.DIST_EXCHANGE
         if self.exchange == 'auto':
             # at 2 ranks both schemes move the same bytes and the all-gather needs no repacking; from 3 ranks on
             # the all-to-all moves (w-1)/w * 2/w of what the all-gather delivers to every rank
             self.exchange = 'a2a' if self.world >= 3 else 'allgather'
         if self.exchange not in ('a2a', 'allgather'):
             raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a' or 'allgather', got %r" % self.exchange)
-        self.balance = os.environ.get('GEOGCN_DIST_BALANCE', '1') != '0'
+        self.balance = bool(balance)        # all-gather scheme: cost-balanced row split (False: uniform, the A/B)
         self._bufs = {}
 
     # -- row split ---------------------------------------------------------------------------------------
@@ -398,7 +361,7 @@ class TorchDistComm(Comm):
                 self._bufs = {}
 
     # -- constant operand ----------------------------------------------------------------------------
-    def graph_operand(self, A_host, hub_row_bytes=None):
+    def graph_operand(self, A_host):
         """A_hat as this exchange scheme needs it: the whole matrix (a2a) or the local row block (allgather), columns
         (and, for a2a, rows) in slot coordinates."""
         K = backend.active()
@@ -415,8 +378,8 @@ class TorchDistComm(Comm):
         same = (Af.shape == Ab.shape and np.array_equal(Af.indptr, Ab.indptr) and np.array_equal(Af.indices, Ab.indices)
                 and np.array_equal(Af.data, Ab.data))
         # (slot positions are monotone in the global index: the stored order, hence the accumulation order, is unchanged)
-        fwd = K.CSR(Af, self.device, hub_row_bytes=hub_row_bytes)
-        bwd = fwd if same else K.CSR(Ab, self.device, hub_row_bytes=hub_row_bytes)
+        fwd = K.CSR(Af, self.device)
+        bwd = fwd if same else K.CSR(Ab, self.device)
         return K.SparseOperand(fwd, bwd, same)
 
     # -- buffers ---------------------------------------------------------------------------------------

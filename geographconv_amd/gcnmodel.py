@@ -10,13 +10,12 @@ them (gcnmain.py:172-179,221,226) and are uploaded once per distinct matrix."""
 from __future__ import annotations
 
 import logging
-import os
 import sys
 
 import numpy as np
 import scipy.sparse as sps
 
-from . import backend
+from . import backend, tuning
 from .dist import Comm
 from .nn import init as _init
 from .nn import layers as L
@@ -410,17 +409,14 @@ class GraphConv():
         self._graph_cache = {}
         self._idx_cache = {}
         self._injected_mask = None
-        self.hub_row_bytes = None         # SpMM cache hint (ops.CSR): off -- no gain at full-row granularity
         self._force_dist = False          # tests: run the partitioned code path at world_size 1
         # capture the whole f_train step (~110 launches) in a hipGraph after two eager steps and replay it: for
         # small graphs (CMU shape) the step is bound by launch overhead, not by the GPU.  Opt-in (argument or
-        # GEOGCN_HIP_GRAPH=1); single GPU only; the inputs of f_train must stay the same objects between calls.
-        self.hip_graph = (os.environ.get('GEOGCN_HIP_GRAPH', '0') == '1') if hip_graph is None else bool(hip_graph)
+        # GEOGCN_HIP_GRAPH=1, tuning.py); single GPU only; the inputs of f_train must stay the same objects between calls.
+        self.hip_graph = tuning.HIP_GRAPH if hip_graph is None else bool(hip_graph)
         self._hg = None
         self._step_serial = 0             # f_train calls so far (freshness of outputs that live in a captured step's buffers)
         self._adam_state_dev = None
-        self.stream_overlap = os.environ.get('GEOGCN_STREAM_OVERLAP', '0') == '1'      # measured: no net gain, off
-        self._overlap_comm = None
         self.best_params = None
         logging.info('highway is {}'.format(self.highway))
 
@@ -470,20 +466,10 @@ class GraphConv():
         return comm.world > 1 or (self._force_dist and hasattr(comm, 'dist'))
 
     def _layer_comm(self, comm):
-        """What the layers get as `comm`: the communicator when the graph is partitioned; on one GPU the
-        stream-overlap helper (SpMM on a side stream under the highway gate's GEMMs) when switched on
-        (GEOGCN_STREAM_OVERLAP=1; off by default: in the model it gave 30.4 ms against 30.1 ms -- the pairs overlap
-        by 6-7 % but the gating mix can no longer ride in the SpMM's epilogue), never in the bf16 configuration
-        (its SpMM operand format is not wired through the two-phase path) or when the step is captured as a hipGraph."""
-        if self._dist(comm):
-            return comm
-        if (self.highway and self.stream_overlap and not self.hip_graph and self.device.type == 'cuda'
-                and (self.gemm_precision or backend.active().GEMM_PRECISION) != 'bf16'):
-            if self._overlap_comm is None or self._overlap_comm.part.N != comm.part.N:
-                from .dist import StreamOverlapComm
-                self._overlap_comm = StreamOverlapComm(comm.part.N, self.device)
-            return self._overlap_comm
-        return None
+        """What the layers get as `comm`: the communicator when the graph is partitioned, None on one GPU.  (A side-stream
+        overlap of the graph product with the gate's GEMMs was measured in rounds 1-2 -- 30.4 against 30.1 ms per step: the
+        pairs overlap by 6-7 % but the gating mix can no longer ride in the SpMM's epilogue -- and removed in round 3.)"""
+        return comm if self._dist(comm) else None
 
     # -- device residency of the constant inputs ------------------------------------------------
     def _comm_for(self, N):
@@ -516,12 +502,12 @@ class GraphConv():
             comm.prepare(A)               # (all-gather scheme: cost-balanced row split, cut from this adjacency)
         part = comm.part
         if self._dist(comm):
-            dA = comm.graph_operand(A, hub_row_bytes=self.hub_row_bytes)
+            dA = comm.graph_operand(A)
             dX = K.SparseOperand.from_scipy(part.local_rows(sps.csr_matrix(X)), self.device)
         else:
             # (dense_head=False: the dense-panel split of the transpose is for X; the graph convolution multiplies by
             #  A^T as one CSR -- it only exists when A is not symmetric)
-            dA = K.SparseOperand.from_scipy(A, self.device, dense_head=False, hub_row_bytes=self.hub_row_bytes)
+            dA = K.SparseOperand.from_scipy(A, self.device, dense_head=False)
             dX = K.SparseOperand.from_scipy(X, self.device)
         hit = {'X_ref': X_in, 'A_ref': A_in, 'X': dX, 'A': dA, 'N': N, 'comm': comm, 'ro': ro, 'A_host': A}
         self._graph_cache = {key: hit}          # one graph resident at a time
@@ -544,7 +530,7 @@ class GraphConv():
         row_of = np.repeat(np.arange(At.shape[0], dtype=np.int64), np.diff(At.indptr))
         indptr = np.concatenate([[0], np.cumsum(np.bincount(row_of[sel], minlength=At.shape[0]))])
         M = sps.csr_matrix((At.data[sel], At.indices[sel], indptr.astype(np.int32)), shape=At.shape)
-        op = g['comm'].graph_operand(M, hub_row_bytes=None) if self._dist(g['comm']) else None
+        op = g['comm'].graph_operand(M) if self._dist(g['comm']) else None
         csr = op.fwd if op is not None else backend.active().CSR(M, self.device)
         g['A_tr'] = (key, csr)
         return csr

@@ -12,7 +12,7 @@ from collections import OrderedDict, deque
 
 import numpy as np
 
-from .. import backend
+from .. import backend, tuning
 from . import init as _init
 from . import nonlinearities as _nl
 
@@ -219,16 +219,14 @@ class InputLayer(Layer):
 
 
 def _fuse_highway(fp32_operand):
-    """GEOGCN_FUSE_HIGHWAY = f32 (default) | all | none: which SpMM operand formats get the gating mix fused."""
-    import os
-    mode = os.environ.get('GEOGCN_FUSE_HIGHWAY', 'f32')
+    """tuning.FUSE_HIGHWAY = 'f32' (default) | 'all' | 'none': which SpMM operand formats get the gating mix fused."""
+    mode = tuning.FUSE_HIGHWAY
     return mode == 'all' or (mode == 'f32' and fp32_operand)
 
 
 def _fuse_gemms():
-    """GEOGCN_FUSE_GEMMS = 1 (default) | 0: the highway block's two weights in one launch (A/B switch)."""
-    import os
-    return os.environ.get('GEOGCN_FUSE_GEMMS', '1') != '0'
+    """tuning.FUSE_GEMMS: the highway block's two weights in one launch (tests flip it for the A/B)."""
+    return bool(tuning.FUSE_GEMMS)
 
 
 def _accumulate(dst, src):

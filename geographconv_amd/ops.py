@@ -6,13 +6,12 @@ a GPU is missing the call raises (no eager / CPU fallback)."""
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import scipy.sparse as sps
 import torch
 
-from . import _ffi
+from . import _ffi, tuning
 from ._ffi import ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_TANH, check  # noqa: F401
 
 
@@ -214,19 +213,11 @@ class Workspace:
         return self.t
 
 
-# Bytes of the gathered operand that the hub hint tries to keep resident in each XCD's 4 MB L2.
-HUB_L2_BUDGET_BYTES = 3 * 2 ** 20
-
-
 class CSR:
-    """Device CSR (int32 indices, fp32 values) + the long-row split plan for the SpMM kernel.
+    """Device CSR (int32 indices, fp32 values, rows in ascending column order) + the long-row split plan for the SpMM
+    kernel."""
 
-    `hub_row_bytes` (bytes of one gathered row of the dense operand, e.g. 1200 for F=300) switches
-    the cache hint on: the columns referenced most often -- as many as fit HUB_L2_BUDGET_BYTES -- are
-    declared hubs, each row's nonzeros are reordered [hubs | rest] (sorted inside each part) and the
-    kernel gathers the rest with non-temporal loads so the hub rows stay in L2."""
-
-    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None, hub_row_bytes=None):
+    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None):
         require_gpu()
         m = sps.csr_matrix(m)
         if long_row_nnz is None:
@@ -246,22 +237,6 @@ class CSR:
         indptr = np.ascontiguousarray(m.indptr, dtype=np.int32)
         indices = np.ascontiguousarray(m.indices, dtype=np.int32)
         data = np.ascontiguousarray(m.data, dtype=np.float32)
-        rowsplit = None
-        self.n_hubs = 0
-        if hub_row_bytes and self.nnz > 0:
-            k = int(HUB_L2_BUDGET_BYTES // max(1, hub_row_bytes))
-            refs = np.bincount(indices, minlength=m.shape[1])
-            if 0 < k < m.shape[1] and (refs > 0).sum() > k:
-                hubs = np.argpartition(-refs, k)[:k]
-                is_hub = np.zeros(m.shape[1], dtype=bool)
-                is_hub[hubs] = True
-                nz_hub = is_hub[indices]
-                row_of = np.repeat(np.arange(m.shape[0], dtype=np.int64), np.diff(indptr))
-                order = np.lexsort((indices, ~nz_hub, row_of))            # row, hubs first, then column
-                indices, data = indices[order], data[order]
-                hub_per_row = np.bincount(row_of[nz_hub], minlength=m.shape[0]).astype(np.int32)
-                rowsplit = np.ascontiguousarray(indptr[:-1] + hub_per_row, dtype=np.int32)
-                self.n_hubs = k
         self.rowptr_host = indptr
         self.colidx_host = indices          # (host copy: plan builders walk the structure, e.g. geogcn_xt_plan_create)
         self.rowptr = torch.from_numpy(indptr).to(device)
@@ -271,7 +246,6 @@ class CSR:
         self._plan = C.c_void_p(0)
         lib = _ffi.lib()
         check(lib.geogcn_spmm_plan_create(self.shape[0], indptr.ctypes.data_as(C.c_void_p),
-                                          rowsplit.ctypes.data_as(C.c_void_p) if rowsplit is not None else None,
                                           int(long_row_nnz), int(chunk_nnz), C.byref(self._plan)),
               'spmm_plan_create')
         self.n_long_rows = int(lib.geogcn_spmm_plan_num_long_rows(self._plan))
@@ -334,7 +308,7 @@ _gemm_ws = {}
 # How the activation x weight products are formed (include/geogcn.h GEOGCN_GEMM_*): 'f32' = exact fp32
 # MFMA, 'bf16x3' = three-term bf16 split (fp32-class accuracy, HBM-bound), 'bf16' = BASELINE config 5.
 GEMM_PRECISIONS = {'f32': _ffi.GEMM_F32, 'bf16x3': _ffi.GEMM_BF16X3, 'bf16': _ffi.GEMM_BF16}
-GEMM_PRECISION = os.environ.get('GEOGCN_GEMM_PRECISION', 'f32')
+GEMM_PRECISION = tuning.GEMM_PRECISION
 
 
 def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=None, act=ACT_NONE,
@@ -612,22 +586,7 @@ def reg_penalty(p, regmask, l1, l2, out=None):
     return out
 
 
-# A column of X whose density exceeds this is cheaper to multiply as part of a DENSE panel on the MFMA
-# pipe (2*N*F flop at ~100 TFLOP/s) than as nnz row gathers (nnz * 4F bytes at the ~7 TB/s beyond-L2
-# ceiling): break-even nnz/N = 2 * 7e12 / (4 * 1e14) = 3.5 %.
-DENSE_HEAD_DENSITY = 0.035
-DENSE_HEAD_MAX_COLS = 512
-
-
-# A bag-of-words X is multiplied in two parts when its column distribution is Zipfian: the columns denser than
-# DENSE_HEAD_DENSITY as a dense N x K panel on the MFMA pipe, the long tail as CSR.  The transposed tail product goes
-# through the document-blocked kernel (geogcn_xt_dot_f32) from XT_MIN_NNZ stored tail entries on (below that dS0 sits
-# in the L2 / Infinity Cache anyway and the plain row gather is as fast).
-XT_MIN_NNZ = int(os.environ.get('GEOGCN_XT_MIN_NNZ', 1_000_000))
-XT_MAX_F = int(os.environ.get('GEOGCN_XT_MAX_F', 320))
-# forward X.W0: the tail's W0 rows are gathered in column slabs of this many floats so that the slab (n_tail_words x
-# slab x 4 bytes) stays inside one XCD's 4 MB L2; 0 = one pass over all columns
-X_FWD_SLAB = int(os.environ.get('GEOGCN_X_FWD_SLAB', 0))
+# (thresholds of the X path -- dense head panel, document-blocked X^T sweep, hot rows in LDS -- live in tuning.py)
 
 
 class SparseOperand:
@@ -636,21 +595,21 @@ class SparseOperand:
     of an unweighted graph A^T == A exactly in fp32 (checked here, not assumed), so
     one CSR serves both directions; otherwise CSR(A^T) is built once on the host.
 
-    For a bag-of-words X (Zipfian columns) both products are split: the few columns denser than
-    DENSE_HEAD_DENSITY form a dense N x K panel (``head_dense``) multiplied on the MFMA pipe -- X^T . G by the
-    split-K GEMM, X . W by a GEMM against the K gathered rows of W -- and the long tail stays sparse:
-    ``bwd`` holds the tail rows of X^T (head rows empty), ``fwd_tail`` the tail columns of X."""
+    For a bag-of-words X (Zipfian columns) the TRANSPOSED product is split: the few columns denser than
+    tuning.DENSE_HEAD_DENSITY form a dense N x K panel (``head_dense``) whose X^T . G runs on the MFMA pipe (split-K GEMM),
+    and the long tail stays sparse: ``bwd`` holds the tail rows of X^T (head rows empty).  The forward product X . W
+    serves the hot rows of W from LDS instead (HotCSR)."""
 
-    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool, head_idx=None, head_dense=None, fwd_tail: CSR = None):
+    def __init__(self, fwd: CSR, bwd: CSR, symmetric: bool, head_idx=None, head_dense=None):
         self.fwd, self.bwd, self.symmetric = fwd, bwd, symmetric
-        self.head_idx, self.head_dense, self.fwd_tail = head_idx, head_dense, fwd_tail
+        self.head_idx, self.head_dense = head_idx, head_dense
         self.shape = fwd.shape
         self._xt_plans = {}
         self._hot = {}            # HotCSR per LDS capacity (forward X . W0 with the hot rows of W0 in LDS)
 
     def xt_plan(self, F):
         """Plan of the document-blocked X^T . G kernel for width F (built on first use; None when the tail is small)."""
-        if self.bwd is None or self.symmetric or self.bwd.nnz < XT_MIN_NNZ:
+        if self.bwd is None or self.symmetric or self.bwd.nnz < tuning.XT_MIN_NNZ:
             return None
         base = getattr(self.bwd, '_base', self.bwd)           # value-dropout variants share the structure's plans
         plans = base._xt_plans if hasattr(base, '_xt_plans') else self._xt_plans
@@ -660,11 +619,10 @@ class SparseOperand:
         return plan
 
     @staticmethod
-    def from_scipy(m, device, need_transpose=True, long_row_nnz=None, chunk_nnz=None, dense_head=True,
-                   hub_row_bytes=None):
+    def from_scipy(m, device, need_transpose=True, long_row_nnz=None, chunk_nnz=None, dense_head=True):
         m = sps.csr_matrix(m).astype(np.float32)
         m.sort_indices()
-        fwd = CSR(m, device, long_row_nnz, chunk_nnz, hub_row_bytes=hub_row_bytes)
+        fwd = CSR(m, device, long_row_nnz, chunk_nnz)
         if not need_transpose:
             return SparseOperand(fwd, None, False)
         sym = False
@@ -675,12 +633,12 @@ class SparseOperand:
                    and np.array_equal(mt.data, m.data))
         if sym:
             return SparseOperand(fwd, fwd, True)
-        head_idx = head_dense = fwd_tail = None
+        head_idx = head_dense = None
         if dense_head and m.shape[0] > 0:
             col_nnz = np.diff(mt.indptr)
-            cand = np.nonzero(col_nnz >= DENSE_HEAD_DENSITY * m.shape[0])[0]
-            if len(cand) > DENSE_HEAD_MAX_COLS:
-                cand = cand[np.argsort(-col_nnz[cand], kind='stable')[:DENSE_HEAD_MAX_COLS]]
+            cand = np.nonzero(col_nnz >= tuning.DENSE_HEAD_DENSITY * m.shape[0])[0]
+            if len(cand) > tuning.DENSE_HEAD_MAX_COLS:
+                cand = cand[np.argsort(-col_nnz[cand], kind='stable')[:tuning.DENSE_HEAD_MAX_COLS]]
             cand = np.sort(cand)
             if len(cand) >= 16:
                 panel = DMat(m.shape[0], len(cand), device)
@@ -693,16 +651,9 @@ class SparseOperand:
                 mt = sps.csr_matrix(mt)
                 mt.eliminate_zeros()
                 mt.sort_indices()
-                # the same tail, row-major: X with the head columns removed (stored order = column order, as in X)
-                sel = keep[m.indices]
-                row_of = np.repeat(np.arange(m.shape[0], dtype=np.int64), np.diff(m.indptr))
-                indptr = np.concatenate([[0], np.cumsum(np.bincount(row_of[sel], minlength=m.shape[0]))]).astype(np.int32)
-                tail = sps.csr_matrix((m.data[sel], m.indices[sel], indptr), shape=m.shape)
-                # (rows of X are short: no row splitting, so the accumulate form starts every row from the GEMM's value)
-                fwd_tail = CSR(tail, device, long_row_nnz=1 << 30, chunk_nnz=128)
-        bwd = CSR(mt, device, long_row_nnz, chunk_nnz, hub_row_bytes=hub_row_bytes if head_dense is None else None)
+        bwd = CSR(mt, device, long_row_nnz, chunk_nnz)
         bwd._xt_plans = {}
-        return SparseOperand(fwd, bwd, False, head_idx, head_dense, fwd_tail)
+        return SparseOperand(fwd, bwd, False, head_idx, head_dense)
 
 
 class XtPlan:
@@ -734,7 +685,7 @@ class _CSRValues:
         self._base = base
         self.val = val
         for k in ('shape', 'nnz', 'rowptr', 'colidx', 'rowptr_host', 'colidx_host', 'device', '_plan', '_ws', 'n_long_rows',
-                  'n_chunks', 'n_hubs'):
+                  'n_chunks'):
             setattr(self, k, getattr(base, k))
 
 
@@ -762,7 +713,7 @@ def sparse_dropout(x: SparseOperand, p, seed, call):
         head = DMat(x.head_dense.n, x.head_dense.F, x.head_dense.device, ld=x.head_dense.ld)
         check(lib.geogcn_dropout_panel_f32(head.n, head.F, _p(x.head_dense.t), head.ld, _p(x.head_idx), V, float(p), int(seed),
                                            int(call), _p(head.t), _stream()), 'dropout_panel_f32')
-    return SparseOperand(fwd, bwd, False, x.head_idx, head, None if x.fwd_tail is None else csr(x.fwd_tail, False))
+    return SparseOperand(fwd, bwd, False, x.head_idx, head)
 
 
 def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
@@ -770,7 +721,7 @@ def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     # column slabs of <= XT_MAX_F: the kernel keeps 2 x F/64 float4 accumulators per lane in registers; up to 320 columns
     # that leaves room for 1024-thread workgroups, beyond it halves the threads and doubles the batches (F = 600 in one
     # piece: 5.5 ms, slower than the row gather's 4.0; as two slabs of 300: see DESIGN.md 4.2)
-    n_slab = -(-G.F // XT_MAX_F)
+    n_slab = -(-G.F // tuning.XT_MAX_F)
     width = pad4(-(-G.F // n_slab))
     if x.xt_plan(min(width, G.F)) is not None:
         # tail rows through the document-blocked kernel (every row written; head rows as zeros)
@@ -828,50 +779,19 @@ def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, ac
     return out
 
 
-# How X . W0 is formed (GEOGCN_X_FWD): 'hot' = hot rows of W0 from LDS (default from HOT_MIN_NNZ stored entries on),
-# 'split' = dense head panel GEMM + CSR tail, 'plain' = one CSR gather kernel
-X_FWD_MODE = os.environ.get('GEOGCN_X_FWD', 'hot')
-HOT_MIN_NNZ = int(os.environ.get('GEOGCN_HOT_MIN_NNZ', 2_000_000))
-
-
 def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE):
-    """out = act(x . W + bias) for a sparse input x (S.structured_dot(X, W0), reference gcnmodel.py:39-42).  With a
-    dense head panel: the K hot vocabulary rows of W are gathered into a K x F matrix and multiplied by the panel on the
-    MFMA pipe (raw product), then the CSR tail continues each row from that value (bias and activation in its epilogue)."""
-    if X_FWD_MODE == 'hot' and isinstance(x.fwd, CSR) and x.fwd.nnz >= HOT_MIN_NNZ and not x.symmetric:
+    """out = act(x . W + bias) for a sparse input x (S.structured_dot(X, W0), reference gcnmodel.py:39-42): the hot rows
+    of W from LDS (geogcn_spmm_csr_hot_f32) from tuning.HOT_MIN_NNZ stored entries on, the plain row gather below.
+    (Measured and removed: the dense head panel on the MFMA pipe + CSR tail continuing the rows -- 1.69 ms against
+    1.32 -- and its column-slab variant)"""
+    if isinstance(x.fwd, CSR) and x.fwd.nnz >= tuning.HOT_MIN_NNZ and not x.symmetric:
         cap = int(_ffi.lib().geogcn_spmm_hot_capacity(W.F))
         if cap > 0:
             hot = x._hot.get(cap)
             if hot is None:
                 hot = x._hot[cap] = HotCSR(x.fwd, x.fwd.val.cpu().numpy(), cap)
             return spmm_hot(hot, W, out=out, bias=bias, act=act)
-    if x.head_dense is None or x.fwd_tail is None or X_FWD_MODE != 'split':
-        return spmm(x.fwd, W, out=out, bias=bias, act=act)
-    K = x.head_dense.F
-    Wh = DMat(K, W.F, W.device)
-    gather_rows(W, x.head_idx, out=Wh.t)
-    out = gemm(x.head_dense, Wh, out=out, precision='f32')
-    if X_FWD_SLAB and W.F > X_FWD_SLAB:
-        # column slabs: the tail's slab of W (n_words x slab x 4 B) stays inside one XCD's L2 across the sweep
-        for c0 in range(0, W.F, X_FWD_SLAB):
-            c1 = min(W.F, c0 + X_FWD_SLAB)
-            _spmm_cols(x.fwd_tail, W, out, bias, act, c0, c1)
-        return out
-    return spmm(x.fwd_tail, W, out=out, bias=bias, act=act, accumulate=True)
-
-
-def _spmm_cols(A: CSR, B: DMat, out: DMat, bias, act, c0, c1):
-    """out[:, c0:c1] = act(out[:, c0:c1] + A . B[:, c0:c1] + bias[c0:c1]) -- a column window of the accumulate form
-    (c0 % 4 == 0: the window starts on a float4)."""
-    lib = _ffi.lib()
-    F = c1 - c0
-    ws = A._ws.get(lib.geogcn_spmm_workspace_bytes(A._plan, F))
-    bptr = C.c_void_p(B.t.data_ptr() + 4 * c0)
-    optr = C.c_void_p(out.t.data_ptr() + 4 * c0)
-    biasp = C.c_void_p(bias.data_ptr() + 4 * c0) if bias is not None else C.c_void_p(0)
-    check(lib.geogcn_spmm_csr_acc_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), bptr, B.ld,
-                                      optr, out.ld, F, biasp, act, _p(ws), ws.numel(), _stream()), 'spmm_csr_acc_f32')
-    return out
+    return spmm(x.fwd, W, out=out, bias=bias, act=act)
 
 
 class SpmmTimer:
@@ -884,11 +804,18 @@ class SpmmTimer:
         check(_ffi.lib().geogcn_timer_create(int(capacity), C.byref(self._h)), 'timer_create')
         self.capacity = int(capacity)
 
-    def attach(self, only_F=0, only_nnz=0):
-        check(_ffi.lib().geogcn_timer_attach_spmm(self._h, int(only_F), int(only_nnz)), 'timer_attach_spmm')
+    def attach(self, csr: CSR, only_F=0):
+        """Sample the plain products that run on `csr`'s plan (width only_F; 0 = any).  The timer is a handle held by the
+        caller and attached to that one plan: the library keeps no global state."""
+        self.detach()
+        check(_ffi.lib().geogcn_spmm_plan_attach_timer(csr._plan, self._h, int(only_F)), 'spmm_plan_attach_timer')
+        self._csr = csr
 
     def detach(self):
-        check(_ffi.lib().geogcn_timer_attach_spmm(None, 0, 0), 'timer_attach_spmm')
+        csr = getattr(self, '_csr', None)
+        if csr is not None and csr._plan:
+            check(_ffi.lib().geogcn_spmm_plan_attach_timer(csr._plan, None, 0), 'spmm_plan_attach_timer')
+        self._csr = None
 
     def read_ms(self):
         buf = (C.c_float * self.capacity)()
@@ -898,6 +825,7 @@ class SpmmTimer:
 
     def __del__(self):
         try:
+            self.detach()
             if self._h:
                 _ffi.lib().geogcn_timer_destroy(self._h)
                 self._h = C.c_void_p(0)

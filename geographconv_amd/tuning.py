@@ -1,0 +1,56 @@
+"""The ONE table of switches and thresholds of the hot path.
+
+Environment variables read by product code -- four, all about WHICH configuration runs, none about how a kernel runs:
+
+  GEOGCN_GEMM_PRECISION  f32 (default) | bf16x3 | bf16      default of GraphConv(gemm_precision=...) / -gemm-precision
+  GEOGCN_HIP_GRAPH       0 (default) | 1                    default of GraphConv(hip_graph=...): capture + replay the step
+  GEOGCN_DIST_EXCHANGE   auto (default) | a2a | allgather   default of TorchDistComm(exchange=...)
+  GEOGCN_DIST_BACKEND    torch (default) | native | staged-gloo   transport of the partitioned path (dist.backend_name)
+
+(`GEOGCN_BUILD_DEFINES` is read by build.py only: ablation builds.)  Everything else is a module attribute below: a
+documented constant with the measurement that set it.  Tests that need an A/B flip the attribute (monkeypatch), nothing
+reads the environment behind the caller's back.  Kernel-side constants that used to be getenv() switches are now
+`constexpr` next to the kernel they belong to (spmm.hip kRowBlock, xt.hip kDocBlock / kUnitCap, elementwise.hip hw_parts,
+gemm.hip wide_bn); the experiments they guarded are recorded in DESIGN.md sections 4.1-4.3 and were removed from the
+code in round 3: the SpMM hub hint (non-temporal tail loads), the split X.W0 forward (dense head GEMM + CSR tail, and its
+column-slab variant), the side-stream overlap of the graph product with the gate GEMMs, the X^T sweep's L2 prefetch and
+per-XCD rendezvous."""
+from __future__ import annotations
+
+import os
+
+# ---- configuration defaults (the four environment variables) --------------------------------------------------------
+GEMM_PRECISION = os.environ.get('GEOGCN_GEMM_PRECISION', 'f32')
+HIP_GRAPH = os.environ.get('GEOGCN_HIP_GRAPH', '0') == '1'
+DIST_EXCHANGE = os.environ.get('GEOGCN_DIST_EXCHANGE', 'auto')
+
+
+def dist_backend():
+    return os.environ.get('GEOGCN_DIST_BACKEND', 'torch')
+
+
+# ---- fusion A/B (both on; tests flip them to prove the fused launches equal the separate ones) ----------------------
+# highway block: (Z, T) = (H.Wh, sigmoid(H.Wt + bt)), (dWh, dWt), dH in one GEMM launch each (-0.46 ms per TWUS step)
+FUSE_GEMMS = True
+# gating mix T*Hc + (1-T)*H in the SpMM's epilogue: 'f32' = for the fp32 gathered operand only (on the bf16 operand the
+# epilogue's T / H loads cost more than the separate pass: 1.82 ms fused against 1.10 + 0.41), 'all', 'none'
+FUSE_HIGHWAY = 'f32'
+
+# ---- X path thresholds ---------------------------------------------------------------------------------------------
+# a column of X denser than this is cheaper as part of a dense N x K panel on the MFMA pipe (2NF flop at ~100 TF) than
+# as nnz row gathers (nnz * 4F bytes at the ~7 TB/s beyond-L2 ceiling): break-even nnz/N = 3.5 %
+DENSE_HEAD_DENSITY = 0.035
+DENSE_HEAD_MAX_COLS = 512
+# X^T . dS0 goes through the document-blocked sweep (geogcn_xt_dot_f32) from this many stored tail entries on; below,
+# dS0 sits in the L2 / Infinity Cache anyway and the plain row gather is as fast
+XT_MIN_NNZ = 1_000_000
+# ... in column slabs of at most this width (2 x F/64 float4 accumulators per lane: up to 320 columns 1024-thread
+# workgroups fit; F = 600 in one piece 5.5 ms, as two slabs of 300 3.0 ms)
+XT_MAX_F = 320
+# X . W0 with the hot rows of W0 in LDS (geogcn_spmm_csr_hot_f32) from this many stored entries on
+HOT_MIN_NNZ = 2_000_000
+
+# ---- partitioned path ----------------------------------------------------------------------------------------------
+# all-gather scheme: cost of one row in stored-edge equivalents when the row split is balanced (dense work of a row
+# ~44 ns over ~0.97 ns per stored edge for the 6 products of a step)
+ROW_COST_IN_EDGES = 45.0

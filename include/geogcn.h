@@ -54,13 +54,8 @@ const char* geogcn_last_error(void);
  * bias may be NULL.  plan may be NULL (no row splitting: correct, slow on hub rows).          */
 typedef struct geogcn_spmm_plan geogcn_spmm_plan;
 
-/* rowsplit_host (nullable, n_rows entries, rowptr[r] <= rowsplit[r] <= rowptr[r+1]) is a CACHE HINT:
- * the caller has ordered each row's nonzeros so that [rowptr[r], rowsplit[r]) reference the "hub"
- * rows of B it wants kept in the 4 MB per-XCD L2; those are gathered with the default policy, the rest
- * [rowsplit[r], rowptr[r+1]) with non-temporal loads so that they do not evict the hubs.  Results do
- * not depend on it.                                                                               */
-int    geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, const int32_t* rowsplit_host,
-                               int32_t long_row_nnz, int32_t chunk_nnz, geogcn_spmm_plan** out);
+int    geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz, int32_t chunk_nnz,
+                               geogcn_spmm_plan** out);
 void   geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan);
 int64_t geogcn_spmm_plan_num_long_rows(const geogcn_spmm_plan* plan);
 int64_t geogcn_spmm_plan_num_chunks(const geogcn_spmm_plan* plan);
@@ -133,16 +128,17 @@ int geogcn_spmm_csr_highway_f32(const geogcn_spmm_plan* plan, int32_t n_rows, in
                                 const float* H, int64_t ld, float* Hc, float* Hout, void* ws, size_t ws_bytes,
                                 void* stream);
 
-/* profiling aid (bench.py's roofline leg): a pool of hipEvent pairs owned by the library.  While a
- * timer is attached, every geogcn_spmm_csr_f32 / _bf16b call (not the fused _highway one) whose F equals `only_F` and whose nnz equals
- * `only_nnz` (0 = any) records one
- * (begin, end) pair around the whole product (spmm_rows_kernel + the long rows' combine kernel) on the call's stream,
- * until the pool is full.  geogcn_timer_read_ms synchronises the recorded events and returns the
- * per-launch durations.  Detach with geogcn_timer_attach_spmm(NULL, 0, 0).                          */
+/* profiling aid (bench.py's roofline leg): a pool of hipEvent pairs owned by the CALLER and attached to ONE plan handle
+ * (no library-global state: two models, or two threads with their own plans, do not see each other's timer).  While a
+ * timer is attached to `plan`, every geogcn_spmm_csr_f32 / _bf16b call on that plan (not the fused _highway one) whose F
+ * equals `only_F` (0 = any) records one (begin, end) pair around the whole product (spmm_rows_kernel + the long rows'
+ * combine kernel) on the call's stream, until the pool is full.  geogcn_timer_read_ms synchronises the recorded events
+ * and returns the per-launch durations.  Detach with geogcn_spmm_plan_attach_timer(plan, NULL, 0) -- before destroying
+ * the timer.                                                                                                     */
 typedef struct geogcn_timer geogcn_timer;
 int  geogcn_timer_create(int32_t capacity, geogcn_timer** out);
 void geogcn_timer_destroy(geogcn_timer* t);
-int  geogcn_timer_attach_spmm(geogcn_timer* t, int32_t only_F, int64_t only_nnz);
+int  geogcn_spmm_plan_attach_timer(geogcn_spmm_plan* plan, geogcn_timer* t, int32_t only_F);
 int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32_t* n_out);
 
 /* ---- K5/K6: T.dot / Gemm -----------------------------------------------------------------

@@ -68,11 +68,10 @@ def test_no_product_import_of_oracle():
 def test_every_entry_point_rejects_null_and_negative_arguments(built):
     """Error behaviour at the boundary (include/geogcn.h conventions): with every pointer NULL and positive sizes, and
     with negative sizes, every int-returning entry point answers < 0 with a message -- before any HIP call, so this runs
-    without a GPU -- and never crashes.  (geogcn_timer_attach_spmm(NULL) is the documented way to detach.)"""
+    without a GPU -- and never crashes."""
     import ctypes as C
     lib = _ffi.lib()
-    skip = {'geogcn_version', 'geogcn_comm_available', 'geogcn_comm_world', 'geogcn_comm_rank', 'geogcn_spmm_hot_capacity',
-            'geogcn_timer_attach_spmm'}
+    skip = {'geogcn_version', 'geogcn_comm_available', 'geogcn_comm_world', 'geogcn_comm_rank', 'geogcn_spmm_hot_capacity'}
     checked = 0
     for name, (res, args) in _ffi.SIGNATURES.items():
         if res is not _ffi.c_i32 or name in skip:

@@ -93,23 +93,52 @@ def test_real_kernels_under_a_real_partition_on_one_gpu(world):
     assert 'DIST_GPU_OK world=%d' % world in r.stdout
 
 
-def test_bench_multi_rank_branches_on_one_gpu():
-    """bench.py's N > 1 code (rank-0-only JSON line, max-over-ranks time, per-rank roofline description, world size in
-    `config`) executed at 2 ranks that share cuda:0 with the collectives staged through the host -- a functional check,
-    never a measurement (the line says so)."""
+def _run_bench_self_launched(extra, timeout):
+    """Exactly the driver's command shape -- `python bench.py --gpus N ...`, NO torchrun, WORLD_SIZE unset -- with the ranks
+    sharing cuda:0 and the collectives staged through the host (a functional check, never a measurement)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GEOGCN_DIST_BACKEND='staged-gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--shape', 'cmu', '--steps', '3', '--warmup', '1']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py')] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1                                   # rank 0 only
-    d = json.loads(lines[0])
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 only
+    assert r.stdout.strip().splitlines()[-1] == lines[0]      # and it is the LAST line of stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks_and_checks_itself():
+    """`python bench.py --gpus 2 --shape cmu --steps 3 --warmup 1` by itself: bench.py starts the two ranks (one process per
+    GPU through torch.distributed.run), rank 0 prints ONE line carrying the world size it saw, both exchange schemes
+    (`value` = the default, `alt` = the other) and a `partition_check` block: two dropout-free steps through every scheme
+    against the same process's un-partitioned steps."""
+    d = _run_bench_self_launched(['--gpus', '2', '--shape', 'cmu', '--steps', '3', '--warmup', '1'], 900)
     assert d['n_gpus'] == 2 and d['config']['world_size'] == 2 and d['config']['parallelism'] == 'rows2'
+    assert d['config']['dist']['world_size_seen'] == 2 and d['config']['dist']['staged'] is True
     assert 'NOT a measurement' in d['config']['collectives'] and d['value'] > 0 and d['scaling'] == 'strong'
     assert d['roofline']['kernel'] and np.isfinite(d['config']['train_loss_last'])
+    assert d['config']['dist']['exchange'] == 'allgather' and d['alt']['exchange'] == 'a2a' and d['alt']['value'] > 0
+    pc = d['partition_check']
+    for scheme in ('allgather', 'a2a'):
+        c = pc[scheme]
+        assert c['max_abs_dloss'] <= 2e-5 and c['max_abs_dacc'] <= 1e-12, (scheme, c)
+        assert c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9995, (scheme, c)
+
+
+def test_bench_partitioned_at_the_full_twitterus_shape():
+    """BASELINE configs[3] at FULL size (N = 440,000, 10.7 M stored edges, 3 x 300) through the same command: two ranks
+    with the real kernels, both exchange schemes, each compared with rank 0's un-partitioned steps (what
+    tools/staged_twus_check.py prints; measured there: losses to 1e-6, max |dP| 3e-9, argmax agreement >= 0.999995)."""
+    d = _run_bench_self_launched(['--gpus', '2', '--steps', '2', '--warmup', '1'], 2400)
+    assert d['config']['world_size'] == 2 and 'N=440000' in d['config']['workload']
+    pc = d['partition_check']
+    for scheme in ('allgather', 'a2a'):
+        c = pc[scheme]
+        assert c['max_abs_dloss'] <= 1e-5 and c['max_abs_dacc'] <= 1e-12, (scheme, c)
+        assert c['max_abs_dP'] <= 5e-8 and c['argmax_agreement'] >= 0.99999, (scheme, c)
 
 
 def test_gcnmain_row_partitioned_on_one_gpu(tmp_path):

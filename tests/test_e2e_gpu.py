@@ -85,12 +85,13 @@ def test_cmu_train_step_matches_oracle(cmu):
 def test_fused_highway_gemms_match_the_separate_launches(cmu, monkeypatch):
     """The highway block multiplies its input by [Wh | Wt] in one launch, H^T by [dZ | dU] in one, and forms
     dH = dZ.Wh^T + dU.Wt^T in one contraction (reference gcnmodel.py:281-286: both branches read `incoming`).  Against
-    the same step with GEOGCN_FUSE_GEMMS=0: forward bitwise equal (same fma chains); gradients equal up to the one
+    the same step with tuning.FUSE_GEMMS = False: forward bitwise equal (same fma chains); gradients equal up to the one
     changed association in dH (two accumulating passes -> one) and the dual launch's split-K slicing."""
     c = cmu
     outs = {}
+    from geographconv_amd import tuning
     for mode in ('1', '0'):
-        monkeypatch.setenv('GEOGCN_FUSE_GEMMS', mode)
+        monkeypatch.setattr(tuning, 'FUSE_GEMMS', mode == '1')
         clf = _clf(c)
         clf.inject_dropout_mask(c['mask'])
         out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
@@ -388,35 +389,6 @@ def test_hip_graph_replay_equals_eager_steps(cmu):
     ytr2[:5] = (ytr2[:5] + 1) % c['C']
     out = clfg.f_train(c['X'], ytr2, c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
     assert clfg._hg['graph'] is None and np.isfinite(out[0])
-
-
-def test_stream_overlap_path_equals_default(cmu):
-    """GEOGCN_STREAM_OVERLAP=1 path: the graph SpMM on a side HIP stream under the gate's GEMMs (two-phase sweep
-    on one GPU).  Same kernels except that the gating mix is its own launch again: results agree to rounding."""
-    from geographconv_amd.gcnmodel import GraphConv
-    from geographconv_amd.nn import layers as L
-    c = cmu
-    runs = []
-    for overlap in (False, True):
-        clf = GraphConv(c['X'].shape[1], c['C'], c['hid'], 0.0, 0.5, highway=True)
-        clf.stream_overlap = overlap
-        clf.build_model(c['A'], seed=77)
-        L.set_all_param_values(clf.l_out, c['params'])
-        clf.inject_dropout_mask(c['mask'])
-        L.DenseLayer.early_starts.update(fwd=0, bwd=0)
-        hist = []
-        for step in range(3):
-            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
-            hist.append([float(v) for v in out[:4]])
-        pred, probs = clf.predict(c['X'], c['A'], c['te'])
-        runs.append((hist, np.asarray(out[4]).copy(), pred, probs, dict(L.DenseLayer.early_starts)))
-    (h0, P0, pr0, pb0, e0), (h1, P1, pr1, pb1, e1) = runs
-    assert e0 == {'fwd': 0, 'bwd': 0} and e1['fwd'] >= 6 and e1['bwd'] >= 6       # the overlap path really ran
-    for a, b in zip(h0, h1):
-        assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]) and abs(a[2] - b[2]) <= 2e-6 * abs(a[2])
-        assert a[1] == b[1] and a[3] == b[3]
-    assert np.abs(P0 - P1).max() <= 2e-6
-    assert np.array_equal(pr0, pr1) and np.abs(pb0 - pb1).max() <= 2e-6
 
 
 def test_asymmetric_adjacency_uses_explicit_transpose():

@@ -196,9 +196,9 @@ def test_spmm_random_structures(dev, seed):
 def test_bow_products_random(dev, seed, monkeypatch):
     """X . W0 with the hot rows of W0 in LDS and X^T . G through the document-blocked kernel, random bag-of-words
     structures (Zipfian columns), against fp64."""
-    from geographconv_amd import ops, synth
-    monkeypatch.setattr(ops, 'XT_MIN_NNZ', 0)
-    monkeypatch.setattr(ops, 'HOT_MIN_NNZ', 0)
+    from geographconv_amd import ops, synth, tuning
+    monkeypatch.setattr(tuning, 'XT_MIN_NNZ', 0)
+    monkeypatch.setattr(tuning, 'HOT_MIN_NNZ', 0)
     rng = np.random.RandomState(4000 + seed)
     for case in range(4):
         n_docs = int(rng.choice([300, 2100, 9000]))

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sps
 
-from geographconv_amd import synth
+from geographconv_amd import synth, tuning
 from oracle import gcn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -148,23 +148,31 @@ def test_spmm_short_rows_bitwise_reproducible_and_sequential(dev):
     assert np.allclose(o1, ref, rtol=1e-5, atol=1e-6)
 
 
-def test_spmm_hub_hint_changes_nothing_but_order(dev):
-    """The cache hint (hub columns first, the rest gathered non-temporally) must not change results
-    beyond summation order."""
+def test_spmm_timer_rides_on_the_plan_handle(dev):
+    """The profiling timer is a caller-held handle attached to ONE plan (no library-global state): products on another
+    plan, of another width, or fused highway launches are not sampled; detaching stops the sampling."""
     from geographconv_amd import ops
-    A = synth.powerlaw_ahat(20000, 300000)
-    B = _rand((20000, 300), 3)
-    plain = ops.CSR(A, dev)
-    hinted = ops.CSR(A, dev, hub_row_bytes=1200 * 40)        # small budget => a few dozen hubs
-    assert hinted.n_hubs > 0 and hinted.n_long_rows == plain.n_long_rows
-    dB = ops.DMat.from_numpy(B, dev)
-    o1 = ops.spmm(plain, dB).numpy()
-    o2 = ops.spmm(hinted, dB).numpy()
-    ref = (A.astype(np.float64) @ B.astype(np.float64))
-    mag = np.asarray(abs(A) @ np.abs(B))
-    assert np.all(np.abs(o1 - ref) <= 2e-6 * mag + 1e-6)
-    assert np.all(np.abs(o2 - ref) <= 2e-6 * mag + 1e-6)
-    assert np.array_equal(o2, ops.spmm(hinted, dB).numpy())
+    A = synth.powerlaw_ahat(5000, 60000)
+    a1, a2 = ops.CSR(A, dev), ops.CSR(A, dev)
+    B = ops.DMat.from_numpy(_rand((5000, 64), 3), dev)
+    B2 = ops.DMat.from_numpy(_rand((5000, 32), 4), dev)
+    t = ops.SpmmTimer(capacity=8)
+    t.attach(a1, only_F=64)
+    ops.spmm(a1, B)
+    ops.spmm(a2, B)            # other plan
+    ops.spmm(a1, B2)           # other width
+    ops.spmm(a1, B)
+    ms = t.read_ms()
+    assert len(ms) == 2 and all(m > 0 for m in ms)
+    t.detach()
+    ops.spmm(a1, B)
+    assert len(t.read_ms()) == 2
+    t.attach(a2)               # any width; re-attaching resets the pool
+    ops.spmm(a2, B2)
+    assert len(t.read_ms()) == 1
+    del t                      # detaches before the pool is destroyed
+    ops.spmm(a2, B2)
+    torch.cuda.synchronize()
 
 
 def test_spmm_scalar_fallback_for_odd_pitch(dev):
@@ -407,7 +415,7 @@ def test_xt_dot_document_blocked_matches_oracle(dev, n_docs, n_words, mean, F, m
     fp64 product, against the plain row-gather SpMM on CSR(X^T), and against itself (bitwise reproducible); rows of
     X^T without nonzeros come out as zeros; value-dropout variants reuse the plan."""
     from geographconv_amd import ops
-    monkeypatch.setattr(ops, 'XT_MIN_NNZ', 0)
+    monkeypatch.setattr(tuning, 'XT_MIN_NNZ', 0)
     X = _bow(n_docs, n_words, mean, seed=F)
     X = sps.csr_matrix(X)
     X.data[::7] *= -1.0                                    # signs: catches an absolute-value / ordering slip
@@ -435,7 +443,7 @@ def test_xt_dot_document_blocked_matches_oracle(dev, n_docs, n_words, mean, F, m
     assert torch.equal(ops.spmm_t(x, dG2).t[:, :F], out.t[:, :F])
     # wide outputs run as column slabs of <= XT_MAX_F; in one piece the rows are cut into different parts (the plan
     # depends on the width), so: the same numbers up to summation order
-    monkeypatch.setattr(ops, 'XT_MAX_F', 1 << 30)
+    monkeypatch.setattr(tuning, 'XT_MAX_F', 1 << 30)
     assert np.all(np.abs(ops.spmm_t(x, dG).numpy() - out.numpy()) <= 4e-6 * mag + 1e-6)
 
 
@@ -443,10 +451,10 @@ def test_xt_dot_with_dense_head_and_value_dropout(dev, monkeypatch):
     """The split transpose (dense head panel on the MFMA pipe + document-blocked tail) and its value-dropout variant
     (SparseInputDropoutLayer: same structure, same plan, new values) against the fp64 products."""
     from geographconv_amd import ops
-    monkeypatch.setattr(ops, 'XT_MIN_NNZ', 0)
+    monkeypatch.setattr(tuning, 'XT_MIN_NNZ', 0)
     X = sps.csr_matrix(_bow(20000, 1500, 30, seed=1))
     x = ops.SparseOperand.from_scipy(X, dev)
-    assert x.head_dense is not None and x.fwd_tail is not None and x.xt_plan(300) is not None
+    assert x.head_dense is not None and x.xt_plan(300) is not None
     G = _rand((20000, 300), 3)
     dG = ops.DMat.from_numpy(G, dev)
     got = ops.spmm_t(x, dG).numpy()
@@ -459,7 +467,7 @@ def test_xt_dot_with_dense_head_and_value_dropout(dev, monkeypatch):
     got = ops.spmm_t(xd, dG).numpy()
     ref = Xd.T.astype(np.float64) @ G.astype(np.float64)
     assert np.all(np.abs(got - ref) <= 3e-6 * mag / 0.6 + 1e-5)
-    # forward through the split as well: X . W with the dropped values
+    # forward as well: X . W with the dropped values
     W = _rand((1500, 300), 4, 0.1)
     dWm = ops.DMat.from_numpy(W, dev)
     got = ops.spmm_x(xd, dWm).numpy()
@@ -467,14 +475,12 @@ def test_xt_dot_with_dense_head_and_value_dropout(dev, monkeypatch):
     assert np.all(np.abs(got - ref) <= 3e-6 * np.asarray(abs(Xd).astype(np.float64) @ np.abs(W)) + 1e-6)
 
 
-@pytest.mark.parametrize("n_docs,n_words,mean,F,slab", [(30000, 2000, 40, 300, 0), (30000, 2000, 40, 300, 64), (9000, 700, 25, 129, 0),
-                                                       (9000, 700, 25, 129, 64), (4000, 600, 30, 600, 128)])
-def test_spmm_x_dense_head_plus_tail(dev, n_docs, n_words, mean, F, slab, monkeypatch):
-    """X . W0 + b0 with tanh (reference gcnmodel.py:39-42) as dense head panel (MFMA) + CSR tail continuing each row
-    (geogcn_spmm_csr_acc_f32), in one pass or in column slabs: against the fp64 product and against the one-kernel
-    SpMM; deterministic."""
+@pytest.mark.parametrize("n_docs,n_words,mean,F", [(30000, 2000, 40, 300), (9000, 700, 25, 129), (4000, 600, 30, 600)])
+def test_spmm_x_below_the_hot_threshold_and_the_accumulate_form(dev, n_docs, n_words, mean, F):
+    """X . W0 + b0 with tanh (reference gcnmodel.py:39-42) for a small X (plain row gather: below tuning.HOT_MIN_NNZ)
+    against the fp64 product; deterministic.  And the accumulate form C = C0 + A.B (geogcn_spmm_csr_acc_f32) with long
+    rows through the chunk path."""
     from geographconv_amd import ops
-    monkeypatch.setattr(ops, 'X_FWD_SLAB', slab)
     X = sps.csr_matrix(_bow(n_docs, n_words, mean, seed=2))
     x = ops.SparseOperand.from_scipy(X, dev)
     assert x.head_dense is not None
@@ -487,10 +493,7 @@ def test_spmm_x_dense_head_plus_tail(dev, n_docs, n_words, mean, F, slab, monkey
     tol = 3e-6 * np.asarray(abs(X).astype(np.float64) @ np.abs(W)) + 1e-6
     assert np.all(np.abs(got.numpy() - ref) <= tol)
     assert torch.all(got.t[:, F:] == 0)
-    one = ops.spmm(x.fwd, dWm, bias=db, act=ops.ACT_TANH)
-    assert np.all(np.abs(got.numpy() - one.numpy()) <= 2 * tol)
     assert torch.equal(ops.spmm_x(x, dWm, bias=db, act=ops.ACT_TANH).t, got.t)
-    # the accumulate form by itself, with long rows through the chunk path: C = C0 + A.B
     A = _skewed_csr(600, n_words, seed=9)
     C0 = _rand((600, F), 6)
     dC = ops.DMat.from_numpy(C0, dev)
@@ -776,7 +779,7 @@ def test_cmu_shape_spmm_full_size(dev):
     assert np.allclose(got, ref, rtol=1e-4, atol=2e-5)
     # the hybrid transpose product the model uses: dense head panel (MFMA) + sparse tail (gather)
     sx = ops.SparseOperand.from_scipy(X, dev)
-    assert sx.head_dense is not None and 16 <= sx.head_dense.F <= ops.DENSE_HEAD_MAX_COLS
+    assert sx.head_dense is not None and 16 <= sx.head_dense.F <= tuning.DENSE_HEAD_MAX_COLS
     assert sx.bwd.nnz + int((X[:, sx.head_idx.cpu().numpy()]).nnz) == X.nnz
     ref64 = (X.T.astype(np.float64) @ H.astype(np.float64))
     got = ops.spmm_t(sx, ops.DMat.from_numpy(H, dev)).numpy()

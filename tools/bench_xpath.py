@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from geographconv_amd import ops, synth  # noqa: E402
+from geographconv_amd import ops, synth, tuning  # noqa: E402
 from tools.bench_kernels import timeit  # noqa: E402
 
 
@@ -50,18 +50,15 @@ def main():
           h2 = ops.HotCSR(x.fwd, X.data, nh)
           show('X.W0   hot rows of W0 in LDS (%d rows, %.0f %%)' % (nh, 100 * h2.hot_fraction),
                timeit(lambda: ops.spmm_hot(h2, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
-      ops.X_FWD_MODE = 'split'
       show('X.W0   one CSR gather kernel', timeit(lambda: ops.spmm(x.fwd, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
-      show('X.W0   dense head GEMM + tail', timeit(lambda: ops.spmm_x(x, W, out=out, bias=b, act=1), args.reps)[0], alg_fwd)
     if args.only == 'fwd':
         return
-    print('doc block %s rows, rendezvous %s' % (os.environ.get('GEOGCN_XT_DOC_BLOCK', 'default'), os.environ.get('GEOGCN_XT_RENDEZVOUS', '0')))
     for name, g in (('ld 320', G), ('ld 300', G300)):
-        ops.XT_MIN_NNZ = 0
+        tuning.XT_MIN_NNZ = 0
         show('X^T.dS0  head GEMM + document-blocked tail (%s)' % name, timeit(lambda: ops.spmm_t(x, g, out=dW), args.reps)[0], alg_bwd)
-        ops.XT_MIN_NNZ = 1 << 60
+        tuning.XT_MIN_NNZ = 1 << 60
         show('X^T.dS0  head GEMM + row-gather tail (%s)' % name, timeit(lambda: ops.spmm_t(x, g, out=dW), args.reps)[0], alg_bwd)
-    ops.XT_MIN_NNZ = 0
+    tuning.XT_MIN_NNZ = 0
     plan = x.xt_plan(F)
     w = ops._ws_for(dev).get(plan.ws_bytes)
     from geographconv_amd import _ffi

@@ -60,7 +60,7 @@ class SimComm(TorchDistComm):
         self.part = RowPartition(N, world, rank)
         self.device = device
         self.exchange = exchange
-        self.balance = os.environ.get('GEOGCN_DIST_BALANCE', '1') != '0'
+        self.balance = True
         self._bufs = {}
 
 

@@ -21,14 +21,13 @@ def main():
     ap.add_argument('--long', type=int, default=256)
     ap.add_argument('--chunk', type=int, default=128)
     ap.add_argument('--aligned', type=int, default=1, help='use the line-aligned gather pitch for B')
-    ap.add_argument('--hub', type=int, default=0, help='hub_row_bytes for the cache hint (0 = off)')
     ap.add_argument('--bf16', type=int, default=0, help='gather a bf16 copy of B (geogcn_spmm_csr_bf16b)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     s = synth.SHAPES[args.shape]
     A = synth.powerlaw_ahat(s.N, s.E_target)
-    dA = ops.CSR(A, dev, args.long, args.chunk, hub_row_bytes=args.hub or None)
-    print('hubs', dA.n_hubs, 'long rows', dA.n_long_rows, flush=True)
+    dA = ops.CSR(A, dev, args.long, args.chunk)
+    print('long rows', dA.n_long_rows, flush=True)
     rng = np.random.RandomState(1)
     for F in args.F:
         H = ops.DMat.empty(s.N, F, dev, ld=ops.gather_ld(F) if args.aligned else None)
