@@ -320,6 +320,11 @@ def main():
         return m
 
     y_tr, y_dev = Y[tr], Y[dev]
+    tr, dev = np.array(tr), np.array(dev)
+    for v in (y_tr, y_dev, tr, dev):
+        # the caller's promise that these never change: GraphConv then hashes each once instead of every step
+        # (gcnmodel._content_key; ~0.1 ms per MB and step otherwise)
+        v.setflags(write=False)
 
     def barrier():
         if world > 1:

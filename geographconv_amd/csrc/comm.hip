@@ -4,10 +4,23 @@
 // through torch.distributed by default and through these with GEOGCN_DIST_BACKEND=native).
 // RCCL is resolved at run time (dlopen): libgeogcn.so has no link dependency on it, loads on machines without it, and
 // inside a process that already carries an RCCL (PyTorch ships its own) the loaded copy is reused, never a second one.
+// It also BUILDS without the RCCL headers: only a handful of opaque types and enum values are needed, declared below
+// (NCCL's stable public ABI) when <rccl/rccl.h> is absent.
 #include "common.h"
 
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>      // types and enums only; every function is looked up below
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclChar = 0, ncclFloat = 7 } ncclDataType_t;
+}
+#endif
 
 #include <mutex>
 

@@ -248,6 +248,11 @@ int geogcn_xt_plan_create(int32_t n_words, int32_t n_docs, const int32_t* rowptr
     std::vector<int> words;
     for (int w = 0; w < n_words; ++w) {
         GEOGCN_REQUIRE(rowptr_t_host[w + 1] >= rowptr_t_host[w], GEOGCN_E_SIZE, "xt_plan_create: rowptr not monotone at %d", w);
+        // precondition of the sweep (the entries of a document block are a PREFIX of the next 16, and the per-XCD entry
+        // points below are found by binary search): document indices ascending inside every row
+        for (int p = rowptr_t_host[w] + 1; p < rowptr_t_host[w + 1]; ++p)
+            GEOGCN_REQUIRE(docidx_t_host[p] > docidx_t_host[p - 1], GEOGCN_E_ARG,
+                           "xt_plan_create: row %d of CSR(X^T) is not in strictly ascending document order", w);
         if (rowptr_t_host[w + 1] > rowptr_t_host[w]) words.push_back(w);
     }
     // units (word, part p of P): P so that no unit outweighs the average group's share of a batch.  The batch count

@@ -87,7 +87,8 @@ int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t
                             int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream);
 
 /* dW[n_words x F] = X^T . G  -- the gradient of S.structured_dot(X, W0) w.r.t. W0 (autodiff of gcnmodel.py:39) for a
- * bag-of-words X whose transpose is given as CSR (rows = vocabulary, columns = documents, sorted).  Instead of gathering
+ * bag-of-words X whose transpose is given as CSR (rows = vocabulary, columns = documents, STRICTLY ASCENDING inside every
+ * row: checked by geogcn_xt_plan_create, GEOGCN_E_ARG otherwise -- the sweep and its entry points rely on it).  Instead of gathering
  * rows of the N x F matrix G at random (every row fetched ~nnz/N times from beyond the L2), the documents are
  * partitioned over 8 groups of workgroups (one per XCD) that sweep their range in L2-sized blocks while each 16-lane
  * group accumulates a fixed set of vocabulary rows in LDS; the 8 partial results per row are added in fixed order.

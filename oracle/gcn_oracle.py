@@ -50,6 +50,26 @@ def spmm_t(A: sps.csr_matrix, G: np.ndarray) -> np.ndarray:
     return np.asarray(A.T @ G)
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest bfloat16 (ties to even), returned as fp32: what `v_cvt_pk_bf16_f32` / a bf16 store does to a finite
+    value.  No reference counterpart -- the reference is fp32 throughout; this models BASELINE configs[4] ("bf16 H.W on
+    MFMA with fp32 accumulate")."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7fff)
+    return ((u + r) & np.uint32(0xffff0000)).view(np.float32)
+
+
+def dense_product(H, W, gemm_operands=None):
+    """T.dot(H, W) (gcnmodel.py:126,149,285).  gemm_operands='bf16': both operands rounded to bf16 (RNE) first, products
+    exact, accumulation in (at least) fp32 -- formed here in fp64 and rounded once, i.e. the ideal 'fp32 accumulate' an
+    MFMA chain approximates to ~K * 2^-24 relative."""
+    if gemm_operands is None:
+        return H @ W
+    if gemm_operands != 'bf16':
+        raise ValueError("gemm_operands must be None or 'bf16'")
+    return (bf16_round(H).astype(np.float64) @ bf16_round(W).astype(np.float64)).astype(np.float32)
+
+
 def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))         # T.nnet.sigmoid
 
@@ -114,11 +134,20 @@ def random_params(input_size, hid, C, highway, seed=0, dtype=np.float32, scale=N
 # forward
 # --------------------------------------------------------------------------------------------
 def forward(params, X, A, hid, highway=True, p_drop=0.0, mask=None, deterministic=True,
-            dtype=np.float32):
+            dtype=np.float32, gemm_operands=None):
     """Full forward pass; returns a cache with every intermediate (for backward and for
     layer-by-layer parity tests).  ``mask`` is the injected Bernoulli(1-p) keep-mask (N x hid[0])
-    -- Theano's MRG stream cannot be reproduced."""
+    -- Theano's MRG stream cannot be reproduced.
+
+    ``gemm_operands='bf16'`` is the bf16-AWARE mode for BASELINE configs[4] (no reference counterpart): every dense
+    H.W product takes bf16-rounded operands with fp32 accumulation (dense_product), and the product Z that the graph
+    convolution gathers is itself STORED as bf16 (the SpMM's arithmetic stays fp32); X.W0, biases, activations, the
+    gating mix and the softmax stay fp32 -- exactly where the HIP path's bf16 configuration rounds."""
     dt = np.dtype(dtype)
+    if gemm_operands is not None and dt != np.float32:
+        raise ValueError("the bf16-aware mode models an fp32 path")
+    mm = lambda H_, W_: dense_product(H_, W_, gemm_operands)
+    store = (lambda Z_: bf16_round(Z_)) if gemm_operands == 'bf16' else (lambda Z_: Z_)
     params = [np.asarray(p, dtype=dt) for p in params]
     (W0, b0), blocks, (Wo, bo) = split_params(params, hid, highway)
     c = {'blocks': []}
@@ -136,12 +165,12 @@ def forward(params, X, A, hid, highway=True, p_drop=0.0, mask=None, deterministi
     c['Hd'] = H
     for (Wh, bh, Wt, bt) in blocks:
         b = {'Hin': H}
-        Z = H @ Wh                              # gcnmodel.py:126  T.dot(input, W)
+        Z = store(mm(H, Wh))                    # gcnmodel.py:126  T.dot(input, W)
         S = spmm(A, Z) + bh                     # gcnmodel.py:130-133
         Hc = np.tanh(S)                         # gcnmodel.py:136
         b['Z'], b['Hc'] = Z, Hc
         if Wt is not None:
-            U = H @ Wt + bt                     # gcnmodel.py:285  DenseLayer
+            U = mm(H, Wt) + bt                  # gcnmodel.py:285  DenseLayer
             Tg = sigmoid(U).astype(dt)          # gcnmodel.py:286
             b['T'] = Tg
             H = Tg * Hc + (dt.type(1.0) - Tg) * H   # gcnmodel.py:266
@@ -150,7 +179,7 @@ def forward(params, X, A, hid, highway=True, p_drop=0.0, mask=None, deterministi
         b['Hout'] = H
         c['blocks'].append(b)
     c['Hlast'] = H
-    Zo = H @ Wo                                 # gcnmodel.py:149
+    Zo = store(mm(H, Wo))                       # gcnmodel.py:149
     So = spmm(A, Zo) + bo                       # gcnmodel.py:153-156
     c['Zo'], c['logits'] = Zo, So
     c['P'] = softmax_rows(So).astype(dt)        # gcnmodel.py:157 / :374
@@ -280,9 +309,9 @@ def f_train(params, st, X, y_train, y_dev, A, train_idx, dev_idx, hid, highway=T
     return new_params, [l_tr, a_tr, l_dev, a_dev, c['P']], grads
 
 
-def f_val(params, X, A, test_idx, hid, highway=True, dtype=np.float32):
+def f_val(params, X, A, test_idx, hid, highway=True, dtype=np.float32, gemm_operands=None):
     """Deterministic forward -> (argmax int64, probs[idx]) (gcnmodel.py:392-394,411)."""
-    c = forward(params, X, A, hid, highway, deterministic=True, dtype=dtype)
+    c = forward(params, X, A, hid, highway, deterministic=True, dtype=dtype, gemm_operands=gemm_operands)
     rows = c['P'][test_idx]
     return rows.argmax(-1).astype(np.int64), rows
 

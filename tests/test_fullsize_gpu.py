@@ -16,6 +16,10 @@ from geographconv_amd import synth
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
+# configs[4] against the bf16-AWARE oracle: absolute + relative bound on every probability (fp32 accumulation-order
+# noise + the Z elements it pushes across a bf16 rounding boundary; the first measurement is recorded in DESIGN.md section 3)
+BF16_AWARE_P_ATOL, BF16_AWARE_P_RTOL = 1e-5, 1e-3
+
 
 @pytest.fixture(scope="module")
 def twus():
@@ -173,7 +177,7 @@ def test_forward_full_size_matches_oracle_argmax_exact(twus):
     print("TWUS argmax: %d of %d rows inside the tie band; label mismatches vs the fp64 oracle: HIP %d, fp32 oracle %d; "
           "HIP vs fp32 oracle %d" % (int((~clear).sum()), N, n_hip, n_cpu32, int((pred != a32).sum())))
     assert either.all(), int((~either).sum())
-    assert n_hip <= n_cpu32 + 2
+    assert n_hip == 0 and n_cpu32 == 0                    # measured: 0 / 0 / 0
     assert np.abs(probs - ref64).max() <= tol + 3e-5
 
 
@@ -198,7 +202,7 @@ def test_train_step_full_size_matches_oracle(twus):
     new, ref, grads = O.f_train(params, O.AdamState(params), t['X'], ytr, ydv, t['A'], t['tr'], t['dev_idx'], hid, True, 0.5,
                                 mask.astype(np.float32))
     assert abs(out[0] - ref[0]) <= 2e-6 * abs(ref[0]) and abs(out[2] - ref[2]) <= 2e-6 * abs(ref[2])
-    assert abs(out[1] - ref[1]) <= 2.0 / len(ytr) and abs(out[3] - ref[3]) <= 2.0 / len(ydv)      # hit counts (ties aside)
+    assert out[1] == ref[1] and out[3] == ref[3]                                  # hit counts: identical
     for i, (g, r) in enumerate(zip(clf.get_grads(), grads)):
         assert np.abs(g - r).max() <= 2e-4 * np.abs(r).max() + 1e-10, (i, float(np.abs(g - r).max()), float(np.abs(r).max()))
     for i, (q, r) in enumerate(zip(L.get_all_param_values(clf.l_out), new)):
@@ -208,9 +212,14 @@ def test_train_step_full_size_matches_oracle(twus):
 
 def test_config5_shape_bf16_six_layers_600_hidden_full_size(twus):
     """BASELINE configs[4]'s shape on one GPU: 6 x 600 highway GCN at the FULL TwitterUS size with bf16 H.W products
-    (fp32 accumulate) and the bf16 gathered operand, deterministic forward over all 440,000 nodes against the fp32
-    oracle (~1 min of CPU).  bf16 carries 8 mantissa bits per product operand, so the comparison is statistical:
-    probabilities within a bf16-class envelope on every row, label agreement rate, and a second run bitwise equal."""
+    (fp32 accumulate) and the bf16 gathered operand, deterministic forward over all 440,000 nodes.
+
+    The pass / fail comparison is against the bf16-AWARE oracle (`O.forward(..., gemm_operands='bf16')`: operands of every
+    H.W rounded to bf16 RNE, fp32 accumulation, Z stored as bf16 -- the same roundings at the same places), so the
+    tolerance is an fp32-class one: what is left between the two is the fp32 accumulation order of the MFMA chain and of
+    the hub rows' chunked sums, plus the rare Z element that lands on the other side of a bf16 rounding boundary because of
+    it.  The statistics against the plain fp32 oracle are printed as a report (they say how far bf16 is from fp32, not
+    whether the kernels are right) and bounded loosely."""
     from geographconv_amd.gcnmodel import GraphConv
     from geographconv_amd.nn import layers as L
     from oracle import gcn_oracle as O
@@ -223,21 +232,27 @@ def test_config5_shape_bf16_six_layers_600_hidden_full_size(twus):
     N = t['A'].shape[0]
     idx = np.arange(N, dtype=np.int32)
     pred, probs = clf.predict(t['X'], t['A'], idx)
-    ref = O.forward(params, t['X'], t['A'], hid, True, dtype=np.float32)['P']
     assert np.all(np.isfinite(probs)) and np.allclose(probs.sum(1), 1.0, atol=1e-4)
+    # -- the gate: against the bf16-aware restatement ----------------------------------------------------------------
+    refb = O.forward(params, t['X'], t['A'], hid, True, dtype=np.float32, gemm_operands='bf16')['P']
+    errb = np.abs(probs - refb)
+    tol = BF16_AWARE_P_ATOL + BF16_AWARE_P_RTOL * refb.max(1)
+    top2 = np.partition(refb, -2, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * tol
+    n_bad = int((pred[clear] != refb.argmax(-1)[clear]).sum())
+    print("config5 shape vs the bf16-aware oracle: max |dP| %.3g, 99.9th pct %.3g, mean %.3g; %d of %d rows inside the tie "
+          "band; label mismatches outside it: %d" % (errb.max(), np.percentile(errb.max(1), 99.9), errb.mean(),
+                                                     int((~clear).sum()), N, n_bad))
+    assert np.all(errb.max(1) <= tol), float(errb.max())
+    assert clear.mean() > 0.99 and n_bad == 0
+    # -- report: distance of the bf16 configuration from exact fp32 --------------------------------------------------
+    ref = O.forward(params, t['X'], t['A'], hid, True, dtype=np.float32)['P']
     err = np.abs(probs - ref)
-    # envelope: 6 layers of products with 2^-8 relative operand rounding; measured max ~3e-3 absolute on probabilities
-    # of ~4e-3 (near-uniform softmax at init), i.e. tens of per cent relative on single entries but tiny in KL
     kl = (ref * (np.log(ref + 1e-30) - np.log(probs + 1e-30))).sum(1)
     agree = float((pred == ref.argmax(-1)).mean())
-    print("config5 shape, bf16 vs fp32 oracle: max |dP| %.3g, mean |dP| %.3g, max KL %.3g, label agreement %.4f"
+    print("config5 shape, bf16 vs fp32 oracle (report): max |dP| %.3g, mean |dP| %.3g, max KL %.3g, label agreement %.4f"
           % (err.max(), err.mean(), kl.max(), agree))
-    assert err.max() <= 5e-3 and err.mean() <= 5e-6 and kl.max() <= 1e-4
-    assert agree >= 0.995
-    # where the fp32 oracle's top-2 margin exceeds the bf16 noise, the labels must agree
-    top2 = np.partition(ref, -2, axis=1)[:, -2:]
-    clear = (top2[:, 1] - top2[:, 0]) > 10 * err.mean() + 4 * err.std()
-    assert np.array_equal(pred[clear], ref.argmax(-1)[clear]) or (pred[clear] != ref.argmax(-1)[clear]).mean() < 1e-3
+    assert err.max() <= 2e-3 and err.mean() <= 1e-6 and kl.max() <= 2e-5 and agree >= 0.9995      # 2x the measured values
     pred2, probs2 = clf.predict(t['X'], t['A'], idx)
     assert np.array_equal(pred, pred2) and np.array_equal(probs, probs2)
 
