@@ -172,3 +172,32 @@ def test_multithreaded_cpu_leg_equals_the_oracle_products():
         r64 = O.spmm_t(A, G.astype(np.float64))                 # fp64 calls (gradient checks) stay on scipy
     assert np.abs(r - A.T @ G).max() <= 1e-5 and r64.dtype == np.float64
     assert O.spmm_t(A, G).dtype == np.float32 and O.spmm.__name__ == 'spmm'      # restored
+
+
+def test_bf16_aware_mode_rounds_where_the_bf16_configuration_rounds():
+    """`gemm_operands='bf16'` (BASELINE configs[4]; no reference counterpart): RNE rounding incl. ties, idempotence, a dense
+    product whose operands are already bf16 is unchanged, the mode stays within a bf16-class distance of the fp32 forward,
+    and the first layer (X.W0: not an H.W product) is untouched."""
+    # ties to even: 1 + 2^-8 lies exactly between 1 and 1 + 2^-7 -> 1 (even mantissa); 1 + 3 * 2^-8 -> 1 + 2^-6
+    x = np.array([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, -(1.0 + 2.0 ** -8), 1.0 + 2.0 ** -8 + 2.0 ** -20, 0.0, 3.0e38],
+                 dtype=np.float32)
+    r = O.bf16_round(x)
+    assert r[0] == 1.0 and r[1] == np.float32(1.0 + 2.0 ** -6) and r[2] == -1.0 and r[3] == np.float32(1.0 + 2.0 ** -7)
+    assert r[4] == 0.0 and np.isfinite(r[5])
+    y = np.random.RandomState(0).randn(1000).astype(np.float32)
+    assert np.array_equal(O.bf16_round(O.bf16_round(y)), O.bf16_round(y))
+    assert np.all(np.abs(O.bf16_round(y) - y) <= np.abs(y) * 2.0 ** -8)
+    H, W = O.bf16_round(np.random.RandomState(1).randn(40, 30).astype(np.float32)), O.bf16_round(
+        np.random.RandomState(2).randn(30, 20).astype(np.float32))
+    assert np.allclose(O.dense_product(H, W, 'bf16'), H.astype(np.float64) @ W.astype(np.float64), rtol=1e-6, atol=1e-6)
+    A, X, Y = synth.small_graph(300, 5.0, 60, 10, 6, seed=3)
+    hid = [24, 24, 24]
+    params = O.random_params(60, hid, 6, True, seed=4, scale=0.4)
+    c32 = O.forward(params, X, A, hid, True)
+    cb = O.forward(params, X, A, hid, True, gemm_operands='bf16')
+    assert np.array_equal(c32['H0'], cb['H0'])
+    d = np.abs(c32['P'] - cb['P']).max()
+    assert 0 < d < 2e-2
+    assert np.array_equal(cb['blocks'][0]['Z'], O.bf16_round(cb['blocks'][0]['Z']))          # Z is STORED as bf16
+    with pytest.raises(ValueError):
+        O.forward(params, X, A, hid, True, dtype=np.float64, gemm_operands='bf16')
