@@ -72,6 +72,26 @@ __device__ __forceinline__ float apply_act(float x) {
     }
 }
 
+// ---- Philox4x32-10 (Salmon et al. 2011): the dropout streams (elementwise.hip; fused epilogue of spmm_hot.hip) ----------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+}
+// the four 24-bit uniforms [0,1) of counter `ctr` (= element index / 4 + stream offset) under key `seed`
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t ctr, float (&u)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
+}
+
 // Zero-fill by a kernel instead of hipMemsetAsync: inside a captured step (hipGraph) a memset node followed
 // by a kernel that accumulates into the same buffer was observed to race on ROCm 7.2 when the graph is
 // launched on an idle device (tests/test_e2e_gpu.py::test_hip_graph_...); kernel -> kernel edges are safe.

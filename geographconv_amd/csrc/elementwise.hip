@@ -259,17 +259,7 @@ __global__ __launch_bounds__(TPB) void dropout_apply_kernel(int64_t n, int F, in
     }
 }
 
-// ---- Philox4x32-10 (Salmon et al. 2011), counter = element index / 4, key = seed ------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k[0] += 0x9E3779B9u;
-    k[1] += 0xBB67AE85u;
-}
-
+// ---- dropout masks: Philox4x32-10 (common.h), counter = element index / 4, key = seed ------------------
 // `calls` (nullable): device-resident call counter of a captured step (hipGraph replays cannot change kernel
 // arguments); the stream position is then (calls * per_call + base) / 4 quads, as the host computes it.
 __global__ __launch_bounds__(TPB) void dropout_mask_kernel(int64_t total, float keep_prob, uint64_t seed,
@@ -278,18 +268,12 @@ __global__ __launch_bounds__(TPB) void dropout_mask_kernel(int64_t total, float 
     if (calls) offset = (uint64_t)((*calls * per_call + base) / 4);
     const int64_t quads = (total + 3) / 4;
     for (int64_t qd = (int64_t)blockIdx.x * TPB + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * TPB) {
-        const uint64_t ctr = (uint64_t)qd + offset;
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-        for (int r = 0; r < 10; ++r) philox_round(c, k);
+        float u[4];
+        philox_uniform4(seed, (uint64_t)qd + offset, u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t e = qd * 4 + i;
-            if (e < total) {
-                const float u = (float)(c[i] >> 8) * (1.0f / 16777216.0f);   // 24-bit uniform [0,1)
-                mask[e] = (u < keep_prob) ? 1 : 0;
-            }
+            if (e < total) mask[e] = (u[i] < keep_prob) ? 1 : 0;
         }
     }
 }

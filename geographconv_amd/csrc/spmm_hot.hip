@@ -10,7 +10,12 @@
 //     entry, the LDS slot instead of the column (geogcn.h: geogcn_spmm_csr_hot_f32);
 //   * a 16-lane group owns one row at a time, K4 float4 accumulators per lane, sequential fmaf in stored order
 //     (hot part, then cold part): deterministic, bitwise reproducible;
-//   * bias + tanh / sigmoid epilogue fused into the store.
+//   * bias + tanh / sigmoid epilogue fused into the store;
+//   * optionally (DROP) the dropout that follows this layer in the reference (lasagne DropoutLayer, gcnmodel.py:357)
+//     rides in the same epilogue: the keep decisions come from the Philox stream of geogcn_dropout_mask_philox (same
+//     counter = element index / 4 + offset: bit-identical masks) or from a caller-supplied mask, and the kernel stores
+//     the activation H0 (the backward needs 1 - H0^2), the dropped copy Hd = H0 * keep / (1-p) and the mask byte --
+//     instead of a separate mask kernel and an apply pass that re-reads H0 (528 MB at the TwitterUS shape).
 #include "common.h"
 
 #include <algorithm>
@@ -47,9 +52,17 @@ struct HotArgs {
     float* C; int64_t ldc;
     int F;
     const float* bias;
+    // DROP only
+    float* Cd;                   // dropped copy, pitch ldc
+    const uint8_t* mask_in;      // nullable: injected keep-mask [n_rows][F] (dense, no pitch)
+    uint8_t* mask_out;           // nullable: keep-mask as generated / used
+    float keep_prob, scale;
+    uint64_t seed, offset;       // Philox stream position (quads), see geogcn_dropout_mask_philox
+    const int64_t* calls;        // nullable: device-resident call counter (captured steps)
+    int64_t per_call, base;
 };
 
-template <int K4, int ACT>
+template <int K4, int ACT, int DROP = 0>
 __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 hot[];         // [n_hot][K4][16]
     const int lane = threadIdx.x % kGroup, g = threadIdx.x / kGroup;
@@ -133,6 +146,10 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
             }
         }
         float4* out = reinterpret_cast<float4*>(a.C + (int64_t)row * a.ldc);
+        uint64_t drop_offset = a.offset;
+        if constexpr (DROP) {
+            if (a.calls) drop_offset = (uint64_t)((*a.calls * a.per_call + a.base) / 4);
+        }
 #pragma unroll
         for (int k = 0; k < K4; ++k) {
             const int q = lane + kGroup * k;
@@ -150,6 +167,25 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
                     }
                 }
                 out[q] = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (DROP) {
+                    // F % 4 == 0 (checked by the entry point): the four elements are one Philox counter and one aligned
+                    // word of the byte mask
+                    const int64_t e0 = (int64_t)row * a.F + q * 4;
+                    uint32_t m4;
+                    if (a.mask_in) {
+                        m4 = *reinterpret_cast<const uint32_t*>(a.mask_in + e0);
+                    } else {
+                        float u[4];
+                        philox_uniform4(a.seed, (uint64_t)(e0 >> 2) + drop_offset, u);
+                        m4 = (u[0] < a.keep_prob ? 1u : 0u) | (u[1] < a.keep_prob ? 0x100u : 0u) |
+                             (u[2] < a.keep_prob ? 0x10000u : 0u) | (u[3] < a.keep_prob ? 0x1000000u : 0u);
+                    }
+                    if (a.mask_out) *reinterpret_cast<uint32_t*>(a.mask_out + e0) = m4;
+                    // (same arithmetic as dropout_apply_kernel: x * ((float)mask * scale))
+                    reinterpret_cast<float4*>(a.Cd + (int64_t)row * a.ldc)[q] =
+                        make_float4(o[0] * ((float)(m4 & 0xffu) * a.scale), o[1] * ((float)((m4 >> 8) & 0xffu) * a.scale),
+                                    o[2] * ((float)((m4 >> 16) & 0xffu) * a.scale), o[3] * ((float)(m4 >> 24) * a.scale));
+                }
             }
         }
     }
@@ -168,28 +204,24 @@ int32_t geogcn_spmm_hot_capacity(int32_t F) {
     return kHotLdsBytes / (K4 * kGroup * (int)sizeof(float4));
 }
 
-int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
-                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
-                            int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream) {
-    GEOGCN_REQUIRE(n_rows >= 0 && F > 0 && n_hot >= 0, GEOGCN_E_SIZE, "spmm_csr_hot_f32: bad sizes");
+static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act, int drop, hipStream_t st) {
+    const int n_rows = a.n_rows, F = a.F;
+    GEOGCN_REQUIRE(n_rows >= 0 && F > 0 && n_hot >= 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (n_rows == 0) return 0;
-    GEOGCN_REQUIRE(rowptr && rowsplit && C && B && (n_hot == 0 || hot_rows), GEOGCN_E_NULL, "spmm_csr_hot_f32: null pointer");
+    GEOGCN_REQUIRE(a.rowptr && a.rowsplit && a.C && a.B && (n_hot == 0 || a.hot_rows), GEOGCN_E_NULL, "%s: null pointer", fn);
     const int cap = geogcn_spmm_hot_capacity(F);
-    GEOGCN_REQUIRE(cap > 0 && n_hot <= cap, GEOGCN_E_ARG, "spmm_csr_hot_f32: F=%d / n_hot=%d outside the LDS capacity (%d rows)", F,
-                   n_hot, cap);
+    GEOGCN_REQUIRE(cap > 0 && n_hot <= cap, GEOGCN_E_ARG, "%s: F=%d / n_hot=%d outside the LDS capacity (%d rows)", fn, F, n_hot, cap);
     const int F4 = (F + 3) / 4;
-    GEOGCN_REQUIRE(ldb % 4 == 0 && ldc % 4 == 0 && ldb >= (int64_t)F4 * 4 && ldc >= (int64_t)F4 * 4 && aligned16(B) && aligned16(C),
-                   GEOGCN_E_ALIGN, "spmm_csr_hot_f32: needs float4-addressable B and C");
-    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG, "spmm_csr_hot_f32: unknown act %d", act);
-    const HotArgs a{n_rows, rowptr, rowsplit, colidx, val, B, ldb, hot_rows, n_hot, C, ldc, F, bias};
+    GEOGCN_REQUIRE(a.ldb % 4 == 0 && a.ldc % 4 == 0 && a.ldb >= (int64_t)F4 * 4 && a.ldc >= (int64_t)F4 * 4 && aligned16(a.B) &&
+                       aligned16(a.C), GEOGCN_E_ALIGN, "%s: needs float4-addressable B and C", fn);
+    GEOGCN_REQUIRE(act >= GEOGCN_ACT_NONE && act <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG, "%s: unknown act %d", fn, act);
     const int K4 = (int)cdiv(F4, kGroup);
     const size_t lds = (size_t)std::max(1, n_hot) * K4 * kGroup * sizeof(float4);
     const int n_tiles = (int)cdiv(n_rows, kGroups);
     const dim3 grid((unsigned)std::min(n_tiles, kNumCU));
-    hipStream_t st = (hipStream_t)stream;
-#define GEOGCN_HOT(K, ACT)                                                                                          \
+#define GEOGCN_HOT(K, ACT, DROP)                                                                                    \
     do {                                                                                                            \
-        auto kern = spmm_hot_kernel<K, ACT>;                                                                        \
+        auto kern = spmm_hot_kernel<K, ACT, DROP>;                                                                  \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
             GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -197,22 +229,57 @@ int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t
         }                                                                                                           \
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);                                                 \
     } while (0)
-#define GEOGCN_HOT_ACT(K)                                                  \
-    case K:                                                                \
-        if (act == GEOGCN_ACT_TANH) GEOGCN_HOT(K, GEOGCN_ACT_TANH);        \
-        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_HOT(K, GEOGCN_ACT_SIGMOID); \
-        else GEOGCN_HOT(K, GEOGCN_ACT_NONE);                               \
+#define GEOGCN_HOT_ACT(K)                                                     \
+    case K:                                                                   \
+        if (drop) {           /* the layer the dropout follows is tanh (gcnmodel.py:347,357); linear for completeness */ \
+            if (act == GEOGCN_ACT_TANH) GEOGCN_HOT(K, GEOGCN_ACT_TANH, 1);    \
+            else GEOGCN_HOT(K, GEOGCN_ACT_NONE, 1);                           \
+        } else if (act == GEOGCN_ACT_TANH) GEOGCN_HOT(K, GEOGCN_ACT_TANH, 0); \
+        else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_HOT(K, GEOGCN_ACT_SIGMOID, 0); \
+        else GEOGCN_HOT(K, GEOGCN_ACT_NONE, 0);                               \
         break;
     switch (K4) {
         GEOGCN_HOT_ACT(1) GEOGCN_HOT_ACT(2) GEOGCN_HOT_ACT(3) GEOGCN_HOT_ACT(4) GEOGCN_HOT_ACT(5) GEOGCN_HOT_ACT(6)
         default:
-            set_error("spmm_csr_hot_f32: F=%d not supported", F);
+            set_error("%s: F=%d not supported", fn, F);
             return GEOGCN_E_ARG;
     }
 #undef GEOGCN_HOT
 #undef GEOGCN_HOT_ACT
     GEOGCN_LAUNCH_CHECK("spmm_hot_kernel");
     return 0;
+}
+
+int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
+                            int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream) {
+    HotArgs a{};
+    a.n_rows = n_rows; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
+    a.hot_rows = hot_rows; a.n_hot = n_hot; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
+    return spmm_hot_launch("spmm_csr_hot_f32", a, n_hot, act, 0, (hipStream_t)stream);
+}
+
+int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+                                    const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
+                                    float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act, float p_drop,
+                                    const uint8_t* mask_in, uint8_t* mask_out, uint64_t seed, uint64_t offset,
+                                    const int64_t* calls_dev, int64_t per_call_elems, int64_t base_elems, void* stream) {
+    const char* fn = "spmm_csr_hot_dropout_f32";
+    GEOGCN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GEOGCN_E_ARG, "%s: p=%f outside [0,1)", fn, p_drop);
+    GEOGCN_REQUIRE(act == GEOGCN_ACT_TANH || act == GEOGCN_ACT_NONE, GEOGCN_E_ARG, "%s: act must be tanh or none (got %d)", fn, act);
+    GEOGCN_REQUIRE(per_call_elems >= 0 && base_elems >= 0, GEOGCN_E_SIZE, "%s: negative stream position", fn);
+    if (n_rows == 0) return 0;
+    GEOGCN_REQUIRE(Cd && (mask_in || mask_out), GEOGCN_E_NULL, "%s: null pointer (Cd, and one of mask_in / mask_out)", fn);
+    GEOGCN_REQUIRE(F > 0 && F % 4 == 0 && aligned16(Cd) && (reinterpret_cast<uintptr_t>(mask_in) & 3u) == 0 &&
+                       (reinterpret_cast<uintptr_t>(mask_out) & 3u) == 0,
+                   GEOGCN_E_ALIGN, "%s: needs F %% 4 == 0 (one Philox counter / one mask word per float4), a 16-byte aligned Cd "
+                   "and 4-byte aligned masks (F=%d)", fn, F);
+    HotArgs a{};
+    a.n_rows = n_rows; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
+    a.hot_rows = hot_rows; a.n_hot = n_hot; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
+    a.Cd = Cd; a.mask_in = mask_in; a.mask_out = mask_out; a.keep_prob = 1.0f - p_drop; a.scale = 1.0f / (1.0f - p_drop);
+    a.seed = seed; a.offset = offset; a.calls = calls_dev; a.per_call = per_call_elems; a.base = base_elems;
+    return spmm_hot_launch(fn, a, n_hot, act, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

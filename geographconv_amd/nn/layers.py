@@ -296,7 +296,7 @@ class DenseLayer(Layer):
             elif isinstance(input, K.DMat):
                 y = K.gemm(input, self.W.data, bias=bias, act=act, precision=prec)   # bias + act fused
             else:
-                y = K.spmm_x(input, self.W.data, bias=bias, act=act)      # sparse input: X.W0
+                y = self._sparse_input_product(input, bias, act, tape, kwargs)      # sparse input: X.W0
         else:
             comm = kwargs.get('comm')
             if comm is None:
@@ -342,6 +342,26 @@ class DenseLayer(Layer):
         if tape is not None:
             tape[self] = saved
         return y
+
+    def _sparse_input_product(self, input, bias, act, tape, kwargs):
+        """act(X . W0 + b0) -- and, when the layer's only consumer is a dropout layer that is active in this pass
+        (gcnmodel.py:353,357), that dropout in the SAME launch: the product's epilogue draws (or reads the injected) keep
+        mask and stores both the activation and its dropped copy; the DropoutLayer then only picks the result up."""
+        K = backend.active()
+        drop = getattr(self, 'dropout_consumer', None)
+        if (drop is not None and tape is not None and not kwargs.get('deterministic', False) and drop.p > 0 and drop.rescale
+                and tuning.FUSE_DROPOUT):
+            injected = kwargs.get('dropout_mask')
+            n = input.shape[0]
+            pos = {} if injected is not None else drop.stream_position(n, self.num_units, self.W.data.device, kwargs)
+            res = K.spmm_x_dropout(input, self.W.data, bias, act, drop.p, mask_in=injected, seed=drop._seed, **pos)
+            if res is not None:
+                y, yd, mask = res
+                if injected is None:
+                    drop.advance(kwargs.get('device_counters'))
+                tape[('fused_drop', drop)] = (y, yd, mask)
+                return y
+        return K.spmm_x(input, self.W.data, bias=bias, act=act)
 
     def _fusable_sibling(self, input, tape, kwargs):
         """The highway block's conv branch, when its H.W can ride in this gate's launch: one GPU, exact-fp32 products,
@@ -503,6 +523,35 @@ class DropoutLayer(Layer):
         self._calls_dev = None
         self.p = p
         self.rescale = rescale
+        # a sparse-input dense layer directly below may run this dropout in its product's epilogue (DenseLayer._sparse_input_product)
+        if isinstance(incoming, DenseLayer) and getattr(incoming, 'dropout_consumer', None) is None:
+            incoming.dropout_consumer = self
+
+    def stream_position(self, n, F, device, kwargs):
+        """Where in this layer's Philox stream the next mask of an n x F input starts: rows are numbered globally so that
+        every rank draws its own slice of the same stream, successive calls advance it by N_total * F elements
+        (rank-consistent when F % 4 == 0: Philox yields 4 values per counter).  -> keyword arguments for the mask kernels:
+        `offset` (quads) from the host-side call counter, or `calls_dev` / `per_call` / `base` for a captured step, whose
+        replays cannot change kernel arguments: offset = (calls * N_total * F + r0 * F) / 4 is then formed on the device."""
+        comm = kwargs.get('comm')
+        r0 = 0 if comm is None or comm.part is None else comm.part.r0
+        N_total = n if comm is None or comm.part is None else comm.part.N
+        ctr = kwargs.get('device_counters')          # None | 'sync' | 'captured'  (GraphConv hipGraph path)
+        if ctr:
+            import torch
+            if self._calls_dev is None or self._calls_dev.device != device:
+                self._calls_dev = torch.zeros(1, dtype=torch.int64, device=device)
+                ctr = 'sync'
+            if ctr == 'sync':
+                self._calls_dev.fill_(self._calls)
+            return dict(calls_dev=self._calls_dev, per_call=N_total * F, base=r0 * F)
+        return dict(offset=((self._calls * N_total + r0) * F) // 4)
+
+    def advance(self, ctr):
+        """One mask drawn: move the stream on (after the kernel that read the device counter has been enqueued)."""
+        if ctr:
+            backend.active().counter_add(self._calls_dev, 1)
+        self._calls += 1
 
     def forward(self, input, tape, deterministic=False, dropout_mask=None, **kwargs):
         K = backend.active()
@@ -512,32 +561,19 @@ class DropoutLayer(Layer):
             return input
         if not self.rescale:
             raise NotImplementedError("rescale=False is not used by the reference path")
+        pre = tape.pop(('fused_drop', self), None) if tape is not None else None
+        if pre is not None and pre[0] is input:
+            tape[self] = {'mask': pre[2]}              # the layer below already drew the mask and applied it
+            return pre[1]
         mask = dropout_mask
         if mask is None:
-            comm = kwargs.get('comm')
-            r0 = 0 if comm is None or comm.part is None else comm.part.r0
-            # counter offset: rows are numbered globally so every rank draws its own slice of the
-            # same stream; successive calls advance the stream by N_total * F elements
-            # (rank-consistent when F % 4 == 0: Philox yields 4 values per counter)
-            F = input.F
-            N_total = input.n if comm is None or comm.part is None else comm.part.N
-            ctr = kwargs.get('device_counters')          # None | 'sync' | 'captured'  (GraphConv hipGraph path)
-            if ctr:
-                # same stream position, read from a device-resident call counter so that a captured step can
-                # be replayed: offset = (calls * N_total * F + r0 * F) / 4
-                import torch
-                if self._calls_dev is None or self._calls_dev.device != input.device:
-                    self._calls_dev = torch.zeros(1, dtype=torch.int64, device=input.device)
-                    ctr = 'sync'
-                if ctr == 'sync':
-                    self._calls_dev.fill_(self._calls)
-                mask = K.dropout_mask_ctr(input.n, F, self.p, self._seed, self._calls_dev, N_total * F, r0 * F,
+            pos = self.stream_position(input.n, input.F, input.device, dict(kwargs))
+            if 'calls_dev' in pos:
+                mask = K.dropout_mask_ctr(input.n, input.F, self.p, self._seed, pos['calls_dev'], pos['per_call'], pos['base'],
                                           input.device)
-                K.counter_add(self._calls_dev, 1)
             else:
-                offset_quads = ((self._calls * N_total + r0) * F) // 4
-                mask = K.dropout_mask(input.n, F, self.p, self._seed, offset_quads, input.device)
-            self._calls += 1
+                mask = K.dropout_mask(input.n, input.F, self.p, self._seed, pos['offset'], input.device)
+            self.advance(kwargs.get('device_counters'))
         y = K.dropout_apply(input, mask, self.p)
         if tape is not None:
             tape[self] = {'mask': mask}

@@ -794,6 +794,33 @@ def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = Non
     return spmm(x.fwd, W, out=out, bias=bias, act=act)
 
 
+def spmm_x_dropout(x: SparseOperand, W: DMat, bias, act, p, mask_in=None, seed=0, offset=0, calls_dev=None, per_call=0, base=0):
+    """(H0, Hd, mask) = (act(x . W + bias), H0 * keep / (1-p), keep-mask) in ONE launch (geogcn_spmm_csr_hot_dropout_f32):
+    the sparse-input layer with the dropout that follows it (reference gcnmodel.py:353,357) in the product's epilogue.  The
+    keep decisions are those dropout_mask(n, F, p, seed, offset) / dropout_mask_ctr would draw (bit-identical), or `mask_in`
+    (uint8 [n, F] on the device) when a mask is injected.  -> None when the fused kernel does not apply (small X, a width
+    that is not a multiple of 4 or beyond the LDS kernel, value-dropped X): the caller then runs the separate kernels."""
+    if not (isinstance(x.fwd, CSR) and x.fwd.nnz >= tuning.HOT_MIN_NNZ and not x.symmetric and W.F % 4 == 0
+            and act in (ACT_NONE, ACT_TANH) and 0.0 < p < 1.0):
+        return None
+    lib = _ffi.lib()
+    cap = int(lib.geogcn_spmm_hot_capacity(W.F))
+    if cap <= 0:
+        return None
+    hot = x._hot.get(cap)
+    if hot is None:
+        hot = x._hot[cap] = HotCSR(x.fwd, x.fwd.val.cpu().numpy(), cap)
+    n = hot.shape[0]
+    H0, Hd = DMat.empty(n, W.F, W.device), DMat.empty(n, W.F, W.device)
+    mask = mask_in if mask_in is not None else torch.empty((n, W.F), dtype=torch.uint8, device=W.device)
+    check(lib.geogcn_spmm_csr_hot_dropout_f32(n, _p(hot.rowptr), _p(hot.rowsplit), _p(hot.colidx), _p(hot.val), _p(W.t), W.ld,
+                                              _p(hot.hot_rows), hot.n_hot, _p(H0.t), _p(Hd.t), H0.ld, W.F, _p(bias), int(act),
+                                              float(p), _p(mask_in), None if mask_in is not None else _p(mask), int(seed),
+                                              int(offset), _p(calls_dev), int(per_call), int(base), _stream()),
+          'spmm_csr_hot_dropout_f32')
+    return H0, Hd, mask
+
+
 class SpmmTimer:
     """hipEvent pairs around the SpMM row kernel, recorded by the library on the launch stream
     (bench.py's roofline leg; torch.cuda.Event would also do, the library pool avoids per-call

@@ -36,6 +36,10 @@ FUSE_GEMMS = True
 # epilogue's T / H loads cost more than the separate pass: 1.82 ms fused against 1.10 + 0.41), 'all', 'none'
 FUSE_HIGHWAY = 'f32'
 
+# dropout after the sparse-input layer in the epilogue of X . W0 (geogcn_spmm_csr_hot_dropout_f32): one launch instead of
+# product + mask kernel + apply pass (-0.2 ms per TWUS step); same Philox bits, same arithmetic
+FUSE_DROPOUT = True
+
 # ---- X path thresholds ---------------------------------------------------------------------------------------------
 # a column of X denser than this is cheaper as part of a dense N x K panel on the MFMA pipe (2NF flop at ~100 TF) than
 # as nnz row gathers (nnz * 4F bytes at the ~7 TB/s beyond-L2 ceiling): break-even nnz/N = 3.5 %

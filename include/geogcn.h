@@ -86,6 +86,20 @@ int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t
                             const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
                             int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream);
 
+/* The same product with the dropout that FOLLOWS this layer in the reference (lasagne.layers.dropout, gcnmodel.py:357)
+ * in its epilogue:  C = act(A . B + bias)  (the layer output, which the backward differentiates through),
+ * Cd = C * keep / (1 - p_drop)  (what the next layer reads; same pitch ldc) and the keep-mask bytes.  The keep decisions
+ * are those of geogcn_dropout_mask_philox(n_rows, F, p_drop, seed, offset) -- bit-identical -- or, with calls_dev given,
+ * of geogcn_dropout_mask_philox_ctr; with mask_in given they are READ from it instead (parity runs inject the mask).
+ * mask_out (nullable when mask_in is given) receives the mask used, dense [n_rows][F].  One launch replaces the mask
+ * kernel and an apply pass that re-reads C.  Needs F % 4 == 0 (GEOGCN_E_ALIGN otherwise: use the separate calls);
+ * act is tanh or none.                                                                                           */
+int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+                                    const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
+                                    float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act, float p_drop,
+                                    const uint8_t* mask_in, uint8_t* mask_out, uint64_t seed, uint64_t offset,
+                                    const int64_t* calls_dev, int64_t per_call_elems, int64_t base_elems, void* stream);
+
 /* dW[n_words x F] = X^T . G  -- the gradient of S.structured_dot(X, W0) w.r.t. W0 (autodiff of gcnmodel.py:39) for a
  * bag-of-words X whose transpose is given as CSR (rows = vocabulary, columns = documents, STRICTLY ASCENDING inside every
  * row: checked by geogcn_xt_plan_create, GEOGCN_E_ARG otherwise -- the sweep and its entry points rely on it).  Instead of gathering

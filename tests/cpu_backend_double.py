@@ -74,6 +74,10 @@ def spmm_x(x, W, out=None, bias=None, act=ACT_NONE):
     return spmm(x.fwd, W, out=out, bias=bias, act=act)
 
 
+def spmm_x_dropout(x, W, bias, act, p, mask_in=None, seed=0, offset=0, calls_dev=None, per_call=0, base=0):
+    return None          # (the fused product + dropout launch is a property of the HIP backend: callers fall back)
+
+
 def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None):
     a = _v(A).T if transA else _v(A)
     b = _v(B).T if transB else _v(B)

@@ -27,10 +27,10 @@ def cmu():
     return dict(A=A, X=X, Y=Y, tr=tr, dev=dev, te=te, C=C, hid=hid, params=params, mask=mask)
 
 
-def _clf(c, p=0.5, reg=0.0, highway=True, hid=None, params=None):
+def _clf(c, p=0.5, reg=0.0, highway=True, hid=None, params=None, hip_graph=None):
     from geographconv_amd.gcnmodel import GraphConv
     from geographconv_amd.nn import layers as L
-    clf = GraphConv(c['X'].shape[1], c['C'], hid or c['hid'], reg, p, highway=highway)
+    clf = GraphConv(c['X'].shape[1], c['C'], hid or c['hid'], reg, p, highway=highway, hip_graph=hip_graph)
     clf.build_model(c['A'], seed=77)
     L.set_all_param_values(clf.l_out, params or c['params'])
     return clf
@@ -389,6 +389,39 @@ def test_hip_graph_replay_equals_eager_steps(cmu):
     ytr2[:5] = (ytr2[:5] + 1) % c['C']
     out = clfg.f_train(c['X'], ytr2, c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
     assert clfg._hg['graph'] is None and np.isfinite(out[0])
+
+
+def test_dropout_in_the_first_layers_epilogue_equals_the_separate_kernels(cmu, monkeypatch):
+    """tuning.FUSE_DROPOUT: the dropout after the sparse-input layer (gcnmodel.py:353,357) drawn and applied in the epilogue
+    of X . W0 -- three training steps with the Philox stream (no injected mask) are bitwise equal to the run with the
+    separate mask / apply kernels, eager and captured; so is a step with an injected mask."""
+    from geographconv_amd import tuning
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    monkeypatch.setattr(tuning, 'HOT_MIN_NNZ', 0)               # (the CMU X is below the production threshold of the LDS kernel)
+    runs = {}
+    for fused in (True, False):
+        for graph in (False, True):
+            monkeypatch.setattr(tuning, 'FUSE_DROPOUT', fused)
+            clf = _clf(c, hip_graph=graph)
+            hist = []
+            for step in range(4):
+                out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+                hist.append([float(v) for v in out[:4]])
+            runs[(fused, graph)] = (hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out))
+    ref = runs[(False, False)]
+    for key, (hist, P, params) in runs.items():
+        assert hist == ref[0] and np.array_equal(P, ref[1]), key
+        assert all(np.array_equal(a, b) for a, b in zip(params, ref[2])), key
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tuning, 'FUSE_DROPOUT', fused)
+        clf = _clf(c)
+        clf.inject_dropout_mask(c['mask'])
+        out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+        outs.append(([float(v) for v in out[:4]], np.asarray(out[4]).copy(), clf.get_grads()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
 
 
 def test_asymmetric_adjacency_uses_explicit_transpose():

@@ -535,6 +535,44 @@ def test_spmm_hot_rows_in_lds(dev, n_docs, n_words, mean, F, n_hot):
     assert int(_ffi.lib().geogcn_spmm_hot_capacity(2000)) == 0
 
 
+@pytest.mark.parametrize("n_docs,n_words,mean,F,p", [(20000, 1500, 30, 300, 0.5), (7001, 700, 25, 64, 0.2), (3000, 300, 12, 128, 0.8)])
+def test_spmm_hot_with_the_dropout_in_its_epilogue(dev, n_docs, n_words, mean, F, p, monkeypatch):
+    """geogcn_spmm_csr_hot_dropout_f32 == geogcn_spmm_csr_hot_f32 + geogcn_dropout_mask_philox + geogcn_dropout_apply_f32,
+    bit for bit (activation, dropped copy, mask bytes): Philox stream at a non-zero offset, the device-counter form of a
+    captured step, and an injected mask.  F % 4 != 0 is refused (the caller then runs the separate kernels)."""
+    from geographconv_amd import _ffi, ops
+    monkeypatch.setattr(tuning, 'HOT_MIN_NNZ', 0)
+    X = sps.csr_matrix(_bow(n_docs, n_words, mean, seed=5))
+    x = ops.SparseOperand.from_scipy(X, dev)
+    W = ops.DMat.from_numpy(_rand((n_words, F), 4, 0.1), dev)
+    b = torch.from_numpy(_rand((F,), 5, 0.1)).to(dev)
+    seed, offset = 123456789, 77 * n_docs * F // 4
+    H0 = ops.spmm_x(x, W, bias=b, act=ops.ACT_TANH)
+    mask = ops.dropout_mask(n_docs, F, p, seed, offset, dev)
+    Hd = ops.dropout_apply(H0, mask, p)
+    got = ops.spmm_x_dropout(x, W, b, ops.ACT_TANH, p, seed=seed, offset=offset)
+    assert got is not None
+    assert torch.equal(got[0].t, H0.t) and torch.equal(got[2], mask) and torch.equal(got[1].t, Hd.t)
+    assert 0.9 * (1 - p) < float(mask.float().mean()) < 1.1 * (1 - p)
+    # device-resident call counter (hipGraph replays): offset = (calls * per_call + base) / 4
+    calls = torch.tensor([77], dtype=torch.int64, device=dev)
+    got = ops.spmm_x_dropout(x, W, b, ops.ACT_TANH, p, seed=seed, calls_dev=calls, per_call=n_docs * F, base=0)
+    assert torch.equal(got[2], mask) and torch.equal(got[1].t, Hd.t)
+    # injected mask
+    inj = (torch.rand((n_docs, F), device=dev) < 0.5).to(torch.uint8)
+    got = ops.spmm_x_dropout(x, W, b, ops.ACT_TANH, p, mask_in=inj)
+    assert got[2] is inj and torch.equal(got[0].t, H0.t) and torch.equal(got[1].t, ops.dropout_apply(H0, inj, p).t)
+    # not applicable: width not a multiple of 4, p = 0
+    W7 = ops.DMat.from_numpy(_rand((n_words, 30), 4, 0.1), dev)
+    assert ops.spmm_x_dropout(x, W7, None, ops.ACT_TANH, p) is None and ops.spmm_x_dropout(x, W, b, ops.ACT_TANH, 0.0) is None
+    lib = _ffi.lib()
+    hot = next(iter(x._hot.values()))
+    rc = lib.geogcn_spmm_csr_hot_dropout_f32(n_docs, ops._p(hot.rowptr), ops._p(hot.rowsplit), ops._p(hot.colidx), ops._p(hot.val),
+                                             ops._p(W7.t), W7.ld, ops._p(hot.hot_rows), 0, ops._p(H0.t), ops._p(Hd.t), H0.ld, 30,
+                                             None, 1, 0.5, None, ops._p(mask), 1, 0, None, 0, 0, ops._stream())
+    assert rc == -3                                        # GEOGCN_E_ALIGN
+
+
 def test_gemm_asymmetric_detects_transposes(dev):
     """A = I check with an asymmetric B (guide rule: symmetric inputs hide row/col swaps)."""
     from geographconv_amd import ops
