@@ -87,6 +87,8 @@ SIGNATURES = {
     'geogcn_softmax_ce_bwd_db_workspace_bytes': (c_sz, [c_i32]),
     'geogcn_softmax_ce_bwd_db_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_i64, c_ptr,
                                              c_ptr, c_sz, c_ptr]),
+    'geogcn_softmax_ce_rows_bwd_db_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_sz,
+                                                  c_ptr]),
     'geogcn_gather_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_scatter_rows_f32': (c_i32, [c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_comm_available': (c_i32, []),

@@ -164,6 +164,9 @@ __global__ __launch_bounds__(TPB) void ce_bwd_kernel(int C, const float* __restr
 // afterwards (colsum_final) -- no pass over the N x C matrix.
 constexpr int kCeBlocks = 1024;
 constexpr int kCeWaves = kCeBlocks * kWavesPerBlock;
+// COMPACT = 1: D has one row per INDEX (row j = the gradient of output row idx[j]) -- plain stores, no zero fill of an
+// N x C matrix, no atomics; pad columns [C, cpad) of each row are written as zeros
+template <int COMPACT>
 __global__ __launch_bounds__(TPB) void ce_bwd_db_kernel(int C, const float* __restrict__ P, int64_t ldp,
                                                         const int* __restrict__ idx, int64_t n_idx,
                                                         const int* __restrict__ y, float inv_n,
@@ -183,8 +186,11 @@ __global__ __launch_bounds__(TPB) void ce_bwd_db_kernel(int C, const float* __re
             const int c = lane + kWave * k;
             if (c < C) {
                 const float g = (P[row * ldp + c] - (c == yy ? 1.0f : 0.0f)) * inv_n;
-                atomicAdd(D + row * ldd + c, g);
+                if constexpr (COMPACT) D[j * ldd + c] = g;
+                else atomicAdd(D + row * ldd + c, g);
                 acc[k] += g;
+            } else if (COMPACT && c < cpad) {
+                D[j * ldd + c] = 0.f;
             }
         }
     }
@@ -358,8 +364,28 @@ int geogcn_softmax_ce_bwd_db_f32(int64_t n, int32_t C, const float* probs, int64
     GEOGCN_REQUIRE(probs && idx && y, GEOGCN_E_NULL, "softmax_ce_bwd_db_f32: null pointer");
     GEOGCN_REQUIRE(ws && ws_bytes >= geogcn_softmax_ce_bwd_db_workspace_bytes(C), GEOGCN_E_ARG,
                    "softmax_ce_bwd_db_f32: workspace too small");
-    hipLaunchKernelGGL(ce_bwd_db_kernel, dim3(kCeBlocks), dim3(TPB), 0, st, C, probs, ldp, idx, n_idx, y,
+    hipLaunchKernelGGL(ce_bwd_db_kernel<0>, dim3(kCeBlocks), dim3(TPB), 0, st, C, probs, ldp, idx, n_idx, y,
                        inv_n, dlogits, ldd, (float*)ws, cpad);
+    GEOGCN_LAUNCH_CHECK("ce_bwd_db_kernel");
+    return colsum_final_launch(kCeBlocks, C, (const float*)ws, cpad, db, st);
+}
+
+int geogcn_softmax_ce_rows_bwd_db_f32(int32_t C, const float* probs, int64_t ldp, const int32_t* idx, int64_t n_idx,
+                                      const int32_t* y, float inv_n, float* drows, int64_t ldd, float* db, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    const char* fn = "softmax_ce_rows_bwd_db_f32";
+    GEOGCN_REQUIRE(C >= 0 && n_idx >= 0, GEOGCN_E_SIZE, "%s: negative size", fn);
+    if (C == 0) return 0;
+    GEOGCN_REQUIRE(db, GEOGCN_E_NULL, "%s: null db", fn);
+    const int cpad = (C + 3) / 4 * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_idx == 0) return zero_fill_async(db, (size_t)cpad * sizeof(float), st);
+    GEOGCN_REQUIRE(probs && idx && y && drows, GEOGCN_E_NULL, "%s: null pointer", fn);
+    GEOGCN_REQUIRE(ldd >= cpad, GEOGCN_E_SIZE, "%s: ldd < roundup4(C)", fn);
+    GEOGCN_REQUIRE(C <= 16 * kWave, GEOGCN_E_ARG, "%s: C=%d > %d", fn, C, 16 * kWave);
+    GEOGCN_REQUIRE(ws && ws_bytes >= geogcn_softmax_ce_bwd_db_workspace_bytes(C), GEOGCN_E_ARG, "%s: workspace too small", fn);
+    hipLaunchKernelGGL(ce_bwd_db_kernel<1>, dim3(kCeBlocks), dim3(TPB), 0, st, C, probs, ldp, idx, n_idx, y, inv_n, drows, ldd,
+                       (float*)ws, cpad);
     GEOGCN_LAUNCH_CHECK("ce_bwd_db_kernel");
     return colsum_final_launch(kCeBlocks, C, (const float*)ws, cpad, db, st);
 }

@@ -566,13 +566,17 @@ class GraphConv():
         self._idx_cache = {}
         return hit
 
-    def _train_columns_operand(self, g, A, train_indices):
-        """CSR of A^T restricted to the columns in `train_indices` (cached per graph and index set)."""
+    def _train_columns_operand(self, g, A, train_indices, allow_compact=True):
+        """CSR of A^T restricted to the columns in `train_indices` (cached per graph and index set) -> (csr, compact).
+        One GPU, unique indices: the COMPACT form -- the kept columns renumbered by their position in `train_indices`
+        (shape N x n_train, stored order unchanged), to be multiplied by the compact cross-entropy gradient (one row per
+        index) instead of a zero-filled N x C matrix.  Partitioned runs and index vectors with repeats keep node-numbered
+        columns and the N x C gradient (the exchange moves whole row blocks; a repeated index accumulates)."""
         idx = np.asarray(train_indices)
-        key = _content_key(idx)
+        key = (_content_key(idx), bool(allow_compact))
         hit = g.get('A_tr')
         if hit is not None and hit[0] == key:
-            return hit[1]
+            return hit[1], hit[2]
         if g.get('ro') is not None:
             A, idx = g['A_host'], g['ro'].indices(idx)
         At = sps.csr_matrix(sps.csr_matrix(A).T).astype(np.float32)
@@ -581,11 +585,18 @@ class GraphConv():
         sel = keep[At.indices]
         row_of = np.repeat(np.arange(At.shape[0], dtype=np.int64), np.diff(At.indptr))
         indptr = np.concatenate([[0], np.cumsum(np.bincount(row_of[sel], minlength=At.shape[0]))])
-        M = sps.csr_matrix((At.data[sel], At.indices[sel], indptr.astype(np.int32)), shape=At.shape)
-        op = g['comm'].graph_operand(M) if self._dist(g['comm']) else None
-        csr = op.fwd if op is not None else backend.active().CSR(M, self.device)
-        g['A_tr'] = (key, csr)
-        return csr
+        compact = allow_compact and not self._dist(g['comm']) and len(idx) > 0 and len(np.unique(idx)) == len(idx)
+        if compact:
+            pos_of = np.full(At.shape[1], -1, dtype=np.int32)
+            pos_of[idx] = np.arange(len(idx), dtype=np.int32)
+            M = sps.csr_matrix((At.data[sel], pos_of[At.indices[sel]], indptr.astype(np.int32)), shape=(At.shape[0], len(idx)))
+            csr = backend.active().CSR(M, self.device, sort=False)      # (node order kept: the same sums as the N x C form)
+        else:
+            M = sps.csr_matrix((At.data[sel], At.indices[sel], indptr.astype(np.int32)), shape=At.shape)
+            op = g['comm'].graph_operand(M) if self._dist(g['comm']) else None
+            csr = op.fwd if op is not None else backend.active().CSR(M, self.device)
+        g['A_tr'] = (key, csr, compact)
+        return csr, compact
 
     def _device_indices(self, comm, idx, y=None, ro=None):
         """Index / label vectors on the device (local share when distributed) + the global count.  Cached by content.
@@ -677,11 +688,18 @@ class GraphConv():
             K.reg_penalty(self.store.p, self.store.regmask, self.regul_coef, self.regul_coef, out=sc[4:5])
         # backward: d(mean CE over train rows)/d logits, then the reverse sweep
         fuse_db = self.l_out.b is not None and self.l_out.b.grad is not None and P.F <= 1024
-        dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr),
-                                   out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)),
-                                   **({'db': self.l_out.b.grad} if fuse_db else {}))
-        # dlogits is zero outside the training rows: A^T . dlogits only needs the training COLUMNS of A^T
-        kw_b = dict(kw, A_bwd_rows_hint=(self.l_out, self._train_columns_operand(g, A, train_indices)))
+        # dlogits is zero outside the training rows: A^T . dlogits only needs the training COLUMNS of A^T -- and, on one
+        # GPU, only the training ROWS of dlogits are ever formed (compact: n_train x C instead of a zero-filled N x C)
+        A_tr, compact = self._train_columns_operand(g, A, train_indices)
+        if compact and fuse_db:
+            dlogits = K.softmax_ce_rows_bwd(P, tr_idx, tr_y, 1.0 / max(1, n_tr), self.l_out.b.grad)
+        else:
+            if compact:
+                A_tr = self._train_columns_operand(g, A, train_indices, allow_compact=False)[0]
+            dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr),
+                                       out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)),
+                                       **({'db': self.l_out.b.grad} if fuse_db else {}))
+        kw_b = dict(kw, A_bwd_rows_hint=(self.l_out, A_tr))
         L.backward(self.l_out, L.PreAct(dlogits, bias_done=fuse_db), tape, **kw_b)
         if self._dist(comm):
             comm.all_reduce_sum_(self.store.g)

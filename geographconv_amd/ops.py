@@ -217,7 +217,9 @@ class CSR:
     """Device CSR (int32 indices, fp32 values, rows in ascending column order) + the long-row split plan for the SpMM
     kernel."""
 
-    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None):
+    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None, sort=True):
+        """`sort=False` keeps the given stored order inside each row (the SpMM accumulates in stored order and does not
+        need it ascending; geogcn_xt_plan_create does and checks)."""
         require_gpu()
         m = sps.csr_matrix(m)
         if long_row_nnz is None:
@@ -227,7 +229,7 @@ class CSR:
             long_row_nnz, chunk_nnz = (256, chunk_nnz or 128) if m.nnz >= 2_000_000 else (48, chunk_nnz or 48)
         elif chunk_nnz is None:
             chunk_nnz = 128
-        if not m.has_sorted_indices:
+        if sort and not m.has_sorted_indices:
             m = m.copy()
             m.sort_indices()
         if m.nnz >= 2 ** 31 or max(m.shape) >= 2 ** 31:
@@ -527,6 +529,17 @@ def softmax_ce_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, out: DMat = None
         return out
     check(_ffi.lib().geogcn_softmax_ce_bwd_f32(P.n, P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y), float(inv_n),
                                                _p(out.t), out.ld, _stream()), 'softmax_ce_bwd_f32')
+    return out
+
+
+def softmax_ce_rows_bwd(P: DMat, idx: torch.Tensor, y: torch.Tensor, inv_n, db: torch.Tensor, out: DMat = None):
+    """COMPACT gradient of the mean cross-entropy: one row per index (row j belongs to output row idx[j]) + the bias
+    gradient db; geogcn_softmax_ce_rows_bwd_db_f32."""
+    lib = _ffi.lib()
+    out = DMat.empty(idx.numel(), P.F, P.device, ld=gather_ld(P.F)) if out is None else out
+    w = _ws_for(P.device).get(lib.geogcn_softmax_ce_bwd_db_workspace_bytes(P.F))
+    check(lib.geogcn_softmax_ce_rows_bwd_db_f32(P.F, _p(P.t), P.ld, _p(idx), idx.numel(), _p(y), float(inv_n), _p(out.t), out.ld,
+                                                _p(db), _p(w), w.numel(), _stream()), 'softmax_ce_rows_bwd_db_f32')
     return out
 
 

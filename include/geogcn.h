@@ -314,6 +314,13 @@ size_t geogcn_softmax_ce_bwd_db_workspace_bytes(int32_t C);
 int geogcn_softmax_ce_bwd_db_f32(int64_t n, int32_t C, const float* probs, int64_t ldp, const int32_t* idx,
                                  int64_t n_idx, const int32_t* y, float inv_n, float* dlogits, int64_t ldd,
                                  float* db, void* ws, size_t ws_bytes, void* stream);
+/* COMPACT form: drows[j, :] = (P[idx[j], :] - onehot(y[j])) * inv_n for j < n_idx -- one row per INDEX instead of a
+ * zero-filled N x C matrix with the indexed rows scattered into it -- plus db as above.  The consumer multiplies by the
+ * transposed adjacency restricted to the indexed COLUMNS, renumbered by position in idx (the structural zeros of the
+ * N x C gradient are never stored, written or gathered).  ldd >= roundup4(C); pad columns [C, roundup4(C)) are zeroed. */
+int geogcn_softmax_ce_rows_bwd_db_f32(int32_t C, const float* probs, int64_t ldp, const int32_t* idx, int64_t n_idx,
+                                      const int32_t* y, float inv_n, float* drows, int64_t ldd, float* db, void* ws,
+                                      size_t ws_bytes, void* stream);
 /* out[j, :] = X[idx[j], :]   AdvancedSubtensor1 (gcnmodel.py:376,378,393); dense out (pitch F)  */
 int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t* idx, int64_t n_idx,
                            float* out, int64_t ldo, void* stream);

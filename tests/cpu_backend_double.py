@@ -219,6 +219,16 @@ def softmax_ce_bwd(P, idx, y, out=None, inv_n=None, db=None):
     return out
 
 
+def softmax_ce_rows_bwd(P, idx, y, inv_n, db, out=None):
+    i = idx.cpu().numpy().astype(np.int64)
+    g = _v(P)[i].copy()
+    g[np.arange(len(i)), y.cpu().numpy().astype(np.int64)] -= 1.0
+    g *= np.float32(inv_n)
+    out = DMat.from_numpy(g.astype(np.float32), P.device) if out is None else out
+    db[:P.F] = torch.from_numpy(g.sum(axis=0).astype(np.float32))
+    return out
+
+
 def gather_rows(X, idx, out=None):
     return torch.from_numpy(_v(X)[idx.numpy()].copy())
 

@@ -424,6 +424,36 @@ def test_dropout_in_the_first_layers_epilogue_equals_the_separate_kernels(cmu, m
     assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
 
 
+def test_compact_cross_entropy_gradient_equals_the_scattered_one(cmu, monkeypatch):
+    """One GPU: the output layer's backward forms only the training ROWS of dlogits (n_train x C, geogcn_softmax_ce_rows_bwd_db_f32)
+    and multiplies by A^T restricted to the training columns renumbered by position -- bitwise the same step as the
+    zero-filled N x C gradient with scattered rows (same stored order, same sums); an index vector with a repeat falls back
+    to the scattered form (a repeated row accumulates)."""
+    from geographconv_amd.gcnmodel import GraphConv
+    c = cmu
+    tr = np.random.RandomState(0).permutation(c['tr'])            # unsorted on purpose: positions != node order
+    runs = []
+    for compact in (True, False):
+        clf = _clf(c)
+        clf.inject_dropout_mask(c['mask'])
+        if not compact:
+            orig = GraphConv._train_columns_operand
+            monkeypatch.setattr(GraphConv, '_train_columns_operand',
+                                lambda self, g, A, ti, allow_compact=True: orig(self, g, A, ti, allow_compact=False))
+        out = clf.f_train(c['X'], c['Y'][tr], c['Y'][c['dev']], c['A'], tr, c['dev'])
+        g = clf._device_graph(c['X'], c['A'])
+        assert g['A_tr'][2] is compact and g['A_tr'][1].shape[1] == (len(tr) if compact else c['A'].shape[0])
+        runs.append(([float(v) for v in out[:4]], clf.get_grads()))
+    assert runs[0][0] == runs[1][0]
+    for i, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
+        assert np.array_equal(a, b), i
+    monkeypatch.undo()
+    clf = _clf(c)
+    rep = np.r_[tr, tr[:3]]
+    clf.f_train(c['X'], c['Y'][rep], c['Y'][c['dev']], c['A'], rep, c['dev'])
+    assert clf._device_graph(c['X'], c['A'])['A_tr'][2] is False
+
+
 def test_asymmetric_adjacency_uses_explicit_transpose():
     """The reference's A_hat is symmetric (unit weights), and then one CSR serves A.Z and A^T.dS.  That is checked at
     upload, not assumed: a row-normalised D^-1 (A + I) is NOT symmetric, the backward must multiply by the explicit
