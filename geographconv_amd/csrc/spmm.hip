@@ -207,28 +207,44 @@ __device__ __forceinline__ float4 highway_mix(const float4 t, const float4 hc, c
 }
 
 struct XcdRows {
-    int lo[kNumXCD + 1];
+    int lo[kNumXCD + 1];         // XCD x owns rows [lo[x], lo[x + 1])
+    int cbase[kNumXCD + 1];      // ... and the long-row chunks [cbase[x], cbase[x + 1]) (chunks are numbered by row)
 };
+constexpr int kIdleSlot = INT32_MIN;
 
-// ONE launch covers every stored edge: the leading `n_chunk_blocks` blocks take the 128-nonzero chunks
-// of the long rows (raw partial sums into the workspace P), the remaining blocks take one CSR row per
-// 16-lane group (long rows skipped there) with the fused epilogue.  The chunk work is issued first so
-// that it overlaps the bulk instead of running as an under-occupied launch of its own.
+// ONE launch covers every stored edge.  Block b runs on XCD b % 8 (measured; speed only) and is the (b / 8)-th block of
+// that XCD's SCHEDULE: XCD x takes the CONTIGUOUS row range [lo[x], lo[x+1]) -- one CSR row per 16-lane group, fused
+// epilogue, rows longer than long_row_nnz skipped -- and the 128-nonzero chunks of the long rows that lie in that range
+// (raw partial sums into the workspace P, combined by spmm_long_reduce_kernel), a chunk block taking its turn where the
+// long row itself sits in the sweep.  When the node numbering has locality (geographconv_amd.graph: community
+// reordering) the rows an XCD works on at any moment share their neighbours and the gathered rows of B stay in that
+// XCD's 4 MB L2 -- the hub rows' chunks included (until round 3 they ran in the leading blocks of the launch on arbitrary
+// XCDs, outside the window: 13 % of the entries of the TwitterUS-shape graphs).  The ranges hold equal numbers of stored
+// entries, not of rows (a hub-first numbering would otherwise give one XCD all the work).
+// `sched` (host-built per plan, nullable when there are no long rows): entry >= 0 = row block v of the XCD's range,
+// < 0 = chunk block -1 - v of its chunk range, kIdleSlot = nothing.  per_xcd = 0 and no schedule: plain b -> row block map.
 template <int K4, int ACT, int G, int BF, int HW = 0>
 __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
-    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, int n_chunk_blocks, int n_chunks,
+    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, const int* __restrict__ sched,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
     const HwArgs hw, const int per_xcd, const XcdRows xr) {
+    constexpr int kGpb = kRowBlock / G;       // groups (= rows, = chunks) per block
     const int lane16 = threadIdx.x % G;
     const int nF4 = (F + 3) >> 2;
     float4 acc[K4];
 #pragma unroll
     for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((int)blockIdx.x < n_chunk_blocks) {
-        const int ch = blockIdx.x * (kRowBlock / G) + (threadIdx.x / G);
-        if (ch >= n_chunks) return;
+    const int x = blockIdx.x % kNumXCD;
+    int v = blockIdx.x / kNumXCD;             // without a schedule: the v-th row block of XCD x
+    if (sched) {
+        v = sched[blockIdx.x];
+        if (v == kIdleSlot) return;
+    }
+    if (v < 0) {
+        const int ch = xr.cbase[x] + (-1 - v) * kGpb + (threadIdx.x / G);
+        if (ch >= xr.cbase[x + 1]) return;
         const int cs = chunk_start[ch], ce = chunk_end[ch];
         group_accumulate<K4, G, BF>(cs, ce, lane16, nF4, colidx, val, B, ldb, acc);
         float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
@@ -239,29 +255,19 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
         }
         return;
     }
-    // XCD-aware row blocks: block b runs on XCD b % 8 (measured; speed only), so XCD x takes the CONTIGUOUS range of row
-    // blocks [x * per_xcd, (x + 1) * per_xcd) and walks it in launch order.  When the node numbering has locality
-    // (geographconv_amd.graph: community reordering) the rows an XCD works on at any moment share their neighbours, and
-    // the gathered rows of B stay in that XCD's 4 MB L2; with the plain b -> row block map the eight L2s would each
-    // see every community in flight.  The ranges hold equal numbers of stored entries, not of rows (a hub-first
-    // numbering would otherwise give one XCD all the work).  per_xcd = 0: plain map.
-    int rb = blockIdx.x - n_chunk_blocks;
-    int row_lo = 0, row_end = n_rows;
+    int row;
     if (per_xcd > 0) {
-        // XCD x owns rows [xr.lo[x], xr.lo[x + 1]) (multiples of kRowAlign: balanced by stored entries on the host)
-        const int x = rb % kNumXCD;
-        rb = xr.lo[x] / (kRowBlock / G) + rb / kNumXCD;
-        row_lo = xr.lo[x];
-        row_end = xr.lo[x + 1];
+        // (lo[x] is a multiple of kRowAlign or n_rows itself: counting from lo[x] a block never reaches below its range --
+        //  harmless for a plain product, which would just be written twice, but the accumulate form reads what it writes)
+        row = xr.lo[x] + v * kGpb + (threadIdx.x / G);
+        if (row >= xr.lo[x + 1]) return;
+    } else {
+        row = (int)blockIdx.x * kGpb + (threadIdx.x / G);
+        if (row >= n_rows) return;
     }
-    const int row = rb * (kRowBlock / G) + (threadIdx.x / G);
-    // (a boundary clamped to n_rows need not be a multiple of the block's rows: the division above then starts the block
-    //  BELOW row_lo, inside the previous XCD's range -- harmless for a plain product, which would just be written twice,
-    //  but the accumulate form reads what it writes)
-    if (row < row_lo || row >= row_end) return;
     const int s = rowptr[row];
     const int e = rowptr[row + 1];
-    if (e - s > long_row_nnz) return;       // its chunks were handled by the leading blocks
+    if (e - s > long_row_nnz) return;       // a long row: its chunks are separate entries of the schedule
     if (hw.init) {
         const float4* irow = reinterpret_cast<const float4*>(hw.init + (int64_t)row * hw.ld_init);
 #pragma unroll
@@ -374,6 +380,9 @@ struct geogcn_spmm_plan {
     int* d_chunk_start = nullptr;  // [n_chunks]
     int* d_chunk_end = nullptr;    // [n_chunks]
     int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per-XCD row ranges (multiples of 64 = kRowAlign), equal stored entries
+    int xcd_cbase[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-XCD chunk ranges (chunks are numbered in row order)
+    int* d_sched[2] = {nullptr, nullptr};             // per-XCD block schedules for 16- / 8-lane groups (only with long rows)
+    int sched_slots[2] = {0, 0};                      // blocks per XCD in each
     // profiling aid (geogcn_spmm_plan_attach_timer): the caller's event pool, sampled by the products that run on THIS plan
     geogcn_timer* timer = nullptr;
     int32_t timer_F = 0;
@@ -395,20 +404,26 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
     constexpr int xcd_rows = 1;      // (0 = plain block -> row-block map: the A/B of DESIGN.md section 4.1)
-    // (chunk blocks padded to a multiple of 8 so that the row blocks start on XCD 0; surplus blocks exit at once)
-    const int n_chunk_blocks = (int)(cdiv(cdiv(n_chunks, kGroupsPerBlock), kNumXCD) * kNumXCD);
     const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
     const int n_row_blocks = (int)cdiv(n_rows, kGroupsPerBlock);
-    XcdRows xr;
+    XcdRows xr{};
     int per_xcd = 0;
+    const int* sched = nullptr;
     if (xcd_rows && plan) {
-        for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = plan->xcd_lo[x];
+        for (int x = 0; x <= kNumXCD; ++x) {
+            xr.lo[x] = plan->xcd_lo[x];
+            xr.cbase[x] = plan->xcd_cbase[x];
+        }
         for (int x = 0; x < kNumXCD; ++x) per_xcd = std::max(per_xcd, (int)cdiv(xr.lo[x + 1] - xr.lo[x], kGroupsPerBlock));
+        if (n_chunks > 0) {       // row blocks and chunk blocks interleaved per XCD (host-built at plan creation)
+            sched = plan->d_sched[G == 8 ? 1 : 0];
+            per_xcd = plan->sched_slots[G == 8 ? 1 : 0];
+        }
     } else if (xcd_rows) {
         per_xcd = (int)cdiv(cdiv(n_row_blocks, kNumXCD) * kGroupsPerBlock, kRowAlign) * kRowAlign / kGroupsPerBlock;
         for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = (int)std::min<int64_t>(n_rows, (int64_t)x * per_xcd * kGroupsPerBlock);
     }
-    const dim3 grid((unsigned)(n_chunk_blocks + (per_xcd ? per_xcd * kNumXCD : n_row_blocks)));
+    const dim3 grid((unsigned)(per_xcd ? per_xcd * kNumXCD : n_row_blocks));
     // the timer rides on the PLAN handle the caller passes (no library-global state): sampled are the products on this plan
     // whose width matches, except the fused highway launches (they move other bytes: not the kernel bench.py prices)
     geogcn_timer* tm = plan ? plan->timer : nullptr;
@@ -417,7 +432,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
 #define GEOGCN_ROWS(ACT) GEOGCN_ROWS__(ACT, 0)
 #define GEOGCN_ROWS__(ACT, HW_)                                                                  \
     hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, G, BF, HW_>), grid, dim3(kRowBlock), 0, st, n_rows, rowptr,   \
-                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz, n_chunk_blocks, n_chunks, \
+                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz, sched,                    \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, hw, per_xcd, xr)
     if (n_rows > 0) {
         if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 1); }        // highway epilogue: tanh branch only (checked by the caller)
@@ -641,12 +656,10 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t 
     long_first.push_back((int)cs.size());
     auto* plan = new geogcn_spmm_plan();
     {
-        // row ranges of the 8 XCDs: cut where the running count of (short-row) stored entries + a per-row term crosses
-        // k/8 of the total, rounded to 32 rows (= whole row blocks for 8- and 16-lane groups)
-        auto cost = [&](int r) -> int64_t {
-            const int64_t nz = rowptr_host[r + 1] - rowptr_host[r];
-            return (nz > long_row_nnz ? 0 : nz) + 4;
-        };
+        // row ranges of the 8 XCDs: cut where the running count of stored entries + a per-row term crosses k/8 of the
+        // total, rounded to 64 rows (= whole row blocks for 8- and 16-lane groups).  Long rows count in full: their chunks
+        // run on the XCD that owns the row.
+        auto cost = [&](int r) -> int64_t { return (int64_t)(rowptr_host[r + 1] - rowptr_host[r]) + 4; };
         int64_t total = 0;
         for (int r = 0; r < n_rows; ++r) total += cost(r);
         int64_t run = 0;
@@ -661,6 +674,37 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t 
         for (; x < 8; ++x) plan->xcd_lo[x] = n_rows;
         plan->xcd_lo[8] = n_rows;
         for (int k = 1; k <= 8; ++k) plan->xcd_lo[k] = std::max(plan->xcd_lo[k], plan->xcd_lo[k - 1]);
+    }
+    // chunk ranges of the XCDs (chunks were numbered in row order above) and, per group width, the XCDs' block schedules:
+    // the row blocks of the range in order, each chunk block slotted in just before the row block its first long row is in
+    std::vector<int> sched[2];
+    if (!cs.empty()) {
+        std::vector<int> chunk_row(cs.size());
+        for (size_t lr = 0; lr < long_rows.size(); ++lr)
+            for (int c = long_first[lr]; c < long_first[lr + 1]; ++c) chunk_row[c] = long_rows[lr];
+        for (int x = 0; x <= kNumXCD; ++x)
+            plan->xcd_cbase[x] = (int)(std::lower_bound(chunk_row.begin(), chunk_row.end(), plan->xcd_lo[x]) - chunk_row.begin());
+        plan->xcd_cbase[kNumXCD] = (int)cs.size();
+        for (int w = 0; w < 2; ++w) {
+            const int gpb = kRowBlock / (w ? 8 : 16);
+            std::vector<std::vector<int>> lists(kNumXCD);
+            size_t slots = 0;
+            for (int x = 0; x < kNumXCD; ++x) {
+                const int lo = plan->xcd_lo[x], hi = plan->xcd_lo[x + 1];
+                const int rb = (int)cdiv(hi - lo, gpb), cb = (int)cdiv(plan->xcd_cbase[x + 1] - plan->xcd_cbase[x], gpb);
+                int c = 0;
+                for (int j = 0; j < rb; ++j) {
+                    while (c < cb && (chunk_row[plan->xcd_cbase[x] + (size_t)c * gpb] - lo) / gpb <= j) lists[x].push_back(-1 - c++);
+                    lists[x].push_back(j);
+                }
+                while (c < cb) lists[x].push_back(-1 - c++);
+                slots = std::max(slots, lists[x].size());
+            }
+            plan->sched_slots[w] = (int)slots;
+            sched[w].assign(slots * kNumXCD, kIdleSlot);
+            for (int x = 0; x < kNumXCD; ++x)
+                for (size_t k = 0; k < lists[x].size(); ++k) sched[w][k * kNumXCD + x] = lists[x][k];
+        }
     }
     plan->n_rows = n_rows;
     plan->long_row_nnz = long_row_nnz;
@@ -678,6 +722,8 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t 
         if (e == hipSuccess) e = upload(long_first, &plan->d_long_first);
         if (e == hipSuccess) e = upload(cs, &plan->d_chunk_start);
         if (e == hipSuccess) e = upload(ce, &plan->d_chunk_end);
+        if (e == hipSuccess) e = upload(sched[0], &plan->d_sched[0]);
+        if (e == hipSuccess) e = upload(sched[1], &plan->d_sched[1]);
         if (e != hipSuccess) {
             set_error("spmm_plan_create: %s", hipGetErrorString(e));
             geogcn_spmm_plan_destroy(plan);
@@ -694,6 +740,8 @@ void geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan) {
     if (plan->d_long_first) (void)hipFree(plan->d_long_first);
     if (plan->d_chunk_start) (void)hipFree(plan->d_chunk_start);
     if (plan->d_chunk_end) (void)hipFree(plan->d_chunk_end);
+    if (plan->d_sched[0]) (void)hipFree(plan->d_sched[0]);
+    if (plan->d_sched[1]) (void)hipFree(plan->d_sched[1]);
     delete plan;
 }
 
