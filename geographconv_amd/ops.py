@@ -377,9 +377,10 @@ def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None,
     return out0, out1
 
 
-def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False):
+def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, carry=None):
     """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
-    dH = dZ . Wh^T + dU . Wt^T of the highway block."""
+    dH = dZ . Wh^T + dU . Wt^T of the highway block.  carry=(G, T): + G (.) (1 - T), the block's carry gradient, formed in
+    the epilogue (geogcn_gemm_kcat_carry_f32) instead of being read from `out`."""
     N = B0.n if transB else B0.F
     if (B1.n if transB else B1.F) != N or A0.n != A1.n or (B0.F if transB else B0.n) != A0.F or (B1.F if transB else B1.n) != A1.F:
         raise ValueError("gemm_kcat: shapes do not match")
@@ -387,6 +388,14 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
         if accumulate:
             raise ValueError("gemm_kcat: accumulate needs an existing output")
         out = DMat.empty(A0.n, N, A0.device)
+    if carry is not None:
+        G, T = carry
+        if accumulate or G.n != A0.n or T.n != A0.n or G.F != N or T.F != N or G.ld != T.ld:
+            raise ValueError("gemm_kcat: carry=(G, T) needs accumulate=False and two M x N matrices of one pitch")
+        check(_ffi.lib().geogcn_gemm_kcat_carry_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t),
+                                                    A1.ld, _p(B1.t), B1.ld, _p(out.t), out.ld, _p(G.t), _p(T.t), G.ld, _stream()),
+              'gemm_kcat_carry_f32')
+        return out
     check(_ffi.lib().geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
                                           _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _stream()), 'gemm_kcat_f32')
     return out
@@ -407,16 +416,20 @@ def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
 
 
 def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None,
-                dbS: torch.Tensor = None, dbU: torch.Tensor = None):
-    """-> (dS, dU, dHcarry); with dbS / dbU given, also the two bias gradients (column sums) in the same pass."""
+                dbS: torch.Tensor = None, dbU: torch.Tensor = None, want_carry=True):
+    """-> (dS, dU, dHcarry); with dbS / dbU given, also the two bias gradients (column sums) in the same pass.
+    want_carry=False: dHcarry = G (1 - T) is not written (-> None): its consumer forms it (gemm_kcat(carry=(G, T)))."""
     lib = _ffi.lib()
     dS = DMat.empty(G.n, G.F, G.device, ld=gather_ld(G.F)) if dS is None else dS      # dS feeds the A^T SpMM
     dU = G.like() if dU is None else dU
-    dHcarry = G.like() if dHcarry is None else dHcarry
+    if want_carry:
+        dHcarry = G.like() if dHcarry is None else dHcarry
+    else:
+        dHcarry = None
     w = _ws_for(G.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(G.n, G.F),
                                   lib.geogcn_colsum_workspace_bytes(G.n, G.F)) if dbS is not None else 0)
     check(lib.geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
-                                     _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
+                                     _p(dHcarry.t) if dHcarry is not None else None, _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
     return dS, dU, dHcarry
 
 

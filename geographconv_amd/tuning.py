@@ -36,6 +36,9 @@ FUSE_GEMMS = True
 # epilogue's T / H loads cost more than the separate pass: 1.82 ms fused against 1.10 + 0.41), 'all', 'none'
 FUSE_HIGHWAY = 'f32'
 
+# highway block backward: the carry gradient G (1 - T) formed in the epilogue of the fused dH product
+# (geogcn_gemm_kcat_carry_f32) instead of written by the gating backward and read back (bitwise the same values)
+FUSE_CARRY = True
 # dropout after the sparse-input layer in the epilogue of X . W0 (geogcn_spmm_csr_hot_dropout_f32): one launch instead of
 # product + mask kernel + apply pass (-0.2 ms per TWUS step); same Philox bits, same arithmetic
 FUSE_DROPOUT = True

@@ -401,6 +401,17 @@ def test_gemm_kcat_two_products_one_accumulator(dev, M, N, K0, K1):
     dB0n, dB1n = ops.DMat.from_numpy(np.ascontiguousarray(B0.T), dev), ops.DMat.from_numpy(np.ascontiguousarray(B1.T), dev)
     got = ops.gemm_kcat(dA0, dB0n, dA1, dB1n)
     assert np.all(np.abs(got.numpy() - ref) <= tol)
+    # carry form (geogcn_gemm_kcat_carry_f32): + G (.) (1 - T) formed in the epilogue == accumulating onto the stored
+    # carry that geogcn_highway_bwd_f32 writes, bit for bit; and highway_bwd without the carry output
+    G, T = ops.DMat.from_numpy(_rand((M, N), 6), dev), ops.DMat.from_numpy(np.abs(_rand((M, N), 7)) % 1.0, dev)
+    Hc, H = ops.DMat.from_numpy(np.tanh(_rand((M, N), 8)), dev), ops.DMat.from_numpy(_rand((M, N), 9), dev)
+    dS, dU, carry = ops.highway_bwd(G, T, Hc, H)
+    dS2, dU2, none = ops.highway_bwd(G, T, Hc, H, want_carry=False)
+    assert none is None and torch.equal(dS.t, dS2.t) and torch.equal(dU.t, dU2.t)
+    assert np.array_equal(carry.numpy(), (G.numpy() * (np.float32(1.0) - T.numpy())).astype(np.float32))
+    want = ops.gemm_kcat(dA0, dB0, dA1, dB1, out=carry, transB=True, accumulate=True)
+    got = ops.gemm_kcat(dA0, dB0, dA1, dB1, transB=True, carry=(G, T))
+    assert torch.equal(got.t, want.t)
 
 
 def _bow(n_docs, n_words, mean, seed):
