@@ -269,14 +269,26 @@ def main():
                          'scheme is timed too and reported under `alt`')
     ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the `value` scheme')
     ap.add_argument('--no-check', action='store_true', help='N > 1: skip the partition_check block')
+    ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
+                    help='A/B aid: override an attribute of geographconv_amd/tuning.py for this run (e.g. --set FUSE_CARRY=0); '
+                         'recorded in config.tuning_overrides -- a line with overrides is not the headline configuration')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
 
     import torch
-    from geographconv_amd import ops, synth
+    from geographconv_amd import ops, synth, tuning
     from geographconv_amd.gcnmodel import GraphConv
+    overrides = {}
+    for kv in args.set:
+        name, _, val = kv.partition('=')
+        if not hasattr(tuning, name):
+            raise SystemExit("--set: geographconv_amd.tuning has no attribute %r" % name)
+        old = getattr(tuning, name)
+        new = (val not in ('0', 'false', 'False', '')) if isinstance(old, bool) else type(old)(val)
+        setattr(tuning, name, new)
+        overrides[name] = new
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -433,6 +445,7 @@ def main():
                        "world_size": world, "collectives": None if comm is None else ("%s, exchange = %s" % ("STAGED through the host + gloo (functional check, NOT a measurement)" if staged else "RCCL (torch.distributed nccl)", comm.exchange)),
                        "dist": dist_info,
                        "reorder": args.reorder,
+                       "tuning_overrides": overrides or None,
                        "dropout_stream": "Philox keyed by device row: with --reorder the dropped entries differ from the "
                                          "un-reordered run of the same seed (statistically equivalent, not bitwise)" if args.reorder else "Philox",
                        "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
