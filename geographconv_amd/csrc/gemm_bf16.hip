@@ -258,8 +258,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
         const unsigned char* As = smem_raw + (Cfg::kDouble ? cur : 0) * Cfg::kStageBytes;
         const unsigned char* Bs = As + Cfg::kABytes;
         // ---- MFMAs on the resident stage ----
-        // fragments are re-read from LDS per (column tile, row tile) pair: 24 live fragment registers instead
-        // of 60+ -- the register file is needed for the two-stage prefetch, LDS bandwidth is not the limit
+        // the A fragments of the stage are read ONCE and kept (MR x NS x 4 VGPRs), the B fragment of a column tile is read
+        // once per column tile: MR + NR ds_read_b128 per stage and plane instead of NR x (1 + MR).  (Until round 3 the A
+        // fragments were re-read for every column tile to save registers: at one 16x16x32 bf16 MFMA = 16 cycles the 25
+        // reads per 20 MFMAs of the 128 x 160 tile made the LDS port, not the matrix pipe, the busiest unit.)
+        bf16x8 af[Cfg::MR][NS];
+#pragma unroll
+        for (int i = 0; i < ((PROBE & 4) ? 0 : Cfg::MR); ++i)
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + wm * kWaveRows + i * 16 + li) * ROWB + lg * 16);
 #pragma unroll
         for (int j = 0; j < ((PROBE & 4) ? 0 : Cfg::NR); ++j) {
             bf16x8 bf[NS];
@@ -268,21 +276,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const Bf16Args a) {
                 bf[pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + wn * (BN / 2) + j * 16 + li) * ROWB + lg * 16);
 #pragma unroll
             for (int i = 0; i < Cfg::MR; ++i) {
-                bf16x8 af[NS];
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl)
-                    af[pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + wm * kWaveRows + i * 16 + li) * ROWB + lg * 16);
                 f32x4 c = acc[i][j];
                 // operands swapped (B fragment first): the 16x16 product comes out transposed, so a lane owns 4
                 // CONSECUTIVE COLUMNS of one row of C and the epilogue stores 16 (fp32) / 8 (bf16) bytes at once
                 if constexpr (NS == 3) {        // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2], af[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2], af[i][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[i][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[i][0], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
         }
