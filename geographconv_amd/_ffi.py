@@ -22,7 +22,7 @@ COMM_ID_BYTES = 128        # GEOGCN_COMM_ID_BYTES
 SIGNATURES = {
     'geogcn_version': (c_i32, []),
     'geogcn_last_error': (C.c_char_p, []),
-    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_i32, c_i32, C.POINTER(c_ptr)]),
+    'geogcn_spmm_plan_create': (c_i32, [c_i32, c_ptr, c_i32, c_i32, c_i32, C.POINTER(c_ptr)]),
     'geogcn_spmm_plan_destroy': (None, [c_ptr]),
     'geogcn_spmm_plan_num_long_rows': (c_i64, [c_ptr]),
     'geogcn_spmm_plan_num_chunks': (c_i64, [c_ptr]),
@@ -61,8 +61,6 @@ SIGNATURES = {
                                      c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_kcat_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                      c_ptr, c_i64, c_i32, c_ptr]),
-    'geogcn_gemm_kcat_carry_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
-                                           c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t n, int ld4, co
         }
         dS[es] = s;
         dU[e] = u;
-        if (dHc) dHc[e] = c;
+        dHc[e] = c;
     }
 }
 
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int 
 #undef GEOGCN_HW
             dS[row * ld4_dS + q] = s;
             dU[e] = u;
-            if (dHc) dHc[e] = c;          // (nullable: the carry G (1-T) can ride in the epilogue of the GEMM that consumes it)
+            dHc[e] = c;
         }
     }
     red[0][threadIdx.x] = aS;
@@ -519,8 +519,7 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
         if (dbU) { const int rc = zero_fill_async(dbU, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream); if (rc) return rc; }
         return 0;
     }
-    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU);
-    GEOGCN_REQUIRE(aligned16(dHcarry), GEOGCN_E_ALIGN, "highway_bwd_f32: misaligned dHcarry");
+    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU, dHcarry);
     GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= ld, GEOGCN_E_ALIGN, "highway_bwd_f32: ld_dS=%lld must be a multiple of 4, >= ld",
                    (long long)ld_dS);
     GEOGCN_REQUIRE((dbS == nullptr) == (dbU == nullptr), GEOGCN_E_ARG, "highway_bwd_f32: pass both bias gradients or neither");

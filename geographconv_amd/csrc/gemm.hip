@@ -182,12 +182,6 @@ struct GemmArgs {
     // repartition all-to-all, written straight from the accumulators.  0 = row-major.
     int panel_w;
     int64_t panel_R;
-    // MODE 0, nullable: C += carry_g (.) (1 - carry_t), element-wise, both M x N[0] with pitch ld_carry -- the highway
-    // block's carry gradient G (1 - T) (gcnmodel.py:266 differentiated) formed in this epilogue instead of being written by
-    // the gating backward and read back by an accumulating GEMM.  Not together with `accumulate`.
-    const float* carry_g;
-    const float* carry_t;
-    int64_t ld_carry;
 };
 
 // Tile coordinates are wave-uniform (functions of blockIdx and loop counters); readfirstlane keeps them in
@@ -416,20 +410,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
                             oldv[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (row_ok && col0 < Nseg) oldv[jn] = *reinterpret_cast<const float4*>(crow + col0);
                         }
-                    } else if (a.carry_g) {
-                        // the same value the gating backward used to store: fl(g * fl(1 - t)), one rounding each (no fma
-                        // contraction into the add below), so the fused and the unfused step agree bit for bit
-#pragma unroll
-                        for (int jn = 0; jn < Cfg::NR; ++jn) {
-                            const int64_t col0 = n0 + wn * Cfg::kWaveN + jn * 16 + lg * 4;
-                            oldv[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (row_ok && col0 < Nseg) {
-                                const float4 g = *reinterpret_cast<const float4*>(a.carry_g + row * a.ld_carry + col0);
-                                const float4 t = *reinterpret_cast<const float4*>(a.carry_t + row * a.ld_carry + col0);
-                                oldv[jn] = make_float4(__fmul_rn(g.x, 1.0f - t.x), __fmul_rn(g.y, 1.0f - t.y),
-                                                       __fmul_rn(g.z, 1.0f - t.z), __fmul_rn(g.w, 1.0f - t.w));
-                            }
-                        }
                     }
                 }
 #pragma unroll
@@ -445,7 +425,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
                         }
                     }
                     if constexpr (MODE == 0) {
-                        if (a.accumulate || a.carry_g) { x[0] += oldv[jn].x; x[1] += oldv[jn].y; x[2] += oldv[jn].z; x[3] += oldv[jn].w; }
+                        if (a.accumulate) { x[0] += oldv[jn].x; x[1] += oldv[jn].y; x[2] += oldv[jn].z; x[3] += oldv[jn].w; }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -531,9 +511,6 @@ struct GemmCall {
     int accumulate;
     int panel_w = 0;
     int64_t panel_R = 0;
-    const float* carry_g = nullptr;
-    const float* carry_t = nullptr;
-    int64_t ld_carry = 0;
     int64_t maxN() const { return n_nseg == 2 ? std::max(N[0], N[1]) : N[0]; }
 };
 
@@ -572,9 +549,6 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     a.accumulate = c.accumulate;
     a.panel_w = c.panel_w;
     a.panel_R = c.panel_R;
-    a.carry_g = c.carry_g;
-    a.carry_t = c.carry_t;
-    a.ld_carry = c.ld_carry;
     a.kchunk = sp.kchunk;
     a.n_mt = (int)cdiv(c.M, BM);
     a.n_nt = n_nt;
@@ -617,7 +591,6 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     a.slab_seg_w = seg_w;
     a.bias[0] = a.bias[1] = nullptr;
     a.accumulate = 0;
-    a.carry_g = a.carry_t = nullptr;
     GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1);
     for (int q = 0; q < c.n_nseg; ++q) {
         const int rc = splitk_reduce_launch(c.M, c.N[q], sp.nsplit, W + q * seg_w, ldw, c.C[q], c.ldc[q], c.bias[q],
@@ -867,10 +840,10 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
 }
 
 // C = A0.op(B0) + A1.op(B1) [+ C]: one accumulator over both reductions, exact fp32
-static int gemm_kcat_entry(const char* fn, int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0,
-                           int64_t lda0, const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1,
-                           int64_t ldb1, float* C, int64_t ldc, int32_t accumulate, const float* carry_g, const float* carry_t,
-                           int64_t ld_carry, void* stream) {
+int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                         const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                         float* C, int64_t ldc, int32_t accumulate, void* stream) {
+    const char* fn = "gemm_kcat_f32";
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C, GEOGCN_E_NULL, "%s: null pointer", fn);
@@ -885,29 +858,7 @@ static int gemm_kcat_entry(const char* fn, int32_t transB, int64_t M, int64_t N,
     c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
     c.C[0] = C; c.ldc[0] = ldc;
     c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate;
-    if (carry_g) {
-        GEOGCN_REQUIRE(carry_t && !accumulate, GEOGCN_E_ARG, "%s: the carry form needs both G and T and accumulate = 0", fn);
-        GEOGCN_REQUIRE(ld_ok(carry_g, ld_carry) && ld_ok(carry_t, ld_carry) && ld_carry >= ((N + 3) & ~(int64_t)3), GEOGCN_E_ALIGN,
-                       "%s: carry operands need 16-byte aligned bases and a pitch %% 4 == 0, >= roundup4(N)", fn);
-        c.carry_g = carry_g; c.carry_t = carry_t; c.ld_carry = ld_carry;
-    }
     return run_call(false, transB != 0, c, nullptr, 0, (hipStream_t)stream);
-}
-
-int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
-                         const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                         float* C, int64_t ldc, int32_t accumulate, void* stream) {
-    return gemm_kcat_entry("gemm_kcat_f32", transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, accumulate,
-                           nullptr, nullptr, 0, stream);
-}
-
-// C = A0.op(B0) + A1.op(B1) + G (.) (1 - T): the highway block's dH with the carry gradient formed in the epilogue
-int geogcn_gemm_kcat_carry_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
-                               const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                               float* C, int64_t ldc, const float* G, const float* T, int64_t ld_gt, void* stream) {
-    const char* fn = "gemm_kcat_carry_f32";
-    GEOGCN_REQUIRE(M == 0 || N == 0 || (G && T), GEOGCN_E_NULL, "%s: null G / T", fn);
-    return gemm_kcat_entry(fn, transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, 0, G, T, ld_gt, stream);
 }
 
 }  // extern "C"

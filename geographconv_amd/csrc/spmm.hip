@@ -208,7 +208,6 @@ __device__ __forceinline__ float4 highway_mix(const float4 t, const float4 hc, c
 
 struct XcdRows {
     int lo[kNumXCD + 1];         // XCD x owns rows [lo[x], lo[x + 1])
-    int cbase[kNumXCD + 1];      // ... and the long-row chunks [cbase[x], cbase[x + 1]) (chunks are numbered by row)
 };
 constexpr int kIdleSlot = INT32_MIN;
 
@@ -222,12 +221,13 @@ constexpr int kIdleSlot = INT32_MIN;
 // XCDs, outside the window: 13 % of the entries of the TwitterUS-shape graphs).  The ranges hold equal numbers of stored
 // entries, not of rows (a hub-first numbering would otherwise give one XCD all the work).
 // `sched` (host-built per plan, nullable when there are no long rows): entry >= 0 = row block v of the XCD's range,
-// < 0 = chunk block -1 - v of its chunk range, kIdleSlot = nothing.  per_xcd = 0 and no schedule: plain b -> row block map.
+// < 0 = chunk block -1 - v (chunks [c * rows-per-block, ...) in row order), kIdleSlot = nothing.  Which XCD walks which chunk
+// block, and when, is the host's choice (geogcn_spmm_plan_create).  per_xcd = 0 and no schedule: plain b -> row block map.
 template <int K4, int ACT, int G, int BF, int HW = 0>
 __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     int n_rows, const int* __restrict__ rowptr, const int* __restrict__ colidx,
     const float* __restrict__ val, const void* __restrict__ B, int64_t ldb, float* __restrict__ C,
-    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, const int* __restrict__ sched,
+    int64_t ldc, int F, const float* __restrict__ bias, int long_row_nnz, const int* __restrict__ sched, int n_chunks,
     const int* __restrict__ chunk_start, const int* __restrict__ chunk_end, float* __restrict__ P, int64_t ldp,
     const HwArgs hw, const int per_xcd, const XcdRows xr) {
     constexpr int kGpb = kRowBlock / G;       // groups (= rows, = chunks) per block
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
         if (v == kIdleSlot) return;
     }
     if (v < 0) {
-        const int ch = xr.cbase[x] + (-1 - v) * kGpb + (threadIdx.x / G);
-        if (ch >= xr.cbase[x + 1]) return;
+        const int ch = (-1 - v) * kGpb + (threadIdx.x / G);
+        if (ch >= n_chunks) return;
         const int cs = chunk_start[ch], ce = chunk_end[ch];
         group_accumulate<K4, G, BF>(cs, ce, lane16, nF4, colidx, val, B, ldb, acc);
         float4* out = reinterpret_cast<float4*>(P + (int64_t)ch * ldp);
@@ -380,7 +380,6 @@ struct geogcn_spmm_plan {
     int* d_chunk_start = nullptr;  // [n_chunks]
     int* d_chunk_end = nullptr;    // [n_chunks]
     int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per-XCD row ranges (multiples of 64 = kRowAlign), equal stored entries
-    int xcd_cbase[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-XCD chunk ranges (chunks are numbered in row order)
     int* d_sched[2] = {nullptr, nullptr};             // per-XCD block schedules for 16- / 8-lane groups (only with long rows)
     int sched_slots[2] = {0, 0};                      // blocks per XCD in each
     // profiling aid (geogcn_spmm_plan_attach_timer): the caller's event pool, sampled by the products that run on THIS plan
@@ -410,10 +409,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     int per_xcd = 0;
     const int* sched = nullptr;
     if (xcd_rows && plan) {
-        for (int x = 0; x <= kNumXCD; ++x) {
-            xr.lo[x] = plan->xcd_lo[x];
-            xr.cbase[x] = plan->xcd_cbase[x];
-        }
+        for (int x = 0; x <= kNumXCD; ++x) xr.lo[x] = plan->xcd_lo[x];
         for (int x = 0; x < kNumXCD; ++x) per_xcd = std::max(per_xcd, (int)cdiv(xr.lo[x + 1] - xr.lo[x], kGroupsPerBlock));
         if (n_chunks > 0) {       // row blocks and chunk blocks interleaved per XCD (host-built at plan creation)
             sched = plan->d_sched[G == 8 ? 1 : 0];
@@ -432,7 +428,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
 #define GEOGCN_ROWS(ACT) GEOGCN_ROWS__(ACT, 0)
 #define GEOGCN_ROWS__(ACT, HW_)                                                                  \
     hipLaunchKernelGGL((spmm_rows_kernel<K4, ACT, G, BF, HW_>), grid, dim3(kRowBlock), 0, st, n_rows, rowptr,   \
-                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz, sched,                    \
+                       colidx, val, B, ldb, C, ldc, F, bias, long_nnz, sched, n_chunks,          \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, hw, per_xcd, xr)
     if (n_rows > 0) {
         if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 1); }        // highway epilogue: tanh branch only (checked by the caller)
@@ -634,7 +630,7 @@ int geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32_
 }
 
 int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz, int32_t chunk_nnz,
-                            geogcn_spmm_plan** out) {
+                            int32_t chunks_with_owner, geogcn_spmm_plan** out) {
     GEOGCN_REQUIRE(rowptr_host && out, GEOGCN_E_NULL, "spmm_plan_create: null pointer");
     GEOGCN_REQUIRE(n_rows >= 0 && long_row_nnz > 0 && chunk_nnz > 0, GEOGCN_E_SIZE,
                    "spmm_plan_create: bad sizes n_rows=%d long=%d chunk=%d", n_rows, long_row_nnz,
@@ -657,9 +653,12 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t 
     auto* plan = new geogcn_spmm_plan();
     {
         // row ranges of the 8 XCDs: cut where the running count of stored entries + a per-row term crosses k/8 of the
-        // total, rounded to 64 rows (= whole row blocks for 8- and 16-lane groups).  Long rows count in full: their chunks
-        // run on the XCD that owns the row.
-        auto cost = [&](int r) -> int64_t { return (int64_t)(rowptr_host[r + 1] - rowptr_host[r]) + 4; };
+        // total, rounded to 64 rows (= whole row blocks for 8- and 16-lane groups).  Long rows count in full when their
+        // chunks run on the XCD that owns the row, not at all when the chunks are dealt round the XCDs.
+        auto cost = [&](int r) -> int64_t {
+            const int64_t nz = rowptr_host[r + 1] - rowptr_host[r];
+            return ((nz > long_row_nnz && !chunks_with_owner) ? 0 : nz) + 4;
+        };
         int64_t total = 0;
         for (int r = 0; r < n_rows; ++r) total += cost(r);
         int64_t run = 0;
@@ -675,29 +674,38 @@ int geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t 
         plan->xcd_lo[8] = n_rows;
         for (int k = 1; k <= 8; ++k) plan->xcd_lo[k] = std::max(plan->xcd_lo[k], plan->xcd_lo[k - 1]);
     }
-    // chunk ranges of the XCDs (chunks were numbered in row order above) and, per group width, the XCDs' block schedules:
-    // the row blocks of the range in order, each chunk block slotted in just before the row block its first long row is in
+    // Per group width, the XCDs' block schedules.  Chunks were numbered in row order above; chunk block c = chunks
+    // [c * gpb, (c + 1) * gpb).
+    //   chunks_with_owner = 1 (a numbering with locality): a chunk block runs on the XCD that owns the row of its first chunk,
+    //     slotted in just before the row block that row is in -- the hub's neighbours are then in the same L2 window as the
+    //     rows around it (community graph + label-propagation order: 1.084 -> 1.018 ms);
+    //   chunks_with_owner = 0 (no locality to keep): chunk block c goes to XCD c % 8 and leads that XCD's schedule, so the
+    //     latency-bound 128-entry walks start first and are spread over the chip.  On the pinned power-law graph the hubs are
+    //     the lowest-numbered rows: with the owner rule ONE XCD would walk nearly all chunks while the other seven share the
+    //     short rows (measured: the highway-fused forward product 2.12 -> 2.34 ms).
     std::vector<int> sched[2];
     if (!cs.empty()) {
         std::vector<int> chunk_row(cs.size());
         for (size_t lr = 0; lr < long_rows.size(); ++lr)
             for (int c = long_first[lr]; c < long_first[lr + 1]; ++c) chunk_row[c] = long_rows[lr];
-        for (int x = 0; x <= kNumXCD; ++x)
-            plan->xcd_cbase[x] = (int)(std::lower_bound(chunk_row.begin(), chunk_row.end(), plan->xcd_lo[x]) - chunk_row.begin());
-        plan->xcd_cbase[kNumXCD] = (int)cs.size();
         for (int w = 0; w < 2; ++w) {
             const int gpb = kRowBlock / (w ? 8 : 16);
+            const int n_cb = (int)cdiv((int64_t)cs.size(), gpb);
             std::vector<std::vector<int>> lists(kNumXCD);
+            if (!chunks_with_owner)
+                for (int c = 0; c < n_cb; ++c) lists[c % kNumXCD].push_back(-1 - c);
             size_t slots = 0;
+            int c = 0;
             for (int x = 0; x < kNumXCD; ++x) {
                 const int lo = plan->xcd_lo[x], hi = plan->xcd_lo[x + 1];
-                const int rb = (int)cdiv(hi - lo, gpb), cb = (int)cdiv(plan->xcd_cbase[x + 1] - plan->xcd_cbase[x], gpb);
-                int c = 0;
+                const int rb = (int)cdiv(hi - lo, gpb);
                 for (int j = 0; j < rb; ++j) {
-                    while (c < cb && (chunk_row[plan->xcd_cbase[x] + (size_t)c * gpb] - lo) / gpb <= j) lists[x].push_back(-1 - c++);
+                    if (chunks_with_owner)
+                        while (c < n_cb && chunk_row[(size_t)c * gpb] < lo + (j + 1) * gpb) lists[x].push_back(-1 - c++);
                     lists[x].push_back(j);
                 }
-                while (c < cb) lists[x].push_back(-1 - c++);
+                if (chunks_with_owner && x == kNumXCD - 1)
+                    while (c < n_cb) lists[x].push_back(-1 - c++);
                 slots = std::max(slots, lists[x].size());
             }
             plan->sched_slots[w] = (int)slots;

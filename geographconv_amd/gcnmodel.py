@@ -277,16 +277,9 @@ class MultiplicativeGatingLayer(L.MergeLayer):
         # one pass: gradients w.r.t. both PRE-activations and the carry
         # ... and the two bias gradients (column sums of dS / dU) while the data is in registers
         fuse_b = gate_l.b is not None and h1_l.b is not None
-        # the carry gradient G (1 - T) is left to the block's fused dH product when that is what comes next (the forward ran
-        # the dual launch, so the backward runs dual TN + K-concatenated NT on the gate layer): not written, not read back
-        lazy = (tuning.FUSE_CARRY and into[2] is None and tape.get(gate_l, {}).get('fused_with') is h1_l
-                and gate_l.input_layer is self.input_layers[2] and grad.ld == t.ld
-                and isinstance(self.input_layers[2], L.Layer) and not isinstance(self.input_layers[2], L.InputLayer))
         dS, dU, dH = K.highway_bwd(grad, t, h1, h2, dbS=h1_l.b.grad if fuse_b else None,
-                                   dbU=gate_l.b.grad if fuse_b else None, want_carry=not lazy)
-        if lazy:
-            dH = L.HighwayCarry(grad, t)
-        elif into[2] is not None:
+                                   dbU=gate_l.b.grad if fuse_b else None)
+        if into[2] is not None:
             K.add_inplace(dH, into[2])
             dH = into[2]
         return [L.PreAct(dU, bias_done=fuse_b), L.PreAct(dS, bias_done=fuse_b), dH]

@@ -121,15 +121,6 @@ class PreAct:
         self.bias_done = bias_done        # the producer already wrote this layer's bias gradient
 
 
-class HighwayCarry:
-    """Gradient token: the true gradient is G (.) (1 - T) -- the highway block's carry gradient (gcnmodel.py:266) -- not yet
-    formed.  Produced by the gating layer's backward only when the block's fused dH product will consume it (the gate's
-    DenseLayer._backward_post, geogcn_gemm_kcat_carry_f32): one N x F write and one read less per block."""
-
-    def __init__(self, G, T):
-        self.G, self.T = G, T
-
-
 class Masked:
     """Gradient token: the true gradient is m * keep_mask * scale (a dropout layer's backward that has not been
     applied yet) -- a DenseLayer below fuses it into its activation-gradient kernel (geogcn_act_bwd_f32 takes the
@@ -239,8 +230,6 @@ def _fuse_gemms():
 
 
 def _accumulate(dst, src):
-    if isinstance(dst, HighwayCarry) or isinstance(src, HighwayCarry):
-        raise NotImplementedError("a highway carry gradient can only be consumed by its block's fused dH product")
     backend.active().add_inplace(src, dst)
     return dst
 
@@ -506,8 +495,6 @@ class DenseLayer(Layer):
                 if not need_input_grad:
                     return [None]
                 # dH = dZ.Wh^T + dU.Wt^T [+ the carry gradient]: one accumulator, one pass over dH
-                if isinstance(into[0], HighwayCarry):
-                    return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, transB=True, carry=(into[0].G, into[0].T))]
                 return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
                                     accumulate=into[0] is not None)]
             K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ

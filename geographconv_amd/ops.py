@@ -217,9 +217,11 @@ class CSR:
     """Device CSR (int32 indices, fp32 values, rows in ascending column order) + the long-row split plan for the SpMM
     kernel."""
 
-    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None, sort=True):
+    def __init__(self, m: sps.spmatrix, device, long_row_nnz=None, chunk_nnz=None, sort=True, local=None):
         """`sort=False` keeps the given stored order inside each row (the SpMM accumulates in stored order and does not
-        need it ascending; geogcn_xt_plan_create does and checks)."""
+        need it ascending; geogcn_xt_plan_create does and checks).  `local`: whether the row numbering has locality (a long
+        row's neighbours lie near it) -- decides on which XCD the long rows' chunks run (geogcn_spmm_plan_create); None =
+        measured here: at least half of the long rows' entries within tuning.L2_WINDOW_ROWS of their row."""
         require_gpu()
         m = sps.csr_matrix(m)
         if long_row_nnz is None:
@@ -247,8 +249,17 @@ class CSR:
         self.device = device
         self._plan = C.c_void_p(0)
         lib = _ffi.lib()
+        if local is None:
+            local = False
+            deg = np.diff(indptr)
+            long_rows = np.nonzero(deg > long_row_nnz)[0]
+            if len(long_rows) and m.shape[0] == m.shape[1]:
+                sel = np.concatenate([np.arange(indptr[r], indptr[r + 1]) for r in long_rows[:4096]])
+                row_of = np.repeat(long_rows[:4096], deg[long_rows[:4096]])
+                local = bool(np.mean(np.abs(indices[sel].astype(np.int64) - row_of) <= tuning.L2_WINDOW_ROWS) >= 0.5)
+        self.chunks_with_owner = bool(local)
         check(lib.geogcn_spmm_plan_create(self.shape[0], indptr.ctypes.data_as(C.c_void_p),
-                                          int(long_row_nnz), int(chunk_nnz), C.byref(self._plan)),
+                                          int(long_row_nnz), int(chunk_nnz), int(self.chunks_with_owner), C.byref(self._plan)),
               'spmm_plan_create')
         self.n_long_rows = int(lib.geogcn_spmm_plan_num_long_rows(self._plan))
         self.n_chunks = int(lib.geogcn_spmm_plan_num_chunks(self._plan))
@@ -377,10 +388,9 @@ def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None,
     return out0, out1
 
 
-def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, carry=None):
+def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False):
     """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
-    dH = dZ . Wh^T + dU . Wt^T of the highway block.  carry=(G, T): + G (.) (1 - T), the block's carry gradient, formed in
-    the epilogue (geogcn_gemm_kcat_carry_f32) instead of being read from `out`."""
+    dH = dZ . Wh^T + dU . Wt^T of the highway block."""
     N = B0.n if transB else B0.F
     if (B1.n if transB else B1.F) != N or A0.n != A1.n or (B0.F if transB else B0.n) != A0.F or (B1.F if transB else B1.n) != A1.F:
         raise ValueError("gemm_kcat: shapes do not match")
@@ -388,14 +398,6 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
         if accumulate:
             raise ValueError("gemm_kcat: accumulate needs an existing output")
         out = DMat.empty(A0.n, N, A0.device)
-    if carry is not None:
-        G, T = carry
-        if accumulate or G.n != A0.n or T.n != A0.n or G.F != N or T.F != N or G.ld != T.ld:
-            raise ValueError("gemm_kcat: carry=(G, T) needs accumulate=False and two M x N matrices of one pitch")
-        check(_ffi.lib().geogcn_gemm_kcat_carry_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t),
-                                                    A1.ld, _p(B1.t), B1.ld, _p(out.t), out.ld, _p(G.t), _p(T.t), G.ld, _stream()),
-              'gemm_kcat_carry_f32')
-        return out
     check(_ffi.lib().geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
                                           _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _stream()), 'gemm_kcat_f32')
     return out
@@ -416,20 +418,16 @@ def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
 
 
 def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None,
-                dbS: torch.Tensor = None, dbU: torch.Tensor = None, want_carry=True):
-    """-> (dS, dU, dHcarry); with dbS / dbU given, also the two bias gradients (column sums) in the same pass.
-    want_carry=False: dHcarry = G (1 - T) is not written (-> None): its consumer forms it (gemm_kcat(carry=(G, T)))."""
+                dbS: torch.Tensor = None, dbU: torch.Tensor = None):
+    """-> (dS, dU, dHcarry); with dbS / dbU given, also the two bias gradients (column sums) in the same pass."""
     lib = _ffi.lib()
     dS = DMat.empty(G.n, G.F, G.device, ld=gather_ld(G.F)) if dS is None else dS      # dS feeds the A^T SpMM
     dU = G.like() if dU is None else dU
-    if want_carry:
-        dHcarry = G.like() if dHcarry is None else dHcarry
-    else:
-        dHcarry = None
+    dHcarry = G.like() if dHcarry is None else dHcarry
     w = _ws_for(G.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(G.n, G.F),
                                   lib.geogcn_colsum_workspace_bytes(G.n, G.F)) if dbS is not None else 0)
     check(lib.geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
-                                     _p(dHcarry.t) if dHcarry is not None else None, _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
+                                     _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
     return dS, dU, dHcarry
 
 

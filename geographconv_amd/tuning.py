@@ -36,9 +36,6 @@ FUSE_GEMMS = True
 # epilogue's T / H loads cost more than the separate pass: 1.82 ms fused against 1.10 + 0.41), 'all', 'none'
 FUSE_HIGHWAY = 'f32'
 
-# highway block backward: the carry gradient G (1 - T) formed in the epilogue of the fused dH product
-# (geogcn_gemm_kcat_carry_f32) instead of written by the gating backward and read back (bitwise the same values)
-FUSE_CARRY = True
 # dropout after the sparse-input layer in the epilogue of X . W0 (geogcn_spmm_csr_hot_dropout_f32): one launch instead of
 # product + mask kernel + apply pass (-0.2 ms per TWUS step); same Philox bits, same arithmetic
 FUSE_DROPOUT = True
@@ -56,6 +53,11 @@ XT_MIN_NNZ = 1_000_000
 XT_MAX_F = 320
 # X . W0 with the hot rows of W0 in LDS (geogcn_spmm_csr_hot_f32) from this many stored entries on
 HOT_MIN_NNZ = 2_000_000
+
+# rows of a 300-wide fp32 operand one XCD's 4 MB L2 holds (1.2 KB each): the window inside which a gather is an L2 hit.
+# ops.CSR calls a numbering "local" -- and runs a long row's chunks on the XCD that owns the row -- when at least half of
+# the long rows' entries lie within this distance of their row
+L2_WINDOW_ROWS = 3300
 
 # ---- partitioned path ----------------------------------------------------------------------------------------------
 # all-gather scheme: cost of one row in stored-edge equivalents when the row split is balanced (dense work of a row

@@ -54,8 +54,11 @@ const char* geogcn_last_error(void);
  * bias may be NULL.  plan may be NULL (no row splitting: correct, slow on hub rows).          */
 typedef struct geogcn_spmm_plan geogcn_spmm_plan;
 
+/* chunks_with_owner: where the chunks of the long rows run (speed only, never a value).  1 = on the XCD that owns the
+ * long row, at the row's place in that XCD's sweep -- for node numberings with locality, where a hub's neighbours share
+ * its L2 window; 0 = dealt round the XCDs, ahead of the row blocks -- for numberings without (e.g. hubs first).      */
 int    geogcn_spmm_plan_create(int32_t n_rows, const int32_t* rowptr_host, int32_t long_row_nnz, int32_t chunk_nnz,
-                               geogcn_spmm_plan** out);
+                               int32_t chunks_with_owner, geogcn_spmm_plan** out);
 void   geogcn_spmm_plan_destroy(geogcn_spmm_plan* plan);
 int64_t geogcn_spmm_plan_num_long_rows(const geogcn_spmm_plan* plan);
 int64_t geogcn_spmm_plan_num_chunks(const geogcn_spmm_plan* plan);
@@ -227,13 +230,6 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
 int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                          float* C, int64_t ldc, int32_t accumulate, void* stream);
-/* The same with the highway block's CARRY gradient formed in the epilogue:  C = A0 . op(B0) + A1 . op(B1) + G (.) (1 - T)
- * (gcnmodel.py:266 differentiated w.r.t. its h2 input; G = gradient at the block's output, T = the gate; both M x N with
- * pitch ld_gt).  Replaces geogcn_highway_bwd_f32 writing dHcarry + an accumulating geogcn_gemm_kcat_f32 reading it back:
- * the same values bit for bit (the product is rounded before it is added), one N x F write and one read less.     */
-int geogcn_gemm_kcat_carry_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
-                               const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                               float* C, int64_t ldc, const float* G, const float* T, int64_t ld_gt, void* stream);
 
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */
@@ -247,7 +243,6 @@ int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
                            const float* H, int64_t ld, float* dS, int64_t ld_dS /* dS may use the line-aligned
                            pitch of an SpMM operand */, float* dU, float* dHcarry,
-                           /* dHcarry nullable: the consumer may form it itself (geogcn_gemm_kcat_carry_f32) */
                            float* dbS /* nullable: column sums of dS = grad of the conv bias */,
                            float* dbU /* nullable: column sums of dU = grad of the gate bias */,
                            void* ws, size_t ws_bytes, void* stream);

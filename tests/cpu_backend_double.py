@@ -109,10 +109,7 @@ def gemm_dual(A, B0, B1, out0=None, out1=None, transA=False, bias0=None, act0=AC
             gemm(A, B1, out=out1, transA=transA, bias=bias1, act=act1))
 
 
-def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, carry=None):
-    if carry is not None:
-        out = DMat.from_numpy(_v(carry[0]) * (1 - _v(carry[1])), A0.device)
-        accumulate = True
+def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False):
     out = gemm(A0, B0, out=out, transB=transB, accumulate=accumulate)
     return gemm(A1, B1, out=out, transB=transB, accumulate=True)
 
@@ -141,15 +138,13 @@ def highway_fwd(T, Hc, H, out=None):
     return out
 
 
-def highway_bwd(G, T, Hc, H, dS=None, dU=None, dHcarry=None, dbS=None, dbU=None, want_carry=True):
+def highway_bwd(G, T, Hc, H, dS=None, dU=None, dHcarry=None, dbS=None, dbU=None):
     mk = lambda: DMat(G.n, G.F, G.device)
-    dS, dU = dS or mk(), dU or mk()
-    dHcarry = (dHcarry or mk()) if want_carry else None
+    dS, dU, dHcarry = dS or mk(), dU or mk(), dHcarry or mk()
     g, t, hc, h = _v(G), _v(T), _v(Hc), _v(H)
     _v(dS)[...] = g * t * (1 - hc * hc)
     _v(dU)[...] = g * (hc - h) * t * (1 - t)
-    if want_carry:
-        _v(dHcarry)[...] = g * (1 - t)
+    _v(dHcarry)[...] = g * (1 - t)
     if dbS is not None:
         dbS.numpy()[:G.F] = _v(dS).sum(axis=0)
         dbU.numpy()[:G.F] = _v(dU).sum(axis=0)

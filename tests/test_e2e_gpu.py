@@ -102,28 +102,6 @@ def test_fused_highway_gemms_match_the_separate_launches(cmu, monkeypatch):
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max() + 1e-12, (i, np.abs(a - b).max(), np.abs(b).max())
 
 
-def test_carry_gradient_in_the_dh_epilogue_is_bitwise_the_unfused_step(cmu, monkeypatch):
-    """tuning.FUSE_CARRY: the highway block's carry gradient G (1 - T) (gcnmodel.py:266 differentiated) formed in the epilogue
-    of the K-concatenated dH product (geogcn_gemm_kcat_carry_f32) instead of written by geogcn_highway_bwd_f32 and read back by
-    an accumulating product: the same value is added in the same place, so losses, probabilities, every gradient and the
-    updated parameters are bitwise equal."""
-    from geographconv_amd import tuning
-    from geographconv_amd.nn import layers as L
-    c = cmu
-    outs = {}
-    for fused in (True, False):
-        monkeypatch.setattr(tuning, 'FUSE_CARRY', fused)
-        clf = _clf(c)
-        clf.inject_dropout_mask(c['mask'])
-        for _ in range(2):
-            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
-        outs[fused] = ([float(v) for v in out[:4]], np.asarray(out[4]).copy(), clf.get_grads(), L.get_all_param_values(clf.l_out))
-    assert outs[True][0] == outs[False][0] and np.array_equal(outs[True][1], outs[False][1])
-    for k in (2, 3):
-        for i, (a, b) in enumerate(zip(outs[True][k], outs[False][k])):
-            assert np.array_equal(a, b), (k, i)
-
-
 @pytest.mark.parametrize("method", ['rcm', 'lpa', 'degree'])
 def test_node_reordering_is_invisible_to_the_caller(cmu, method):
     """GraphConv(reorder=...): the graph, X, the index vectors and the injected mask are renumbered on the way to the

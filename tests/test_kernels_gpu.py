@@ -148,6 +148,31 @@ def test_spmm_short_rows_bitwise_reproducible_and_sequential(dev):
     assert np.allclose(o1, ref, rtol=1e-5, atol=1e-6)
 
 
+def test_spmm_long_row_chunks_on_the_owning_xcd_or_dealt_round(dev):
+    """geogcn_spmm_plan_create(chunks_with_owner): where the long rows' chunks run is a scheduling decision -- both
+    placements give bitwise the same product (plain, with the highway epilogue, bf16 operand, narrow 8-lane variant), for
+    hubs at the front of the numbering and for hubs spread over it; ops.CSR picks by measuring the long rows' locality."""
+    from geographconv_amd import ops
+    A = synth.powerlaw_ahat(30000, 400000)                    # hubs = lowest row ids
+    perm = np.random.RandomState(0).permutation(30000)
+    for M in (A, sps.csr_matrix(A[perm][:, perm])):
+        own, deal = ops.CSR(M, dev, local=True), ops.CSR(M, dev, local=False)
+        assert own.n_chunks == deal.n_chunks > 0 and own.chunks_with_owner and not deal.chunks_with_owner
+        for F in (300, 24):
+            B = ops.DMat.from_numpy(_rand((30000, F), F), dev)
+            b = torch.from_numpy(np.pad(_rand((F,), 2), (0, ops.pad4(F) - F))).to(dev)
+            assert torch.equal(ops.spmm(own, B, bias=b, act=ops.ACT_TANH).t, ops.spmm(deal, B, bias=b, act=ops.ACT_TANH).t)
+        B = ops.DMat.from_numpy(_rand((30000, 300), 5), dev)
+        assert torch.equal(ops.spmm(own, ops.cast_bf16(B)).t, ops.spmm(deal, ops.cast_bf16(B)).t)
+        T, H = ops.DMat.from_numpy(np.abs(_rand((30000, 300), 6)) % 1.0, dev), ops.DMat.from_numpy(_rand((30000, 300), 7), dev)
+        b = torch.from_numpy(_rand((300,), 2)).to(dev)
+        r1, r2 = ops.spmm_highway(own, B, b, T, H), ops.spmm_highway(deal, B, b, T, H)
+        assert torch.equal(r1[0].t, r2[0].t) and torch.equal(r1[1].t, r2[1].t)
+    assert ops.CSR(A, dev).chunks_with_owner is False        # (a power-law graph without community structure)
+    band = sps.diags([np.ones(30000 - abs(k)) for k in range(-200, 201)], list(range(-200, 201)), format='csr', dtype=np.float32)
+    assert ops.CSR(band, dev, long_row_nnz=256).chunks_with_owner is True
+
+
 def test_spmm_timer_rides_on_the_plan_handle(dev):
     """The profiling timer is a caller-held handle attached to ONE plan (no library-global state): products on another
     plan, of another width, or fused highway launches are not sampled; detaching stops the sampling."""
@@ -401,17 +426,6 @@ def test_gemm_kcat_two_products_one_accumulator(dev, M, N, K0, K1):
     dB0n, dB1n = ops.DMat.from_numpy(np.ascontiguousarray(B0.T), dev), ops.DMat.from_numpy(np.ascontiguousarray(B1.T), dev)
     got = ops.gemm_kcat(dA0, dB0n, dA1, dB1n)
     assert np.all(np.abs(got.numpy() - ref) <= tol)
-    # carry form (geogcn_gemm_kcat_carry_f32): + G (.) (1 - T) formed in the epilogue == accumulating onto the stored
-    # carry that geogcn_highway_bwd_f32 writes, bit for bit; and highway_bwd without the carry output
-    G, T = ops.DMat.from_numpy(_rand((M, N), 6), dev), ops.DMat.from_numpy(np.abs(_rand((M, N), 7)) % 1.0, dev)
-    Hc, H = ops.DMat.from_numpy(np.tanh(_rand((M, N), 8)), dev), ops.DMat.from_numpy(_rand((M, N), 9), dev)
-    dS, dU, carry = ops.highway_bwd(G, T, Hc, H)
-    dS2, dU2, none = ops.highway_bwd(G, T, Hc, H, want_carry=False)
-    assert none is None and np.array_equal(dS.numpy(), dS2.numpy()) and torch.equal(dU.t, dU2.t)      # (dS: gather pitch, pads unwritten)
-    assert np.array_equal(carry.numpy(), (G.numpy() * (np.float32(1.0) - T.numpy())).astype(np.float32))
-    want = ops.gemm_kcat(dA0, dB0, dA1, dB1, out=carry, transB=True, accumulate=True)
-    got = ops.gemm_kcat(dA0, dB0, dA1, dB1, transB=True, carry=(G, T))
-    assert torch.equal(got.t, want.t)
 
 
 def _bow(n_docs, n_words, mean, seed):
