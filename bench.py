@@ -105,76 +105,44 @@ def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample, multithreaded=False):
                       "graph; %s, BLAS sgemm uses %d threads" % (n_conv, shape, spmm_note, threads)}
 
 
-def time_isolated(fn, reps=10, warmup=2):
-    import torch
-    for _ in range(warmup):
-        fn()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record()
-        fn()
-        b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
-    return ts[len(ts) // 2]
-
-
-def other_kernels(clf, g, hid, N, C, precision):
-    """Live, isolated timings of the other hot kernels on the model's own operands (median of 10 launches each):
-    HBM-bound ones priced with their algorithmic bytes, the GEMMs with their flops against the fp32 MFMA peak."""
-    import torch
+def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
+    """The other hot kernels timed INSIDE real training steps (ops.StepTimers: an event pair around each wrapper call on the
+    launch stream, `n_steps` extra steps after the timed region; median over the calls): the step's own operands, cache state
+    and clocks.  HBM-bound ones are priced with their algorithmic bytes, the GEMMs with their flops against the fp32 MFMA peak."""
     from geographconv_amd import ops
-    dev = clf.device
     F = hid[0]
+    with ops.StepTimers() as st:
+        for _ in range(n_steps):
+            step()
+    ms = {k: sorted(v)[len(v) // 2] for k, v in st.ms().items()}
+    calls = {k: len(v) // n_steps for k, v in st.ms().items()}
     out = []
+    how = "in-step: median of %d calls inside %d f_train steps (event pairs on the launch stream)"
 
-    def hbm(name, ms, alg, note=''):
-        out.append({"kernel": name, "bound": "hbm", "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": alg / ms / 1e6 / HBM_PEAK_GBPS, "note": note})
+    def hbm(name, key, alg, note=''):
+        if key in ms:
+            out.append({"kernel": name, "bound": "hbm", "ms": ms[key], "algorithmic_bytes": alg, "achieved": alg / ms[key] / 1e6,
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms[key] / 1e6 / HBM_PEAK_GBPS,
+                        "calls_per_step": calls[key], "how": how % (calls[key] * n_steps, n_steps), "note": note})
 
-    def mfma(name, ms, flops, note=''):
-        out.append({"kernel": name, "bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "note": note})
+    def mfma(name, key, flops, note=''):
+        if key in ms:
+            out.append({"kernel": name, "bound": "mfma", "ms": ms[key], "flops": flops, "achieved": flops / ms[key] / 1e9,
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / ms[key] / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                        "calls_per_step": calls[key], "how": how % (calls[key] * n_steps, n_steps), "note": note})
     X, A = g['X'], g['A']
-    W0 = clf.store.params[0].data
-    b0 = clf.store.params[1].data
-    S0 = ops.DMat(N, F, dev)
-    nnzX, V = X.fwd.nnz, X.shape[1]
-    hbm("X . W0 + b0, tanh  (spmm_hot_kernel: hot rows of W0 in LDS)", time_isolated(lambda: ops.spmm_x(X, W0, out=S0, bias=b0, act=ops.ACT_TANH)),
-        8 * nnzX + 4 * (N + 1) + 4 * V * F + 4 * N * F)
-    G = ops.DMat.empty(N, F, dev, ld=ops.gather_ld(F))
-    G.t.normal_()
-    dW0 = ops.DMat(V, F, dev)
-    hbm("X^T . dS0  (head panel GEMM + xt_tail_kernel + combine)", time_isolated(lambda: ops.spmm_t(X, G, out=dW0)),
-        8 * nnzX + 4 * N * F + 4 * V * F)
-    if len(hid) > 1 and F == hid[1]:
-        T = ops.DMat(N, F, dev)
-        T.t.uniform_()
-        H = ops.DMat(N, F, dev)
-        H.t.normal_()
-        bh = torch.zeros(ops.pad4(F), device=dev)
-        nnz = A.fwd.nnz
-        hbm("tanh(A_hat . Z + bh) with the highway mix in the epilogue  (spmm_rows_kernel<.., HW>)",
-            time_isolated(lambda: ops.spmm_highway(A.fwd, G, bh, T, H)), spmm_algorithmic_bytes(N, N, nnz, F) + 3 * 4 * N * F,
-            "algorithmic bytes = the plain product's + T, H read and Hout written")
-        if precision == 'f32':
-            Wh = ops.DMat(F, F, dev)
-            Wt = ops.DMat(F, F, dev)
-            Wh.t.normal_(0, 0.05)
-            Wt.t.normal_(0, 0.05)
-            bt = torch.full((ops.pad4(F),), -4.0, device=dev)
-            Z = ops.DMat.empty(N, F, dev, ld=ops.gather_ld(F))
-            T2 = ops.DMat(N, F, dev)
-            fl = 2.0 * N * F * F
-            mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_kernel NN, dual)",
-                 time_isolated(lambda: ops.gemm_dual(H, Wh, Wt, out0=Z, out1=T2, bias1=bt, act1=ops.ACT_SIGMOID)), 2 * fl)
-            dWh, dWt = ops.DMat(F, F, dev), ops.DMat(F, F, dev)
-            mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)",
-                 time_isolated(lambda: ops.gemm_dual(H, G, T, out0=dWh, out1=dWt, transA=True)), 2 * fl)
-            dH = ops.DMat(N, F, dev)
-            dH.t.zero_()
-            mfma("dH += dZ . Wh^T + dU . Wt^T  (gemm_kernel NT, K-concatenated)",
-                 time_isolated(lambda: ops.gemm_kcat(G, Wh, T, Wt, out=dH, transB=True, accumulate=True)), 2 * fl)
+    nnzX, V, nnz = X.fwd.nnz, X.shape[1], A.fwd.nnz
+    xw = 8 * nnzX + 4 * (N + 1) + 4 * V * F + 4 * N * F
+    hbm("X . W0 + b0, tanh  (spmm_hot_kernel: hot rows of W0 in LDS)", 'spmm_x', xw)
+    hbm("X . W0 + b0, tanh, with the dropout that follows in the epilogue  (spmm_hot_kernel<.., DROP>)", 'spmm_x_dropout',
+        xw + 4 * N * F + N * F, "algorithmic bytes = the plain product's + the dropped copy and the byte mask written")
+    hbm("X^T . dS0  (head panel GEMM + xt_tail_kernel + combine)", 'spmm_t', 8 * nnzX + 4 * N * F + 4 * V * F)
+    hbm("tanh(A_hat . Z + bh) with the highway mix in the epilogue  (spmm_rows_kernel<.., HW> + long-row combine)", 'spmm_highway',
+        spmm_algorithmic_bytes(N, N, nnz, F) + 3 * 4 * N * F, "algorithmic bytes = the plain product's + T, H read and Hout written")
+    fl = 2.0 * N * F * F
+    mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_kernel NN, dual)", 'gemm_dual_nn', 2 * fl)
+    mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)", 'gemm_dual_tn', 2 * fl)
+    mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_kernel NT, K-concatenated)", 'gemm_kcat', 2 * fl)
     return out
 
 
@@ -416,7 +384,8 @@ def main():
                     "edges_per_launch": int(csr.nnz), "bytes_per_edge": alg / max(1, int(csr.nnz))}
         if world == 1 and args.shape != 'cmu':
             try:
-                roofline["others"] = other_kernels(clf, g, args.hid, N, C, args.gemm_precision)
+                roofline["others"] = other_kernels(clf, lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), g, args.hid, N, C,
+                                                   args.gemm_precision)
             except Exception as e:                       # evidence only: never fail the headline line over it
                 roofline["others_error"] = repr(e)
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz

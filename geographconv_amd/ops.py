@@ -15,6 +15,49 @@ from . import _ffi, tuning
 from ._ffi import ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_TANH, check  # noqa: F401
 
 
+class StepTimers:
+    """Measurement aid (bench.py): while an instance is installed with `with StepTimers() as t:`, the wrappers named in
+    `_timed` record a torch.cuda.Event pair around their launches on the current stream -- the kernels timed INSIDE a real
+    training step, on the step's own operands and cache state, instead of isolated re-runs.  Off (None) in normal use: the
+    wrappers then pay one attribute test."""
+    active = None
+
+    def __init__(self):
+        self.events = {}
+
+    def __enter__(self):
+        StepTimers.active = self
+        return self
+
+    def __exit__(self, *exc):
+        StepTimers.active = None
+
+    def ms(self):
+        """-> {label: [milliseconds per call]} (synchronises)."""
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+
+
+def _timed(label):
+    def deco(fn):
+        def wrapper(*args, **kw):
+            t = StepTimers.active
+            if t is None:
+                return fn(*args, **kw)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(*args, **kw)
+            if out is None:                # (a fused path that declined: nothing ran)
+                return out
+            b.record()
+            name = label(*args, **kw) if callable(label) else label
+            t.events.setdefault(name, []).append((a, b))
+            return out
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
+
+
 def pad4(F: int) -> int:
     return (int(F) + 3) // 4 * 4
 
@@ -297,6 +340,7 @@ def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F
     return out
 
 
+@_timed('spmm_highway')
 def spmm_highway(A: CSR, B, bias: torch.Tensor, T: DMat, H: DMat, Hc: DMat = None, Hout: DMat = None):
     """(Hc, Hout) = (tanh(A . B + bias), T*Hc + (1-T)*H) in one launch -- the highway block's convolution with
     the gating mix (reference gcnmodel.py:266) fused into the SpMM's epilogue."""
@@ -366,6 +410,7 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     return out
 
 
+@_timed(lambda A, B0, B1, **kw: 'gemm_dual_tn' if kw.get('transA') else 'gemm_dual_nn')
 def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None, transA=False, bias0=None, act0=ACT_NONE,
               bias1=None, act1=ACT_NONE):
     """(out0, out1) = (act0(op(A) . B0 + bias0), act1(op(A) . B1 + bias1)) in ONE launch (exact fp32): the highway block's
@@ -388,6 +433,7 @@ def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None,
     return out0, out1
 
 
+@_timed('gemm_kcat')
 def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False):
     """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
     dH = dZ . Wh^T + dU . Wt^T of the highway block."""
@@ -740,6 +786,7 @@ def sparse_dropout(x: SparseOperand, p, seed, call):
     return SparseOperand(fwd, bwd, False, x.head_idx, head)
 
 
+@_timed('spmm_t')
 def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff)."""
     # column slabs of <= XT_MAX_F: the kernel keeps 2 x F/64 float4 accumulators per lane in registers; up to 320 columns
@@ -803,6 +850,7 @@ def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, ac
     return out
 
 
+@_timed('spmm_x')
 def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE):
     """out = act(x . W + bias) for a sparse input x (S.structured_dot(X, W0), reference gcnmodel.py:39-42): the hot rows
     of W from LDS (geogcn_spmm_csr_hot_f32) from tuning.HOT_MIN_NNZ stored entries on, the plain row gather below.
@@ -818,6 +866,7 @@ def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = Non
     return spmm(x.fwd, W, out=out, bias=bias, act=act)
 
 
+@_timed('spmm_x_dropout')
 def spmm_x_dropout(x: SparseOperand, W: DMat, bias, act, p, mask_in=None, seed=0, offset=0, calls_dev=None, per_call=0, base=0):
     """(H0, Hd, mask) = (act(x . W + bias), H0 * keep / (1-p), keep-mask) in ONE launch (geogcn_spmm_csr_hot_dropout_f32):
     the sparse-input layer with the dropout that follows it (reference gcnmodel.py:353,357) in the product's epilogue.  The
