@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: Lasagne-like graph helpers, initialisers, parameter order,
 gcnmain's data plumbing (dump.pkl format, geo_eval, haversine, flag parsing)."""
 import gzip
+import sys
 import os
 import pickle
 
@@ -159,3 +160,81 @@ def test_synthetic_data_tuple_shape():
     assert A.shape == (9475, 9475) and Xtr.shape[0] + Xdv.shape[0] + Xte.shape[0] == 9475
     assert len(Utr) == Xtr.shape[0] and set(clat) == set(str(c) for c in range(129))
     assert all(u in uloc for u in Ute[:5])
+
+
+def test_content_keys_are_128_bit_and_frozen_arrays_are_hashed_once():
+    """Device copies of index / label vectors are keyed by CONTENT (128-bit hash): an in-place edit changes the key; a
+    read-only array that owns its data is hashed once per object; a read-only VIEW of a writable array is not trusted."""
+    from geographconv_amd import gcnmodel as M
+    a = np.arange(1000, dtype=np.int32)
+    k1 = M._content_key(a)
+    assert max(M._content_key(np.arange(n))[2].bit_length() for n in range(1, 9)) > 64           # a 128-bit digest
+    a[3] = 7
+    k2 = M._content_key(a)
+    assert k1 != k2 and M._content_key(a.copy()) == k2
+    a.setflags(write=False)
+    calls = []
+    real = M._hash_bytes
+    M._hash_bytes = lambda mv: calls.append(1) or real(mv)
+    try:
+        assert M._content_key(a) == k2 and M._content_key(a) == k2 and M._content_key(a) == k2
+        assert len(calls) == 1                                  # hashed once, then remembered for this object
+        b = np.arange(1000, dtype=np.int32)
+        v = b[:500]
+        v.setflags(write=False)
+        M._content_key(v)
+        M._content_key(v)
+        assert len(calls) == 3                                  # a view of a writable base: rehashed every time
+    finally:
+        M._hash_bytes = real
+    assert M._content_key(None) is None
+
+
+def test_product_code_reads_only_the_documented_environment_variables():
+    """geographconv_amd/tuning.py is the one table: four environment variables (+ the build script's GEOGCN_BUILD_DEFINES), no
+    getenv() in the kernels outside an ablation build."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'geographconv_amd')
+    seen = set()
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                if f.endswith('.py'):
+                    seen.update(re.findall(r"environ(?:\.get)?\(?\[?\s*['\"](GEOGCN_[A-Z0-9_]+)", src))
+                else:
+                    src = re.sub(r'#ifdef GEOGCN_BF16_PROBE_BUILD.*?#endif', '', src, flags=re.S)
+                    seen.update(re.findall(r'getenv\("(GEOGCN_[A-Z0-9_]+)"', src))
+    assert seen == {'GEOGCN_GEMM_PRECISION', 'GEOGCN_HIP_GRAPH', 'GEOGCN_DIST_EXCHANGE', 'GEOGCN_DIST_BACKEND',
+                    'GEOGCN_BUILD_DEFINES'}, seen
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run: one process per GPU on
+    127.0.0.1 and a free port, the caller's flags handed through, the ranks' exit code returned."""
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1', '--shape', 'cmu'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert 1024 < int(cmd[cmd.index('--master-port') + 1]) < 65536
+    assert cmd[-8:] == ['--gpus', '4', '--steps', '3', '--warmup', '1', '--shape', 'cmu'] and cmd[-9].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
