@@ -141,6 +141,21 @@ def test_bench_partitioned_at_the_full_twitterus_shape():
         assert c['max_abs_dP'] <= 5e-8 and c['argmax_agreement'] >= 0.99999, (scheme, c)
 
 
+def test_bench_partitioned_config5_shape_bf16_full_size():
+    """BASELINE configs[4]'s model (six 600-wide highway layers, bf16 H.W products, bf16 gathered operand AND bf16 on the wire)
+    at the full TwitterUS size through the same self-launching command: two ranks, both exchange schemes, each against rank
+    0's un-partitioned bf16 steps.  Measured (profiles/r03_l_staged_cfg5_w2.json): losses to 1.4e-6, identical accuracies, max
+    |dP| 1.9e-7, argmax agreement >= 0.999975 (the partitioned GEMMs tile 220,000 rows per rank: the fp32 accumulation order
+    inside a product is unchanged, the loss sums are added over two partial sums)."""
+    d = _run_bench_self_launched(['--gpus', '2', '--hid', '600', '600', '600', '600', '600', '600', '--gemm-precision', 'bf16',
+                                  '--steps', '1', '--warmup', '1'], 2400)
+    assert d['config']['world_size'] == 2 and d['dtype'] == 'bf16' and '600x600x600x600x600x600' in d['config']['workload']
+    for scheme in ('allgather', 'a2a'):
+        c = d['partition_check'][scheme]
+        assert c['max_abs_dloss'] <= 1e-5 and c['max_abs_dacc'] <= 4e-6, (scheme, c)
+        assert c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9999, (scheme, c)
+
+
 def test_gcnmain_row_partitioned_on_one_gpu(tmp_path):
     """The reference's entry point under torch.distributed.run with 3 ranks (sharing cuda:0, staged collectives): fit with
     early stopping decided identically on every rank, predict + geo_eval through the row partition -- same dev accuracy and
