@@ -666,7 +666,7 @@ class SparseOperand:
     one CSR serves both directions; otherwise CSR(A^T) is built once on the host.
 
     For a bag-of-words X (Zipfian columns) the TRANSPOSED product is split: the few columns denser than
-    tuning.DENSE_HEAD_DENSITY form a dense N x K panel (``head_dense``) whose X^T . G runs on the MFMA pipe (split-K GEMM),
+    the cost model of dense_head_size picks form a dense N x K panel (``head_dense``) whose X^T . G runs on the MFMA pipe (split-K GEMM),
     and the long tail stays sparse: ``bwd`` holds the tail rows of X^T (head rows empty).  The forward product X . W
     serves the hot rows of W from LDS instead (HotCSR)."""
 
@@ -706,10 +706,8 @@ class SparseOperand:
         head_idx = head_dense = None
         if dense_head and m.shape[0] > 0:
             col_nnz = np.diff(mt.indptr)
-            cand = np.nonzero(col_nnz >= tuning.DENSE_HEAD_DENSITY * m.shape[0])[0]
-            if len(cand) > tuning.DENSE_HEAD_MAX_COLS:
-                cand = cand[np.argsort(-col_nnz[cand], kind='stable')[:tuning.DENSE_HEAD_MAX_COLS]]
-            cand = np.sort(cand)
+            k = dense_head_size(col_nnz, m.shape[0])
+            cand = np.sort(np.argsort(-col_nnz, kind='stable')[:k])
             if len(cand) >= 16:
                 panel = DMat(m.shape[0], len(cand), device)
                 panel.t[:, :len(cand)].copy_(torch.from_numpy(np.ascontiguousarray(m[:, cand].toarray())))
@@ -724,6 +722,23 @@ class SparseOperand:
         bwd = CSR(mt, device, long_row_nnz, chunk_nnz)
         bwd._xt_plans = {}
         return SparseOperand(fwd, bwd, False, head_idx, head_dense)
+
+
+def dense_head_size(col_nnz, n_rows):
+    """How many of the densest columns of a bag-of-words X go into the dense head panel of X^T . G (0 = none): the size among
+    tuning.DENSE_HEAD_SIZES (whole GEMM tiles) that minimises  padded rows x 2 N / GEMM rate  +  tail entries x 4 B / gather
+    rate  (per output column; both terms scale with the output width alike)."""
+    nnz_sorted = np.sort(np.asarray(col_nnz, dtype=np.int64))[::-1]
+    nonempty = int(np.count_nonzero(nnz_sorted))
+    cum = np.concatenate([[0], np.cumsum(nnz_sorted)])
+    total = int(cum[-1])
+
+    def cost(k):
+        padded = 0 if k == 0 else min(-(-k // 128) * 128, -(-k // 160) * 160)
+        return padded * 2.0 * n_rows / tuning.DENSE_HEAD_GEMM_FLOPS + (total - int(cum[k])) * 4.0 / tuning.DENSE_HEAD_GATHER_BYTES_PER_S
+    sizes = [k for k in tuning.DENSE_HEAD_SIZES if k <= min(nonempty, tuning.DENSE_HEAD_MAX_COLS)]
+    best = min([0] + sizes, key=cost)
+    return int(best)
 
 
 class XtPlan:

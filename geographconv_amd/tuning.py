@@ -41,9 +41,16 @@ FUSE_HIGHWAY = 'f32'
 FUSE_DROPOUT = True
 
 # ---- X path thresholds ---------------------------------------------------------------------------------------------
-# a column of X denser than this is cheaper as part of a dense N x K panel on the MFMA pipe (2NF flop at ~100 TF) than
-# as nnz row gathers (nnz * 4F bytes at the ~7 TB/s beyond-L2 ceiling): break-even nnz/N = 3.5 %
-DENSE_HEAD_DENSITY = 0.035
+# X^T . G is split into a dense N x K head panel on the MFMA pipe and a sparse tail.  K is chosen by a cost model (round 3;
+# ops.dense_head_size): the K densest columns cost padded(K) rows of a split-K GEMM (tiles of 128 / 160 rows: 180 columns pay
+# for 256), the tail costs its stored entries at the sweep's MARGINAL gather rate.  Rates fitted to same-box measurements of the
+# whole product at the TwitterUS shape (profiles/r03_m_head_size.txt): head of 160 / 180 / 256 / 320 / 384 / 480 columns = 2.03 /
+# 2.13 / 1.91 / 2.02 / 2.03 / 2.28 ms -- the head GEMM costs ~2.6 us per padded row (101 TFLOP/s of padded work), an entry moved
+# from the tail saves ~0.2 ns (the densest tail words are split into many units: their entries cost more than the average
+# 0.13 ns).  Until round 3 the rule was a density threshold (3.5 %), which took 180 columns = 256 padded rows with 76 of them empty.
+DENSE_HEAD_GEMM_FLOPS = 101e12
+DENSE_HEAD_GATHER_BYTES_PER_S = 6.0e12
+DENSE_HEAD_SIZES = (160, 256, 320, 384, 480, 512)
 DENSE_HEAD_MAX_COLS = 512
 # X^T . dS0 goes through the document-blocked sweep (geogcn_xt_dot_f32) from this many stored tail entries on; below,
 # dS0 sits in the L2 / Infinity Cache anyway and the plain row gather is as fast

@@ -454,7 +454,7 @@ def test_compact_cross_entropy_gradient_equals_the_scattered_one(cmu, monkeypatc
     assert clf._device_graph(c['X'], c['A'])['A_tr'][2] is False
 
 
-def test_asymmetric_adjacency_uses_explicit_transpose():
+def test_asymmetric_adjacency_uses_explicit_transpose(monkeypatch):
     """The reference's A_hat is symmetric (unit weights), and then one CSR serves A.Z and A^T.dS.  That is checked at
     upload, not assumed: a row-normalised D^-1 (A + I) is NOT symmetric, the backward must multiply by the explicit
     transpose (also in the training-columns shortcut of the output layer) -- gradients against the oracle."""
@@ -469,7 +469,12 @@ def test_asymmetric_adjacency_uses_explicit_transpose():
     A = sps.csr_matrix(sps.diags(1.0 / d) @ B, dtype=np.float32)        # random-walk normalisation: rows sum to 1
     A.sort_indices()
     assert abs(A - A.T).max() > 1e-3
+    from geographconv_amd import tuning
+    # (a dense head panel for this small operand too: whole tiles of 32 columns, GEMM rows priced at nothing)
+    monkeypatch.setattr(tuning, 'DENSE_HEAD_SIZES', (32,))
+    monkeypatch.setattr(tuning, 'DENSE_HEAD_GEMM_FLOPS', 1e30)
     op = ops.SparseOperand.from_scipy(A, torch.device('cuda:0'))
+    monkeypatch.undo()
     assert not op.symmetric and op.bwd is not op.fwd
     hid = [32, 32]
     params = O.random_params(X.shape[1], hid, 7, True, seed=11)

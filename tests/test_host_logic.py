@@ -238,3 +238,17 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
     assert 1024 < int(cmd[cmd.index('--master-port') + 1]) < 65536
     assert cmd[-8:] == ['--gpus', '4', '--steps', '3', '--warmup', '1', '--shape', 'cmu'] and cmd[-9].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_dense_head_size_follows_the_cost_model():
+    """ops.dense_head_size: the head panel of X^T . G takes whole GEMM tiles of the densest columns while a padded row of the
+    split-K product (2 N flop per output column) is cheaper than gathering the entries it removes from the tail."""
+    from geographconv_amd import ops, synth
+    s = synth.SHAPES['twus']
+    X = synth.bow_x(s.N, s.V, s.mean_nnz)
+    col = np.diff(sps.csc_matrix(X).indptr)
+    assert ops.dense_head_size(col, s.N) == 256                        # (the 3.5 % density rule took 180 columns = 256 padded rows)
+    assert ops.dense_head_size(np.full(5000, 40), 100000) == 0         # uniformly sparse columns: no head
+    assert ops.dense_head_size(np.r_[np.full(160, 60000), np.full(5000, 40)], 100000) == 160
+    assert ops.dense_head_size(np.r_[np.full(100, 60000), np.full(20, 40)], 100000) == 0     # fewer columns than a tile
+    assert ops.dense_head_size(np.zeros(10, dtype=np.int64), 50) == 0

@@ -66,6 +66,15 @@ def main():
         plan._h, ops._p(x.bwd.colidx), ops._p(x.bwd.val), ops._p(G.t), G.ld, ops._p(dW.t), dW.ld, ops._p(w), w.numel(),
         ops._stream())), args.reps)[0], alg_bwd)
     show('   head GEMM alone (transA)', timeit(lambda: ops.gemm(x.head_dense, G, transA=True), args.reps)[0], alg_bwd)
+    # head size: the cost model's choice (above) against forced sizes (180 = what the 3.5 % density rule of rounds 1-2 took)
+    del plan
+    for k in (160, 256, 320, 384, 480):
+        tuning.DENSE_HEAD_SIZES = (k,)
+        xk = ops.SparseOperand.from_scipy(X, dev)
+        tuning.XT_MIN_NNZ = 0
+        show('X^T.dS0  head of %d columns + tail (%d entries)' % (xk.head_dense.F if xk.head_dense is not None else 0, xk.bwd.nnz),
+             timeit(lambda: ops.spmm_t(xk, G, out=dW), args.reps)[0], alg_bwd)
+        del xk
 
 
 if __name__ == '__main__':
