@@ -346,8 +346,15 @@ __global__ __launch_bounds__(TPB) void colsum_final_kernel(int nparts, int F, co
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + c;
     float a = 0.f;
-    if (col < F)
-        for (int p = g; p < nparts; p += 16) a += P[(int64_t)p * stride + col];
+    if (col < F) {
+        int p = g;                       // (four loads in flight, same order of additions)
+        for (; p + 48 < nparts; p += 64) {
+            const float p0 = P[(int64_t)p * stride + col], p1 = P[(int64_t)(p + 16) * stride + col];
+            const float p2 = P[(int64_t)(p + 32) * stride + col], p3 = P[(int64_t)(p + 48) * stride + col];
+            a = (((a + p0) + p1) + p2) + p3;
+        }
+        for (; p < nparts; p += 16) a += P[(int64_t)p * stride + col];
+    }
     s[g][c] = a;
     __syncthreads();
     if (g == 0 && col < F) {

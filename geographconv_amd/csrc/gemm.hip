@@ -466,8 +466,19 @@ __global__ __launch_bounds__(TPB) void splitk_reduce_kernel(int64_t M, int64_t N
     const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= M * N) return;
     const int64_t row = e / N, col = e % N;
+    // slabs added in slab order; eight loads are in flight at a time (a load -> add chain per slab paid one L2 round trip each)
     float acc = 0.f;
-    for (int z = 0; z < nsplit; ++z) acc += W[((int64_t)z * M + row) * ldw + col];
+    const float* w = W + row * ldw + col;
+    const int64_t zs = M * ldw;
+    int z = 0;
+    for (; z + 8 <= nsplit; z += 8) {
+        float pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = w[(int64_t)(z + k) * zs];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += pv[k];
+    }
+    for (; z < nsplit; ++z) acc += w[(int64_t)z * zs];
     if (bias) acc += bias[col];
     acc = apply_act<ACT>(acc);
     if (accumulate) acc += C[row * ldc + col];

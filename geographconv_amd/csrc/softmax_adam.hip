@@ -131,10 +131,14 @@ __global__ __launch_bounds__(TPB) void ce_partial_kernel(int C, const float* __r
         part[2 * blockIdx.x + 1] = b;
     }
 }
+// one wave: lane l adds the partials l, l + 64, ... in turn, the 64 lane sums are combined by the fixed butterfly of wave_sum --
+// the same association every run (one thread walking ~1,000 partials alone took 45-65 us of an otherwise idle GPU)
 __global__ void pair_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ out2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        for (int i = 0; i < nparts; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += kWave) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) {
         out2[0] = a;
         out2[1] = b;
     }
@@ -262,11 +266,10 @@ __global__ __launch_bounds__(TPB) void reg_partial_kernel(int64_t n, const float
     }
 }
 __global__ void scalar_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f;
-        for (int i = 0; i < nparts; ++i) a += part[i];
-        out[0] = a;
-    }
+    float a = 0.f;                       // (one wave, fixed association: see pair_final_kernel)
+    for (int i = threadIdx.x; i < nparts; i += kWave) a += part[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) out[0] = a;
 }
 
 constexpr int kRegParts = 256;
