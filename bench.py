@@ -232,7 +232,7 @@ def main():
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32 = exact fp32 MFMA (the headline configuration)')
     ap.add_argument('--cpu-sample', default='step', choices=['step', 'layer', 'none'])
-    ap.add_argument('--exchange', default='auto', choices=['auto', 'a2a', 'allgather'],
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'a2a', 'allgather', 'halo'],
                     help='N > 1: exchange scheme whose time is `value` (auto: all-gather at 2 ranks, a2a from 3); the other '
                          'scheme is timed too and reported under `alt`')
     ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the `value` scheme')

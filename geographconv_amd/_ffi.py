@@ -100,6 +100,7 @@ SIGNATURES = {
     'geogcn_comm_allreduce_sum_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
     'geogcn_comm_allgather': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'geogcn_comm_alltoall': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'geogcn_comm_alltoallv': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'geogcn_pack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     'geogcn_unpack_panels_f32': (c_i32, [c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_adam_step_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32,

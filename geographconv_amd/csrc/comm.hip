@@ -185,4 +185,39 @@ int geogcn_comm_alltoall(geogcn_comm* comm, const void* send, void* recv, int64_
     return 0;
 }
 
+int geogcn_comm_alltoallv(geogcn_comm* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes,
+                          void* stream) {
+    GEOGCN_REQUIRE(comm && comm->comm, GEOGCN_E_NULL, "comm_alltoallv: null communicator");
+    GEOGCN_REQUIRE(send_bytes && recv_bytes, GEOGCN_E_NULL, "comm_alltoallv: null size vectors");
+    int64_t s_total = 0, r_total = 0;
+    for (int p = 0; p < comm->world; ++p) {
+        GEOGCN_REQUIRE(send_bytes[p] >= 0 && recv_bytes[p] >= 0, GEOGCN_E_SIZE, "comm_alltoallv: negative size for peer %d", p);
+        s_total += send_bytes[p];
+        r_total += recv_bytes[p];
+    }
+    GEOGCN_REQUIRE((send || s_total == 0) && (recv || r_total == 0), GEOGCN_E_NULL, "comm_alltoallv: null buffer");
+    GEOGCN_REQUIRE(send != recv || (s_total == 0 && r_total == 0), GEOGCN_E_NULL, "comm_alltoallv: aliased buffers");
+    Rccl* r = rccl();
+    // the halo exchange: rank p gets the rows of mine its block of A_hat references, and nothing else; pieces are laid
+    // out back to back in peer order on both sides.  Every rank calls with its own vectors (a rank with nothing to
+    // send or receive still enters the group: its peers' sizes for it are zero as well, by symmetry of the lists)
+    GEOGCN_NCCL(r, r->GroupStart());
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < comm->world; ++p) {
+        ncclResult_t e = ncclSuccess;
+        if (send_bytes[p] > 0) e = r->Send((const char*)send + so, (size_t)send_bytes[p], ncclChar, p, comm->comm, (hipStream_t)stream);
+        if (e == ncclSuccess && recv_bytes[p] > 0)
+            e = r->Recv((char*)recv + ro, (size_t)recv_bytes[p], ncclChar, p, comm->comm, (hipStream_t)stream);
+        if (e != ncclSuccess) {
+            r->GroupEnd();
+            geogcn::set_error("comm_alltoallv: peer %d: %s", p, r->GetErrorString(e));
+            return 1000 + (int)e;
+        }
+        so += (size_t)send_bytes[p];
+        ro += (size_t)recv_bytes[p];
+    }
+    GEOGCN_NCCL(r, r->GroupEnd());
+    return 0;
+}
+
 }  // extern "C"

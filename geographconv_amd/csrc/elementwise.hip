@@ -376,6 +376,18 @@ __global__ __launch_bounds__(TPB) void gather_rows_kernel(int F, const float* __
     }
 }
 
+// 16 bytes per lane (the halo exchange packs whole pitched rows with this: F = the row pitch)
+__global__ __launch_bounds__(TPB) void gather_rows4_kernel(int F4, const float4* __restrict__ X, int64_t ldx4,
+                                                           const int* __restrict__ idx, int64_t n_idx,
+                                                           float4* __restrict__ out, int64_t ldo4) {
+    const int64_t total = n_idx * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t j = e / F4;
+        const int col = (int)(e - j * F4);
+        out[j * ldo4 + col] = X[(int64_t)idx[j] * ldx4 + col];
+    }
+}
+
 __global__ __launch_bounds__(TPB) void add_inplace_kernel(int64_t total4, const float4* __restrict__ X,
                                                           float4* __restrict__ Y) {
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total4; e += (int64_t)gridDim.x * TPB) {
@@ -724,6 +736,12 @@ int geogcn_gather_rows_f32(int32_t F, const float* X, int64_t ldx, const int32_t
     if (F == 0 || n_idx == 0) return 0;
     GEOGCN_REQUIRE(X && idx && out, GEOGCN_E_NULL, "gather_rows_f32: null pointer");
     GEOGCN_REQUIRE(ldx >= F && ldo >= F, GEOGCN_E_SIZE, "gather_rows_f32: ld < F");
+    if (F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)X | (uintptr_t)out) % 16 == 0) {
+        hipLaunchKernelGGL(gather_rows4_kernel, dim3(stream_grid(n_idx * (F / 4))), dim3(TPB), 0, (hipStream_t)stream, F / 4,
+                           (const float4*)X, ldx / 4, idx, n_idx, (float4*)out, ldo / 4);
+        GEOGCN_LAUNCH_CHECK("gather_rows4_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(n_idx * F)), dim3(TPB), 0, (hipStream_t)stream, F, X, ldx,
                        idx, n_idx, out, ldo);
     GEOGCN_LAUNCH_CHECK("gather_rows_kernel");

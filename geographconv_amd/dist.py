@@ -18,11 +18,20 @@ convolution S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two int
     matrix.  The row split is balanced by COST (stored edges + a per-row term), not by row count: on a power-law graph a
     rank holding the hubs would otherwise do several times the SpMM work of the others.
 
+``halo`` -- the all-gather scheme for graphs WITH locality (communities numbered contiguously, `GraphConv(reorder=...)`): the
+    same cost-balanced 1-D row split, but a rank receives only the rows of Z its block of A_hat actually references (its
+    HALO) instead of all of Z: the owner packs them (one row-gather launch) and ONE all-to-all with per-peer sizes delivers
+    them behind the rank's own rows, the local SpMM reads [own rows | halo] through renumbered columns (stored order kept:
+    bitwise the one-GPU accumulation).  On the pinned power-law graph a block of 55,000 rows references 95 % of all nodes
+    -- no better than the all-gather; on a community graph the halo is the endpoints of the ~11 % global edges.  `auto`
+    picks it when the largest halo is at most tuning.DIST_HALO_MAX_FRACTION of the remote rows.
+
 In the bf16 configuration (`gemm_precision='bf16'`, BASELINE config 5) the exchanged operand is bfloat16 in both schemes
 (the GEMM stores it as such; dS is cast while it is staged): half the bytes on the wire and per gathered row.
 
 Collectives go through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in
-the CPU tests).  GEOGCN_DIST_EXCHANGE=a2a|allgather overrides the default (all-gather at 2 ranks, a2a from 3)."""
+the CPU tests).  GEOGCN_DIST_EXCHANGE=a2a|allgather|halo overrides the default (halo where the graph allows it, else
+all-gather at 2 ranks, a2a from 3)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -119,6 +128,76 @@ class RowPartition:
         sel = (idx >= self.r0) & (idx < self.r1)
         loc = (idx[sel] - self.r0).astype(np.int32)
         return (loc, None if y is None else np.asarray(y)[sel].astype(np.int32), sel)
+
+
+def _pattern_rows(A_csr, r0, r1, symmetric):
+    """Rows [r0, r1) of the pattern of A + A^T as (indptr, indices) -- the halo of a row block must serve the forward
+    operand (A's block) and the backward one (A^T's block) alike; for a symmetric A that is A's own block."""
+    blk = A_csr[r0:r1]
+    if symmetric:
+        return blk.indptr.astype(np.int64), blk.indices.astype(np.int64)
+    both = sps.csr_matrix(blk != 0) + sps.csr_matrix(sps.csr_matrix(A_csr.T)[r0:r1] != 0)
+    both.sort_indices()
+    return both.indptr.astype(np.int64), both.indices.astype(np.int64)
+
+
+def halo_sizes(A_csr, bounds, symmetric):
+    """Rows every rank would RECEIVE per exchange under the halo scheme: distinct columns of its block (of A + A^T) that
+    other ranks own.  One pass over the whole matrix, the same on every rank (the `auto` choice must be global)."""
+    A_csr = sps.csr_matrix(A_csr)
+    N, world = A_csr.shape[0], len(bounds) - 1
+    if not symmetric:
+        A_csr = sps.csr_matrix((A_csr != 0) + (sps.csr_matrix(A_csr.T) != 0))
+    rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(A_csr.indptr))
+    cols = A_csr.indices.astype(np.int64)
+    own_r = np.searchsorted(bounds, rows, side='right') - 1
+    own_c = np.searchsorted(bounds, cols, side='right') - 1
+    far = own_r != own_c
+    pairs = np.unique(own_r[far] * N + cols[far])
+    return np.bincount(pairs // N, minlength=world).astype(np.int64)
+
+
+class HaloPlan:
+    """Who sends which rows to whom under the halo scheme, computed by every rank from ITS OWN row block of the pattern of
+    A + A^T (symmetric as a pattern, so rank q's receive list from me -- the columns in my range its rows reference, in
+    ascending order -- is my send list to q: the rows of mine that have an entry in q's range, ascending.  No negotiation).
+
+    Operand layout on rank r: rows [0, n_local) = its own block, then the halo: the rows received from rank 0, 1, ... (each
+    piece ascending by global index, i.e. the whole halo ascending).  `position(cols)` renumbers global column ids."""
+
+    def __init__(self, part: RowPartition, indptr, indices):
+        self.part = part
+        r0, r1, world, rank = part.r0, part.r1, part.world, part.rank
+        bounds = part.bounds_all
+        indices = np.asarray(indices, dtype=np.int64)
+        remote = np.unique(indices[(indices < r0) | (indices >= r1)])
+        self.recv_cols = remote                                                   # global ids, ascending = grouped by owner
+        owner = np.searchsorted(bounds, remote, side='right') - 1
+        self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        rows = np.repeat(np.arange(part.n_local, dtype=np.int64), np.diff(indptr))
+        own_c = np.searchsorted(bounds, indices, side='right') - 1
+        far = own_c != rank
+        key = np.unique(own_c[far] * max(part.n_local, 1) + rows[far])            # (destination, local row), ascending
+        self.send_rows = (key % max(part.n_local, 1)).astype(np.int32)
+        self.send_counts = np.bincount(key // max(part.n_local, 1), minlength=world).astype(np.int64)
+        self.n_halo, self.n_send = int(len(remote)), int(len(key))
+        self.n_operand = part.n_local + self.n_halo
+
+    def position(self, cols):
+        cols = np.asarray(cols, dtype=np.int64)
+        own = (cols >= self.part.r0) & (cols < self.part.r1)
+        at = np.searchsorted(self.recv_cols, cols)
+        found = self.recv_cols[np.minimum(at, self.n_halo - 1)] == cols if self.n_halo else np.zeros(len(cols), dtype=bool)
+        if not np.all(own | found):
+            raise ValueError("halo exchange: the matrix references rows outside the halo of the adjacency the plan was "
+                             "built from (TorchDistComm.prepare must see the full graph first)")
+        return np.where(own, cols - self.part.r0, self.part.n_local + at).astype(np.int32)
+
+    def local_rows_csr(self, m):
+        """Row block of a CSR matrix with its columns renumbered to operand positions, STORED ORDER KEPT (own columns are
+        no longer ascending next to halo ones; the SpMM accumulates in stored order -- the one-GPU order)."""
+        blk = sps.csr_matrix(sps.csr_matrix(m)[self.part.r0:self.part.r1])
+        return sps.csr_matrix((blk.data, self.position(blk.indices), blk.indptr), shape=(blk.shape[0], max(self.n_operand, 1)))
 
 
 class Comm:
@@ -245,7 +324,17 @@ class NativeRccl:
         return self._run(lambda st: self._ffi.check(self._lib.geogcn_comm_allgather(
             self._h, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), nbytes, st), 'comm_allgather'), async_op, (out, inp))
 
-    def all_to_all_single(self, out, inp, group=None, async_op=False):
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        if output_split_sizes is not None:
+            # the halo exchange: per-peer ROW counts of 2-D buffers with one pitch (geogcn_comm_alltoallv takes bytes)
+            assert out.is_contiguous() and inp.is_contiguous() and out.dim() == 2 and inp.dim() == 2
+            rb = inp.shape[1] * inp.element_size()
+            assert rb == out.shape[1] * out.element_size()
+            sb = (C.c_int64 * self.world)(*[int(s) * rb for s in input_split_sizes])
+            rcv = (C.c_int64 * self.world)(*[int(s) * rb for s in output_split_sizes])
+            return self._run(lambda st: self._ffi.check(self._lib.geogcn_comm_alltoallv(
+                self._h, C.c_void_p(inp.data_ptr()), sb, C.c_void_p(out.data_ptr()), rcv, st), 'comm_alltoallv'),
+                async_op, (out, inp))
         nbytes = inp.numel() * inp.element_size()
         assert out.is_contiguous() and inp.is_contiguous() and out.numel() * out.element_size() == nbytes and nbytes % self.world == 0
         return self._run(lambda st: self._ffi.check(self._lib.geogcn_comm_alltoall(
@@ -288,7 +377,16 @@ class HostStagedGloo:
         out.view(-1).view(torch.uint8).copy_(torch.cat(self._gather_bytes(inp)))
         return self._Done()
 
-    def all_to_all_single(self, out, inp, group=None, async_op=False):
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        if output_split_sizes is not None:
+            # halo exchange: per-peer row counts; as bytes through gloo's own all-to-all-v
+            rb = inp.shape[1] * inp.element_size()
+            ci = self._bytes(inp)
+            co = torch.empty(sum(int(s) for s in output_split_sizes) * rb, dtype=torch.uint8)
+            self._d.all_to_all_single(co, ci, [int(s) * rb for s in output_split_sizes], [int(s) * rb for s in input_split_sizes])
+            if co.numel():
+                out.view(-1).view(torch.uint8).copy_(co)
+            return self._Done()
         # (gloo's own all-to-all rejects some dtypes: every rank gathers every send buffer and keeps its own panel of each)
         w, r = self._d.get_world_size(), self._d.get_rank()
         parts = self._gather_bytes(inp)
@@ -339,13 +437,16 @@ class TorchDistComm(Comm):
         self.part = RowPartition(N, self.world, self.rank)
         self.device = device
         self.exchange = exchange or tuning.DIST_EXCHANGE
+        self._auto = self.exchange == 'auto'      # prepare() may still move to 'halo' once it has seen the graph
         if self.exchange == 'auto':
             # at 2 ranks both schemes move the same bytes and the all-gather needs no repacking; from 3 ranks on
             # the all-to-all moves (w-1)/w * 2/w of what the all-gather delivers to every rank
             self.exchange = 'a2a' if self.world >= 3 else 'allgather'
-        if self.exchange not in ('a2a', 'allgather'):
-            raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a' or 'allgather', got %r" % self.exchange)
-        self.balance = bool(balance)        # all-gather scheme: cost-balanced row split (False: uniform, the A/B)
+        if self.exchange not in ('a2a', 'allgather', 'halo'):
+            raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a', 'allgather' or 'halo', got %r" % self.exchange)
+        self.balance = bool(balance)        # all-gather / halo schemes: cost-balanced row split (False: uniform, the A/B)
+        self.halo = None                    # HaloPlan, built by graph_operand
+        self.halo_rows = None               # rows received per exchange and rank under the halo scheme (prepare)
         self._bufs = {}
 
     # -- row split ---------------------------------------------------------------------------------------
@@ -354,11 +455,35 @@ class TorchDistComm(Comm):
         term) instead of the same number of rows.  Every rank computes the same cuts from the same host matrix.  The
         a2a scheme keeps the uniform split: there the SpMM work does not depend on the row split (every rank walks all of
         A_hat on its feature panel) and the dense work is proportional to rows."""
-        if self.exchange == 'allgather' and self.balance and self.world > 1:
-            A_csr = sps.csr_matrix(A_host)
-            if A_csr.shape[0] == self.part.N:
-                self.part = RowPartition(self.part.N, self.world, self.rank, bounds=balanced_bounds(A_csr.indptr, self.world))
-                self._bufs = {}
+        if self.world <= 1:
+            return
+        A_csr = sps.csr_matrix(A_host)
+        if A_csr.shape[0] != self.part.N:
+            return
+        bounds = balanced_bounds(A_csr.indptr, self.world) if self.balance else self.part.bounds_all
+        if self._auto or self.exchange == 'halo':
+            from . import graph
+            self._symmetric = bool(graph.is_symmetric(A_csr))
+            self.halo_rows = halo_sizes(A_csr, bounds, self._symmetric)
+            remote = self.part.N - np.diff(bounds)
+            if self._auto and self.halo_rows.max() <= tuning.DIST_HALO_MAX_FRACTION * max(1, remote.min()):
+                self.exchange = 'halo'
+        if self.exchange in ('allgather', 'halo') and self.balance:
+            self.part = RowPartition(self.part.N, self.world, self.rank, bounds=bounds)
+            self._bufs = {}
+        if self.exchange == 'halo':
+            self._build_halo(A_csr)
+
+    def _build_halo(self, A_csr):
+        """The halo plan belongs to the GRAPH (prepare sees the whole adjacency); operands derived from it later -- the
+        transpose restricted to the training columns -- reference a subset of the same rows and reuse the plan."""
+        sym = getattr(self, '_symmetric', None)
+        if sym is None:
+            from . import graph
+            sym = self._symmetric = bool(graph.is_symmetric(A_csr))
+        self.halo = HaloPlan(self.part, *_pattern_rows(A_csr, self.part.r0, self.part.r1, sym))
+        self._send_rows = torch.from_numpy(self.halo.send_rows).to(self.device)
+        self._bufs = {}
 
     # -- constant operand ----------------------------------------------------------------------------
     def graph_operand(self, A_host):
@@ -370,16 +495,21 @@ class TorchDistComm(Comm):
         A_csr.sort_indices()
         At = sps.csr_matrix(A_csr.T)
         At.sort_indices()
-        if self.exchange == 'a2a':
+        if self.exchange == 'halo':
+            if self.halo is None or self.halo.part is not part:
+                self._build_halo(A_csr)             # (prepare was not called: this matrix IS the graph)
+            Af, Ab = self.halo.local_rows_csr(A_csr), self.halo.local_rows_csr(At)
+        elif self.exchange == 'a2a':
             Af, Ab = part.padded_square_csr(A_csr), part.padded_square_csr(At)
         else:
             Af = part.local_rows_csr(A_csr, part.n_gathered)
             Ab = part.local_rows_csr(At, part.n_gathered)
         same = (Af.shape == Ab.shape and np.array_equal(Af.indptr, Ab.indptr) and np.array_equal(Af.indices, Ab.indices)
                 and np.array_equal(Af.data, Ab.data))
-        # (slot positions are monotone in the global index: the stored order, hence the accumulation order, is unchanged)
-        fwd = K.CSR(Af, self.device)
-        bwd = fwd if same else K.CSR(Ab, self.device)
+        # (slot positions are monotone in the global index: the stored order, hence the accumulation order, is unchanged;
+        #  halo positions are not monotone -- `sort=False` keeps the stored order there)
+        fwd = K.CSR(Af, self.device, sort=False)
+        bwd = fwd if same else K.CSR(Ab, self.device, sort=False)
         return K.SparseOperand(fwd, bwd, same)
 
     # -- buffers ---------------------------------------------------------------------------------------
@@ -396,6 +526,20 @@ class TorchDistComm(Comm):
                 buf = K.DMat(self.part.n_gathered, F, self.device, ld=K.gather_ld(F))
             self._bufs[key] = buf
         return buf
+
+    def _halo_buffers(self, F, tag, bf16=False):
+        """(operand [own rows | halo], send buffer) of one exchange site; both keep the gather pitch."""
+        K = backend.active()
+        key = ('halo', int(F), tag, bool(bf16))
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            n = max(self.halo.n_operand, 1)
+            op = K.HMat(n, F, self.device) if bf16 else K.DMat(n, F, self.device, ld=K.gather_ld(F))
+            if bf16:
+                op.t.zero_()
+            send = torch.zeros((max(self.halo.n_send, 1), op.ld), dtype=op.t.dtype, device=self.device)
+            bufs = self._bufs[key] = (op, send)
+        return bufs
 
     def _panels(self, kind, F, tag, bf16=False):
         K = backend.active()
@@ -417,6 +561,8 @@ class TorchDistComm(Comm):
         graph_spmm_begin then packs)."""
         K = backend.active()
         bf16 = self._bf16(precision) and direct
+        if self.exchange == 'halo':
+            return self._halo_buffers(F, tag, bf16)[0].rows(0, self.part.n_local)    # the GEMM writes the head of the operand
         if self.exchange == 'allgather':
             buf = self._gather_buffer(F, tag, bf16)
             lo = self.rank * self.part.R
@@ -429,7 +575,7 @@ class TorchDistComm(Comm):
         """The backward's dS (a plain fp32 matrix) as the exchange's operand."""
         K = backend.active()
         bf16 = self._bf16(precision)
-        if self.exchange == 'allgather':
+        if self.exchange in ('allgather', 'halo'):
             g = self.matmul_target(F, tag=tag, precision=precision)
             if bf16:
                 K.cast_bf16(m, out=g)
@@ -459,6 +605,15 @@ class TorchDistComm(Comm):
         on its own stream); continue with graph_spmm_mid / graph_spmm_end."""
         K = backend.active()
         h = dict(A=A_csr, bias=bias, act=act, F=F, tag=tag, mid=False)
+        if self.exchange == 'halo':
+            op, send = self._halo_buffers(F, tag, isinstance(z, K.HMat))
+            hp = self.halo
+            K.pack_rows(op.rows(0, self.part.n_local), self._send_rows, send[:hp.n_send])
+            h['buf'] = op
+            h['work'] = self.dist.all_to_all_single(op.t[self.part.n_local:self.part.n_local + hp.n_halo], send[:hp.n_send],
+                                                    output_split_sizes=hp.recv_counts.tolist(),
+                                                    input_split_sizes=hp.send_counts.tolist(), group=self.group, async_op=True)
+            return h
         if self.exchange == 'allgather':
             buf = self._gather_buffer(F, tag, isinstance(z, K.HMat))
             R = self.part.R
@@ -477,7 +632,7 @@ class TorchDistComm(Comm):
 
     def graph_spmm_mid(self, h):
         """a2a: wait for panel `rank` of all rows, multiply, start the return exchange.  allgather: nothing to do."""
-        if h['mid'] or self.exchange == 'allgather':
+        if h['mid'] or self.exchange in ('allgather', 'halo'):
             return h
         K = backend.active()
         part = self.part
@@ -504,7 +659,7 @@ class TorchDistComm(Comm):
     def graph_spmm_end(self, h):
         """-> row-partitioned result (n_local x F)."""
         K = backend.active()
-        if self.exchange == 'allgather':
+        if self.exchange in ('allgather', 'halo'):
             if h['work'] is not None:
                 h['work'].wait()
             return K.spmm(h['A'], h['buf'], bias=h['bias'], act=h['act'], F=h['F'])

@@ -608,6 +608,18 @@ def gather_rows(X: DMat, idx: torch.Tensor, out: torch.Tensor = None):
     return out
 
 
+def pack_rows(X, idx: torch.Tensor, out: torch.Tensor):
+    """out[j] = the whole PITCHED row idx[j] of X (DMat or HMat; `out` has X's dtype and pitch): the halo exchange's send
+    buffer (dist.py).  bf16 rows travel as pairs -- the pitch is even -- through the same 16-byte-per-lane kernel."""
+    if idx.numel() == 0:
+        return out
+    assert out.dtype == X.t.dtype and out.shape[1] == X.ld and out.is_contiguous()
+    src, dst = (X.t.view(torch.float32), out.view(torch.float32)) if X.t.dtype == torch.bfloat16 else (X.t, out)
+    w = src.shape[1]
+    check(_ffi.lib().geogcn_gather_rows_f32(w, _p(src), w, _p(idx), idx.numel(), _p(dst), w, _stream()), 'gather_rows_f32')
+    return out
+
+
 def scatter_rows(src: DMat, idx: torch.Tensor, out: DMat):
     """out[idx[j], :] = src[j, :]"""
     check(_ffi.lib().geogcn_scatter_rows_f32(src.F, _p(src.t), src.ld, _p(idx), idx.numel(), _p(out.t), out.ld,

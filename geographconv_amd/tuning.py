@@ -4,7 +4,7 @@ Environment variables read by product code -- four, all about WHICH configuratio
 
   GEOGCN_GEMM_PRECISION  f32 (default) | bf16x3 | bf16      default of GraphConv(gemm_precision=...) / -gemm-precision
   GEOGCN_HIP_GRAPH       0 (default) | 1                    default of GraphConv(hip_graph=...): capture + replay the step
-  GEOGCN_DIST_EXCHANGE   auto (default) | a2a | allgather   default of TorchDistComm(exchange=...)
+  GEOGCN_DIST_EXCHANGE   auto (default) | a2a | allgather | halo   default of TorchDistComm(exchange=...)
   GEOGCN_DIST_BACKEND    torch (default) | native | staged-gloo   transport of the partitioned path (dist.backend_name)
 
 (`GEOGCN_BUILD_DEFINES` is read by build.py only: ablation builds.)  Everything else is a module attribute below: a
@@ -70,3 +70,8 @@ L2_WINDOW_ROWS = 3300
 # all-gather scheme: cost of one row in stored-edge equivalents when the row split is balanced (dense work of a row
 # ~44 ns over ~0.97 ns per stored edge for the 6 products of a step)
 ROW_COST_IN_EDGES = 45.0
+# `auto` exchange: take the halo scheme when the largest per-rank halo (rows received per exchange) is at most this
+# fraction of the rows an all-gather would deliver to that rank.  Below one half the halo's pack launch and its
+# non-contiguous sends are paid for several times over; the pinned power-law graph sits at 0.95, a community graph
+# numbered by label propagation at 0.1-0.3 (dist.halo_sizes)
+DIST_HALO_MAX_FRACTION = 0.5

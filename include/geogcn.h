@@ -368,6 +368,12 @@ int     geogcn_comm_allgather(geogcn_comm* comm, const void* send, void* recv, i
  * geogcn_gemm_panels_f32 writes and the narrow SpMM reads); W - 1 point-to-point transfers in one group, one per xGMI
  * link.  send and recv must not alias.                                                                              */
 int     geogcn_comm_alltoall(geogcn_comm* comm, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+/* halo exchange (graphs WITH locality, dist.py HaloPlan): rank p receives send_bytes[p] bytes of `send` -- the rows of this
+ * rank's block that p's rows of A_hat reference, packed back to back in peer order -- and recv_bytes[p] bytes from p land in
+ * `recv`, again back to back in peer order.  Both vectors are HOST arrays of `world` entries; zero-sized pieces are skipped
+ * (the lists are symmetric: what I do not send to p, p does not post a receive for).  send and recv must not alias.        */
+int     geogcn_comm_alltoallv(geogcn_comm* comm, const void* send, const int64_t* send_bytes, void* recv,
+                              const int64_t* recv_bytes, void* stream);
 
 /* ---- K11/K12: lasagne.updates.adam (+ l1/l2 penalty gradient), gcnmodel.py:383-387,407 ------
  * flat arenas of n floats: t is the step index AFTER increment (1 for the first call).

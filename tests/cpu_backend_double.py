@@ -233,6 +233,12 @@ def gather_rows(X, idx, out=None):
     return torch.from_numpy(_v(X)[idx.numpy()].copy())
 
 
+def pack_rows(X, idx, out):
+    if idx.numel():
+        out.copy_(X.t[idx.long()])
+    return out
+
+
 def pack_panels(X, R, W, wp, out):
     o = out.numpy().reshape(W, R, wp)
     o[...] = 0

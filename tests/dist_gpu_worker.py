@@ -20,7 +20,8 @@ def main():
     from geographconv_amd.nn import layers as L
     from tests.helpers import load_case, make_clf
     for name, exchange in [('tiny_highway', 'a2a'), ('tiny_plain_reg', 'a2a'), ('tiny_odd_widths', 'a2a'),
-                           ('tiny_highway', 'allgather'), ('tiny_odd_widths', 'allgather')]:
+                           ('tiny_highway', 'allgather'), ('tiny_odd_widths', 'allgather'), ('tiny_highway', 'halo'),
+                           ('tiny_plain_reg', 'halo'), ('tiny_odd_widths', 'halo')]:
         z, A, X, params, cfg = load_case(name)
         comm = TorchDistComm(cfg['N'], device, exchange=exchange)
         clf = make_clf(cfg, params, device=device, comm=comm)
@@ -49,7 +50,7 @@ def main():
     Zh = np.random.RandomState(1).randn(6000, 44).astype(np.float32)
     bias = torch.from_numpy(np.random.RandomState(2).randn(44).astype(np.float32)).to(device)
     full = ops.spmm(ops.CSR(A, device), ops.DMat.from_numpy(Zh, device), bias=bias, act=ops.ACT_TANH)
-    for exchange in ('allgather', 'a2a'):
+    for exchange in ('allgather', 'a2a', 'halo'):
         comm = TorchDistComm(6000, device, exchange=exchange)
         comm.prepare(A)
         dA = comm.graph_operand(A)
@@ -60,7 +61,8 @@ def main():
     # bf16 configuration through the partitioned path (bf16 operand on the wire): agrees with the one-GPU bf16 run
     z_, A_, X_, params, cfg = load_case('tiny_highway')
     ref = None
-    for comm in (None, TorchDistComm(cfg['N'], device, exchange='a2a'), TorchDistComm(cfg['N'], device, exchange='allgather')):
+    for comm in (None, TorchDistComm(cfg['N'], device, exchange='a2a'), TorchDistComm(cfg['N'], device, exchange='allgather'),
+                 TorchDistComm(cfg['N'], device, exchange='halo')):
         from geographconv_amd.gcnmodel import GraphConv
         clf = GraphConv(cfg['V'], cfg['C'], cfg['hid'], cfg['reg'], cfg['p'], highway=True, device=device, comm=comm,
                         gemm_precision='bf16')
@@ -89,7 +91,7 @@ def main():
     tr_, dv_ = np.sort(perm[:2500]).astype(np.int32), np.sort(perm[2500:3500]).astype(np.int32)
     mask_ = (rng.rand(5003, 52) < 0.5).astype(np.uint8)
     ref = None
-    for exchange in (None, 'a2a', 'allgather'):
+    for exchange in (None, 'a2a', 'allgather', 'halo'):
         comm = None if exchange is None else TorchDistComm(5003, device, exchange=exchange)
         clf = GraphConv(700, C_, hid, 0.0, 0.5, highway=True, device=device, comm=comm)
         clf.build_model(None, seed=77)
@@ -107,6 +109,42 @@ def main():
             assert np.allclose(got[1], want[1], rtol=2e-4, atol=2e-6), (exchange, step)
             for i, (g, r) in enumerate(zip(got[2], want[2])):
                 assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), (exchange, step, i)
+    # a graph WITH locality (communities numbered contiguously): `auto` must pick the halo exchange from 2 ranks on, receive a
+    # fraction of what an all-gather delivers, and reproduce the one-GPU run
+    import scipy.sparse as sps
+    Nc, ncomm = 6000, 12
+    A_ = _synth.community_ahat(Nc, 70000, n_comm=ncomm, p_in=0.9, seed=11)
+    order = np.argsort(_synth.community_edges(Nc, 70000, ncomm, 0.9, seed=11)[1], kind='stable')
+    A_ = sps.csr_matrix(A_[order][:, order])
+    A_.sort_indices()
+    X_ = _synth.bow_x(Nc, 500, 10, seed=12)
+    Y_ = _synth.labels(Nc, 9, seed=13)
+    hid, C_ = [36, 36], 9
+    params = O.random_params(500, hid, C_, True, seed=14, scale=0.3)
+    perm = np.random.RandomState(15).permutation(Nc)
+    tr_, dv_ = np.sort(perm[:3000]).astype(np.int32), np.sort(perm[3000:4000]).astype(np.int32)
+    ref = None
+    for auto in (False, True):
+        comm = TorchDistComm(Nc, device) if auto else None
+        clf = GraphConv(500, C_, hid, 0.0, 0.0, highway=True, device=device, comm=comm)
+        clf.build_model(None, seed=77)
+        L.set_all_param_values(clf.l_out, [q.copy() for q in params])
+        res = []
+        for step in range(2):
+            o = clf.f_train(X_, Y_[tr_], Y_[dv_], A_, tr_, dv_)
+            res.append(([float(v) for v in o[:4]], clf.gather_output(o[4]), clf.get_grads()))
+        if not auto:
+            ref = res
+            continue
+        if dist.get_world_size() > 1:
+            assert comm.exchange == 'halo', comm.exchange
+            remote = Nc - np.diff(comm.part.bounds_all)
+            assert comm.halo.n_halo == comm.halo_rows[comm.rank] and comm.halo_rows.max() <= 0.5 * remote.min(), comm.halo_rows
+        for step, (got, want) in enumerate(zip(res, ref)):
+            assert np.allclose(got[0], want[0], rtol=2e-5, atol=2e-6), ('auto-halo', step, got[0], want[0])
+            assert np.allclose(got[1], want[1], rtol=2e-4, atol=2e-6), ('auto-halo', step)
+            for i, (g, r) in enumerate(zip(got[2], want[2])):
+                assert np.allclose(g, r, rtol=5e-4, atol=5e-7 + 2e-5 * np.abs(r).max()), ('auto-halo', step, i)
     # random small models (sizes smaller than / not divisible by the world size, odd widths, tiny class counts) against
     # the CPU restatement -- the same generator as tests/test_dist_cpu.py, here with the HIP kernels
     for seed in range(int(os.environ.get('GEOGCN_TEST_DIST_SEEDS', '8'))):
@@ -128,7 +166,7 @@ def main():
         if len(dv_) == 0:
             dv_ = tr_[:1].copy()
         mask_ = (rng.rand(N, hid[0]) < (1 - p)).astype(np.uint8) if p > 0 else np.ones((N, hid[0]), np.uint8)
-        for exchange in ('a2a', 'allgather'):
+        for exchange in ('a2a', 'allgather', 'halo'):
             comm = TorchDistComm(N, device, exchange=exchange)
             comm.prepare(A_)
             # (every third model also goes through a node reordering: invisible to the caller, partitioned or not)
@@ -152,7 +190,7 @@ def main():
         # the bf16 configuration (bf16 operand and wire) on the same model: partitioned vs this process's one-GPU bf16 run
         if seed % 2 == 0:
             ref = None
-            for exchange in (None, 'a2a', 'allgather'):
+            for exchange in (None, 'a2a', 'allgather', 'halo'):
                 comm = None if exchange is None else TorchDistComm(N, device, exchange=exchange)
                 if comm is not None:
                     comm.prepare(A_)

@@ -82,6 +82,56 @@ def test_cost_balanced_bounds_and_slot_layout():
     assert np.array_equal(S[parts[0].slot_position(np.arange(3000))], A @ Z)
 
 
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_halo_plan_lists_agree_across_ranks_and_keep_the_product(symmetric):
+    """halo scheme: every rank derives its send and receive lists from ITS OWN rows; they must pair up (what r sends to q
+    is, row for row, what q expects from r), the renumbered block must give the plain product in the STORED order, and
+    `halo_sizes` (the global figure behind the `auto` choice) must equal what the plans say."""
+    from geographconv_amd.dist import HaloPlan, _pattern_rows, balanced_bounds, halo_sizes
+    A = None
+    if symmetric:
+        # a community graph numbered BY community (the generator shuffles the ids; graph.label_propagation recovers this)
+        A = synth.community_ahat(1200, 9000, n_comm=6, p_in=0.9, seed=5)
+        order = np.argsort(synth.community_edges(1200, 9000, 6, 0.9, seed=5)[1], kind='stable')
+        A = sps.csr_matrix(A[order][:, order])
+        A.sort_indices()
+    else:
+        A = sps.random(1200, 1200, density=0.004, format='csr', dtype=np.float32, random_state=2) + sps.identity(1200, format='csr', dtype=np.float32)
+        A = sps.csr_matrix(A)
+        A.sort_indices()
+    N, w = A.shape[0], 5
+    b = balanced_bounds(A.indptr, w, row_cost=10.0)
+    b[2] = b[1]                                                          # a rank that owns NO rows
+    parts = [RowPartition(N, w, r, bounds=b) for r in range(w)]
+    plans = [HaloPlan(p, *_pattern_rows(A, p.r0, p.r1, symmetric)) for p in parts]
+    assert np.array_equal(halo_sizes(A, b, symmetric), [pl.n_halo for pl in plans])
+    Z = np.random.RandomState(0).randn(N, 5).astype(np.float32)
+    At = sps.csr_matrix(A.T)
+    At.sort_indices()
+    for q, (p, pl) in enumerate(zip(parts, plans)):
+        assert pl.recv_counts[q] == 0 and pl.send_counts[q] == 0 and pl.recv_counts.sum() == pl.n_halo
+        # what arrives: rank r's packed rows for q, peer after peer
+        pieces = []
+        for r, (pr, plr) in enumerate(zip(parts, plans)):
+            o = int(plr.send_counts[:q].sum())
+            rows = plr.send_rows[o:o + int(plr.send_counts[q])]
+            assert len(rows) == pl.recv_counts[r]
+            pieces.append(pr.r0 + rows)
+        assert np.array_equal(np.concatenate(pieces), pl.recv_cols)      # same rows, same order, no negotiation
+        operand = np.concatenate([Z[p.r0:p.r1], Z[pl.recv_cols]])
+        for M in (A, At):
+            blk = pl.local_rows_csr(M)
+            ref = M[p.r0:p.r1]
+            assert np.array_equal(blk.indptr, ref.indptr) and np.array_equal(blk.data, ref.data)     # stored order kept
+            assert np.array_equal(operand[blk.indices], Z[ref.indices])
+    if symmetric:
+        # the community graph's halo is a fraction of what an all-gather delivers; the power-law graph's is nearly all of it
+        comm_frac = max(pl.n_halo / max(1, N - p.n_local) for p, pl in zip(parts, plans) if p.n_local)
+        P = synth.powerlaw_ahat(1200, 9000, seed=5)
+        pw = halo_sizes(P, balanced_bounds(P.indptr, w), True) / (N - np.diff(balanced_bounds(P.indptr, w)))
+        assert comm_frac < pw.max()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -124,7 +174,8 @@ def _worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3), ("a2a", 8), ("allgather", 4)])
+@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3), ("a2a", 8), ("allgather", 4), ("halo", 2),
+                                            ("halo", 3), ("halo", 8)])
 def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     import torch.multiprocessing as mp
     from tests.helpers import load_case
@@ -200,7 +251,7 @@ def _asym_worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 2)])
+@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 2), ("halo", 3)])
 def test_multi_rank_asymmetric_adjacency(exchange, world):
     import torch.multiprocessing as mp
     from oracle import gcn_oracle as O
@@ -289,7 +340,7 @@ def _random_worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 3), ("a2a", 4)])
+@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 3), ("a2a", 4), ("halo", 4)])
 def test_multi_rank_gloo_random_models(exchange, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')

@@ -74,6 +74,19 @@ def test_comm_entry_points_world1():
     torch.cuda.synchronize()
     assert torch.equal(buf, keep) and torch.equal(recv, send)
     assert lib.geogcn_comm_alltoall(c._h, C.c_void_p(send.data_ptr()), C.c_void_p(send.data_ptr()), 16, None) == -1   # aliased
+    # the halo exchange's per-peer sizes (row counts of pitched 2-D buffers -> geogcn_comm_alltoallv in bytes): at one rank
+    # the only piece is the own one; zero-sized pieces are skipped
+    rows = torch.randn(5, 64, device=dev)
+    got = torch.zeros(5, 64, device=dev)
+    c.all_to_all_single(got, rows, output_split_sizes=[5], input_split_sizes=[5], async_op=True).wait()
+    c.all_to_all_single(got[:0], rows[:0], output_split_sizes=[0], input_split_sizes=[0])
+    torch.cuda.synchronize()
+    assert torch.equal(got, rows)
+    one = (C.c_int64 * 1)(64)
+    assert lib.geogcn_comm_alltoallv(c._h, C.c_void_p(rows.data_ptr()), one, C.c_void_p(rows.data_ptr()), one, None) == -1   # aliased
+    assert lib.geogcn_comm_alltoallv(c._h, C.c_void_p(rows.data_ptr()), None, C.c_void_p(got.data_ptr()), one, None) == -1
+    neg = (C.c_int64 * 1)(-4)
+    assert lib.geogcn_comm_alltoallv(c._h, C.c_void_p(rows.data_ptr()), neg, C.c_void_p(got.data_ptr()), one, None) == -2
     assert lib.geogcn_comm_allreduce_sum_f32(None, C.c_void_p(x.data_ptr()), 4, None) == -1
     c.close()
 

@@ -37,7 +37,15 @@ class FakeDist:
     def get_world_size(self, group=None):
         return self.world
 
-    def all_to_all_single(self, out, inp, group=None, async_op=False):
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        if output_split_sizes is not None:               # halo exchange: as many bytes written as a rank receives
+            k = min(out.shape[0], inp.shape[0])
+            out[:k].copy_(inp[:k])
+            if out.shape[0] > k:
+                out[k:].zero_()
+            self.bytes_a2a += out.numel() * out.element_size()
+            self.n_a2a += 1
+            return _Done()
         out.copy_(inp)                                   # same bytes through HBM instead of xGMI
         self.bytes_a2a += inp.numel() * inp.element_size() * (self.world - 1) // self.world
         self.n_a2a += 1
@@ -61,6 +69,10 @@ class SimComm(TorchDistComm):
         self.device = device
         self.exchange = exchange
         self.balance = True
+        self._auto = exchange == 'auto'
+        if self._auto:
+            self.exchange = 'a2a' if world >= 3 else 'allgather'
+        self.halo = self.halo_rows = None
         self._bufs = {}
 
 
@@ -73,11 +85,13 @@ def main():
     ap.add_argument('--shape', default='twus')
     ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
     ap.add_argument('--gemm-precision', default='f32')
+    ap.add_argument('--reorder', default=None, help="GraphConv(reorder=...): 'lpa' numbers communities contiguously")
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     A, X, Y, (tr, dv, te), C = synth.make_graph(args.shape)
     comm = SimComm(A.shape[0], dev, args.rank, args.world, args.exchange)
-    clf = GraphConv(X.shape[1], C, args.hid, 0.0, 0.5, highway=True, device=dev, comm=comm, gemm_precision=args.gemm_precision)
+    clf = GraphConv(X.shape[1], C, args.hid, 0.0, 0.5, highway=True, device=dev, comm=comm, gemm_precision=args.gemm_precision,
+                    reorder=args.reorder)
     clf.build_model(A, seed=77)
     for _ in range(2):
         clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
@@ -89,8 +103,10 @@ def main():
         clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
+    if comm.halo_rows is not None:
+        print('halo rows per rank and exchange: %s  (an all-gather delivers %d)' % (comm.halo_rows.tolist(), comm.part.N - comm.part.n_local))
     print('world=%d rank=%d exchange=%s %s rows %d (of %d): %.2f ms compute per step; per step: %d all-to-all (%.0f MB on the wire), '
-          '%d all-gather (%.0f MB)' % (args.world, args.rank, args.exchange, args.gemm_precision, comm.part.n_local, comm.part.N, ms,
+          '%d all-gather (%.0f MB)' % (args.world, args.rank, comm.exchange, args.gemm_precision, comm.part.n_local, comm.part.N, ms,
                                        d.n_a2a // args.steps, d.bytes_a2a / args.steps / 1e6, d.n_ag // args.steps,
                                        d.bytes_ag / args.steps / 1e6))
 
