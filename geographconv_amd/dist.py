@@ -24,7 +24,7 @@ convolution S = A_hat . Z (forward) / dZ = A_hat^T . dS (backward), with two int
     them behind the rank's own rows, the local SpMM reads [own rows | halo] through renumbered columns (stored order kept:
     bitwise the one-GPU accumulation).  On the pinned power-law graph a block of 55,000 rows references 95 % of all nodes
     -- no better than the all-gather; on a community graph the halo is the endpoints of the ~11 % global edges.  `auto`
-    picks it when the largest halo is at most tuning.DIST_HALO_MAX_FRACTION of the remote rows.
+    picks it when the largest halo is at most tuning.DIST_HALO_MAX_FRACTION (0.9 at two ranks) of the remote rows.
 
 In the bf16 configuration (`gemm_precision='bf16'`, BASELINE config 5) the exchanged operand is bfloat16 in both schemes
 (the GEMM stores it as such; dS is cast while it is staged): half the bytes on the wire and per gathered row.
@@ -466,7 +466,8 @@ class TorchDistComm(Comm):
             self._symmetric = bool(graph.is_symmetric(A_csr))
             self.halo_rows = halo_sizes(A_csr, bounds, self._symmetric)
             remote = self.part.N - np.diff(bounds)
-            if self._auto and self.halo_rows.max() <= tuning.DIST_HALO_MAX_FRACTION * max(1, remote.min()):
+            limit = tuning.DIST_HALO_MAX_FRACTION_2_RANKS if self.world == 2 else tuning.DIST_HALO_MAX_FRACTION
+            if self._auto and self.halo_rows.max() <= limit * max(1, remote.min()):
                 self.exchange = 'halo'
         if self.exchange in ('allgather', 'halo') and self.balance:
             self.part = RowPartition(self.part.N, self.world, self.rank, bounds=bounds)

@@ -71,7 +71,11 @@ L2_WINDOW_ROWS = 3300
 # ~44 ns over ~0.97 ns per stored edge for the 6 products of a step)
 ROW_COST_IN_EDGES = 45.0
 # `auto` exchange: take the halo scheme when the largest per-rank halo (rows received per exchange) is at most this
-# fraction of the rows an all-gather would deliver to that rank.  Below one half the halo's pack launch and its
-# non-contiguous sends are paid for several times over; the pinned power-law graph sits at 0.95, a community graph
-# numbered by label propagation at 0.1-0.3 (dist.halo_sizes)
+# fraction of the rows an all-gather would deliver to that rank.  From 3 ranks on the alternative is the feature
+# repartition (a quarter of the all-gather's bytes at 8 ranks, but ~1 ms more compute per rank and step): the halo wins
+# below 0.44 (8 ranks) ... 0.6 (4 ranks) of an all-gather -> 0.5.  At 2 ranks the alternative IS the all-gather, over the one
+# link of the pair: any smaller halo pays for its pack launch (60 us against 3.4 ms of wire per exchange) -> 0.9.
+# The pinned power-law graph sits at 0.87-0.95, a community graph numbered by label propagation at 0.27 (8 ranks) / 0.67
+# (2 ranks) (dist.halo_sizes)
 DIST_HALO_MAX_FRACTION = 0.5
+DIST_HALO_MAX_FRACTION_2_RANKS = 0.9
