@@ -390,6 +390,206 @@ int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
 }
 
 
+// ---- the skinny contractions of the bf16 configuration (K <= 608, N <= 640): whole rows of A per block ----------------
+// gemm_bf16_kernel above stages 128 x 32 slices of A per barrier -- one 128-byte line per row and stage, 26 KB in flight per
+// block -- and runs latency-bound at 15 % of the bf16 pipe (profiles/r02_c_bf16_gemm.md).  For the shapes the GCN actually has
+// (N_nodes x 600 x 600, x 300 x 300, x 600 x 256 ...) this kernel takes 64 WHOLE rows of A per block instead: one contiguous read
+// (154 KB at K = 600, every load issued before the first is waited for), rounded to bf16 into LDS once (<= 79 KB: two blocks per
+// CU), then every wave multiplies all 64 rows by its own columns -- 5 column tiles per pass, up to two passes -- with B fragments
+// read straight from the L2-resident weights, which the prep kernel lays out in FRAGMENT order ([column tile][k-step][lane][8]:
+// a wave's fragment load is 1 KB of consecutive bytes; with row-major planes it touched 16 half lines: 0.82 against 0.66 ms in
+// tools/micro/bf16_astat.hip).  No barrier inside a tile, A read from HBM exactly once.  Same MFMA, same k order, same epilogue
+// arithmetic as gemm_bf16_kernel: the results are bit-identical.
+template <int NS_>
+__global__ __launch_bounds__(TPB) void prep_b_frag_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int NKs, int n_tiles,
+                                                          int b_is_nk, unsigned short* __restrict__ out) {
+    const int64_t total = (int64_t)n_tiles * NKs * 512;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        const int64_t f = e >> 9;
+        const int kt = (int)(f % NKs), nt = (int)(f / NKs);
+        const int n = nt * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8 + el;
+        float x = 0.f;
+        if (k < K && n < N) x = b_is_nk ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n];
+        out[e] = (unsigned short)bf16_rne(x);
+    }
+}
+
+constexpr int kRowsBM = 64, kRowsWCT = 5, kRowsDepth = 2;
+
+template <int KP, int ACT>
+__global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a, const int passes) {
+    constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
+    constexpr int PITCH = KP * 2 + 16;          // bytes per LDS row: an odd multiple of 16 -> conflict-free ds_read_b128
+    constexpr int F4R = KP / 4;                 // float4 per row
+    constexpr int ITERS = BM * F4R / TPB;
+    constexpr int CH = 2, IPC = ITERS / CH;     // two batches of loads: half the staging registers
+    constexpr int MR = BM / 16, NK = KP / 32;
+    static_assert(BM * F4R % (TPB * CH) == 0, "a tile must divide over the block in two batches");
+    extern __shared__ __attribute__((aligned(16))) unsigned char As[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int K4 = (int)((a.K + 3) & ~(int64_t)3);            // pad columns of A up to roundup4(K) are zero (geogcn.h); beyond: not read
+    const uint32_t ld4 = (uint32_t)a.lda * 4u;
+    const __amdgpu_buffer_rsrc_t brs = tn_rsrc(reinterpret_cast<const float*>(a.Bp), (int64_t)4 * passes * WCT * NK * 1024);
+    for (int mt = blockIdx.x; mt < a.n_mt; mt += gridDim.x) {
+        const int64_t m0 = (int64_t)mt * BM;
+        {
+            // (the offsets of the loads and LDS stores are the same for every tile: left alone, hipcc computes them once and keeps
+            //  ~76 registers alive across the MFMA loop -- an opaque copy of the thread index makes them per-tile work)
+            int tt = tid;
+            asm volatile("" : "+v"(tt));
+            // one descriptor per tile: rows past M read as zeros in hardware
+            const int64_t rows = std::min<int64_t>(BM, a.M - m0);
+            const __amdgpu_buffer_rsrc_t rs = tn_rsrc(a.A + m0 * a.lda, rows * a.lda * 4);
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                float4 v[IPC];
+#pragma unroll
+                for (int i = 0; i < IPC; ++i) {
+                    const int idx = tt + TPB * (ch * IPC + i);
+                    const int r = idx / F4R, c = idx - r * F4R;
+                    v[i] = tn_load4(rs, c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : kOob);
+                }
+#pragma unroll
+                for (int i = 0; i < IPC; ++i) {
+                    const int idx = tt + TPB * (ch * IPC + i);
+                    const int r = idx / F4R, c = idx - r * F4R;
+                    uint2 w;
+                    w.x = bf16_pack(v[i].x, v[i].y);
+                    w.y = bf16_pack(v[i].z, v[i].w);
+                    *reinterpret_cast<uint2*>(As + r * PITCH + c * 8) = w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ps = 0; ps < passes; ++ps) {
+            const int tile0 = (wid * passes + ps) * WCT;        // first of this wave's column tiles in this pass
+            const int64_t ncol0 = (int64_t)tile0 * 16;
+            f32x4 acc[MR][WCT];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // B fragments DEPTH k-steps ahead in a ring of DEPTH + 1 register sets.  The k loop stays ROLLED (DEPTH + 1 steps per
+            // trip; ring slots are compile-time constants inside a trip) and the scheduler is fenced per step, so the requests stay
+            // one set per step; requests past the last step re-read the last one (no branch around a load)
+            auto bload = [&](bf16x8 (&b)[WCT], int kt) {
+                const int kk = kt < NK ? kt : NK - 1;
+#pragma unroll
+                for (int j = 0; j < WCT; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
+            };
+            auto kstep = [&](const bf16x8 (&b)[WCT], int kt) {
+                bf16x8 af[MR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (i * 16 + li) * PITCH + kt * 64 + lg * 16);
+#pragma unroll
+                for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+                        // operands swapped (B fragment first): the 16 x 16 product comes out transposed, a lane owns 4 consecutive
+                        // columns of one row of C
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], af[i], acc[i][j], 0, 0, 0);
+            };
+            bf16x8 ring[D1][WCT];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+#pragma unroll 1
+            for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                for (int u = 0; u < D1; ++u) {
+                    bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH);
+                    if (k0 + u < NK) kstep(ring[u], k0 + u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // epilogue: the arithmetic of gemm_bf16_kernel, in its order
+            float bcol[WCT][4];
+#pragma unroll
+            for (int j = 0; j < WCT; ++j) {
+                const int64_t col0 = ncol0 + j * 16 + lg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && col0 + r < a.N) ? a.bias[col0 + r] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int64_t row = m0 + i * 16 + li;
+                const bool row_ok = row < a.M;
+                float4 oldv[WCT];
+                if (a.accumulate) {          // (fp32 C only)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) {
+                        const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                        oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row_ok && col0 < a.N) oldv[j] = *reinterpret_cast<const float4*>((const float*)a.C + row * a.ldc + col0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) {
+                    const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                    float x[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = apply_act<ACT>(acc[i][j][r] + bcol[j][r]);
+                    if (a.accumulate) { x[0] += oldv[j].x; x[1] += oldv[j].y; x[2] += oldv[j].z; x[3] += oldv[j].w; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r >= a.N) x[r] = 0.f;
+                    if (row_ok && col0 < a.n_store) {
+                        const int64_t off = row * a.ldc + col0;
+                        if (a.c_bf16) {
+                            uint2 w;
+                            w.x = bf16_pack(x[0], x[1]);
+                            w.y = bf16_pack(x[2], x[3]);
+                            *reinterpret_cast<uint2*>((unsigned short*)a.C + off) = w;
+                        } else {
+                            *reinterpret_cast<float4*>((float*)a.C + off) = make_float4(x[0], x[1], x[2], x[3]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();          // everybody done reading this tile's rows
+    }
+}
+
+// N <= 640 in one or two passes of 4 waves x 5 column tiles; K padded to exactly one of the instantiated depths
+inline int rows_kp(int64_t N, int64_t K, int panel_w, int ns) {
+#ifdef GEOGCN_BF16_NO_ROWS_KERNEL        // A/B build only (GEOGCN_BUILD_DEFINES): everything on gemm_bf16_kernel, as before round 3
+    return 0;
+#endif
+    if (ns != 1 || panel_w != 0 || N > 640 || N < 1) return 0;
+    const int64_t Kp = cdiv(K, BKH) * BKH;
+    return (Kp == 608 || Kp == 320 || Kp == 256) ? (int)Kp : 0;
+}
+inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
+
+template <int KP>
+int launch_rows(const Bf16Args& a, int act, hipStream_t st) {
+    constexpr int lds = kRowsBM * (KP * 2 + 16);
+    const int passes = rows_passes(a.N);
+    const int G = (int)std::min<int64_t>((int64_t)kNumCU * 2, a.n_mt);
+#define GEOGCN_R(ACT)                                                                                           \
+    do {                                                                                                        \
+        auto kern = gemm_bf16_rows_kernel<KP, ACT>;                                                             \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);                             \
+        GEOGCN_LAUNCH_CHECK("gemm_bf16_rows_kernel");                                                           \
+    } while (0)
+    if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
+    else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_R(GEOGCN_ACT_SIGMOID);
+    else GEOGCN_R(GEOGCN_ACT_NONE);
+#undef GEOGCN_R
+    return 0;
+}
+
+
 // ---- dW = A^T . B with bf16 products (bf16 configuration only) -------------------------------------------
 // Both operands are k-STRIDED fp32 in memory ([K][M] and [K][N], K = the node dimension): a thread loads an
 // 8 (k) x 4 (columns) patch as eight float4s, rounds it to bf16 and writes four 16-byte k-contiguous pieces,
@@ -544,7 +744,9 @@ inline bool tn_plan(int64_t M, int64_t N, int64_t K, TnPlan& p) {
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
     const int ns = (precision == GEOGCN_GEMM_BF16X3) ? 3 : 1;
     const int64_t Kp = cdiv(K, BKH) * BKH;
-    return (size_t)ns * (size_t)N * (size_t)Kp * sizeof(unsigned short);
+    // (the whole-rows kernel reads its weights in fragment order, padded to 4 waves x passes x 5 column tiles)
+    const int64_t cols = rows_kp(N, K, 0, ns) ? std::max<int64_t>(N, (int64_t)4 * rows_passes(N) * kRowsWCT * 16) : N;
+    return (size_t)ns * (size_t)cols * (size_t)Kp * sizeof(unsigned short);
 }
 
 // called by geogcn_gemm_f32 for transA == 0 and precision != F32
@@ -557,6 +759,17 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
     GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "gemm_f32(bf16): workspace too small (%zu < %zu)",
                    ws_bytes, need);
     unsigned short* planes = (unsigned short*)ws;
+    if (const int kp = rows_kp(N, K, panel_w, ns); kp && lda % 4 == 0) {
+        const int n_tiles = 4 * rows_passes(N) * kRowsWCT, nks = kp / BKH;
+        const unsigned fgrid = (unsigned)std::min<int64_t>(cdiv((int64_t)n_tiles * nks * 512, TPB), 1024);
+        hipLaunchKernelGGL((prep_b_frag_kernel<1>), dim3(fgrid), dim3(TPB), 0, st, B, ldb, (int)K, (int)N, nks, n_tiles, transB, planes);
+        GEOGCN_LAUNCH_CHECK("prep_b_frag_kernel");
+        Bf16Args a{M, N, K, A, lda, planes, kp, C, ldc, bias, accumulate, (int)cdiv(M, kRowsBM), 1, c_bf16,
+                   c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3), 0, 0};
+        if (kp == 608) return launch_rows<608>(a, act, st);
+        if (kp == 320) return launch_rows<320>(a, act, st);
+        return launch_rows<256>(a, act, st);
+    }
     const unsigned pgrid = (unsigned)std::min<int64_t>(cdiv((int64_t)N * Kp, TPB), 1024);
     if (ns == 3)
         hipLaunchKernelGGL((prep_b_planes_kernel<3>), dim3(pgrid), dim3(TPB), 0, st, B, ldb, (int)K, (int)N, Kp, transB, planes);

@@ -303,6 +303,54 @@ def test_gemm_bf16_modes(dev, M, N, K):
         ops.gemm(dA, dB, out=ops.HMat(M, N, dev), precision='f32')
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 600, 600), (130, 640, 600), (70, 256, 600), (333, 300, 256), (65, 7, 300),
+                                   (4099, 321, 300), (64, 320, 590), (1, 600, 600)])
+def test_gemm_bf16_whole_rows_kernel(dev, M, N, K):
+    """The skinny shapes of the bf16 configuration (K padded to 256 / 320 / 608, N <= 640) run on gemm_bf16_rows_kernel: 64
+    whole rows of A per block, weights in fragment order.  Checked against the SAME arithmetic in float64 -- operands rounded
+    to bf16 (RNE), exact products -- within the fp32 accumulation envelope, through every epilogue (bias + activation,
+    accumulate, bf16 result), both weight layouts, ragged row counts, and for run-to-run equality."""
+    from geographconv_amd import ops
+
+    def bf16(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).double().numpy()
+
+    A = _rand((M, K), 11)
+    W = _rand((K, N), 12) * 0.3
+    bias = _rand((N,), 13)
+    dA, dW = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(W, dev)
+    dWt = ops.DMat.from_numpy(np.ascontiguousarray(W.T), dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(N) - N))).to(dev)
+    ref = bf16(A) @ bf16(W)
+    env = 4e-7 * K ** 0.5 * (np.abs(bf16(A)) @ np.abs(bf16(W))) + 1e-6
+    for kw in (dict(), dict(transB=True)):
+        Bop = dWt if kw else dW
+        got = ops.gemm(dA, Bop, precision='bf16', **kw)
+        assert np.all(np.abs(got.numpy() - ref) <= env), np.abs(got.numpy() - ref).max()
+        assert torch.all(got.t[:, N:] == 0)                                     # pad columns stay zero
+        assert torch.equal(got.t, ops.gemm(dA, Bop, precision='bf16', **kw).t)
+        got = ops.gemm(dA, Bop, bias=db, act=ops.ACT_SIGMOID, precision='bf16', **kw).numpy()
+        want = 1.0 / (1.0 + np.exp(-(ref + bias)))
+        assert np.all(np.abs(got - want) <= env + 1e-6)
+        C0 = _rand((M, N), 14)
+        dC = ops.DMat.from_numpy(C0, dev)
+        ops.gemm(dA, Bop, out=dC, accumulate=True, precision='bf16', **kw)
+        assert np.all(np.abs(dC.numpy() - (ref + C0)) <= env + 1e-6)
+        f32 = ops.gemm(dA, Bop, bias=db, act=ops.ACT_TANH, precision='bf16', **kw)
+        h = ops.HMat(M, N, dev)
+        h.t.fill_(7.0)
+        ops.gemm(dA, Bop, out=h, bias=db, act=ops.ACT_TANH, precision='bf16', **kw)
+        assert torch.equal(h.t[:, :N], f32.t[:, :N].to(torch.bfloat16))
+        assert torch.all(h.t[:, N:(N + 7) // 8 * 8].float() == 0)
+    # an operand with the line-aligned gather pitch (what the model hands over) and a row range of a larger matrix
+    big = ops.DMat.empty(M + 9, K, dev, ld=ops.gather_ld(K))
+    big.t.fill_(float('nan'))                                                   # (pads beyond roundup4(K) are never read)
+    big.t[:, :ops.pad4(K)] = 0
+    big.t[5:5 + M, :K] = torch.from_numpy(A).to(dev)
+    got = ops.gemm(big.rows(5, 5 + M), dW, precision='bf16')
+    assert np.all(np.abs(got.numpy() - ref) <= env)
+
+
 @pytest.mark.parametrize("R,M,N", [(5000, 300, 300), (4097, 300, 129), (333, 300, 600), (20000, 64, 8)])
 def test_gemm_tn_splitk_matches_oracle_and_is_deterministic(dev, R, M, N):
     from geographconv_amd import ops
