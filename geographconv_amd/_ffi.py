@@ -65,6 +65,8 @@ SIGNATURES = {
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'geogcn_highway_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
+    'geogcn_highway_bwd_bf16s_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
+                                             c_ptr, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_highway_bwd_workspace_bytes': (c_sz, [c_i64, c_i32]),
     'geogcn_act_bwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_f32, c_ptr, c_i64, c_ptr]),
     'geogcn_act_bwd_colsum_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_f32, c_ptr, c_i64, c_ptr,

@@ -97,26 +97,55 @@ __global__ __launch_bounds__(TPB) void highway_fwd_kernel(int64_t total4, const 
     }
 }
 
+// the three gradients of the gating mix, every operation rounded on its own (no fused multiply-add): the four kernels below
+// -- fp32 / bf16 dS, with / without column sums -- must produce the SAME fp32 values (a contraction chosen differently in one
+// instantiation moved dS by an ulp and its bf16 rounding across a tie), and this is the arithmetic of the NumPy restatement
+__device__ __forceinline__ void hw_grad(float g, float t, float hc, float h, float& s, float& u, float& c) {
+#pragma clang fp contract(off)
+    s = (g * t) * (1.0f - hc * hc);
+    u = ((g * (hc - h)) * t) * (1.0f - t);
+    c = g * (1.0f - t);
+}
+
+// S16: dS is stored as bfloat16 (round to nearest even, the bits geogcn_cast_bf16_f32 would produce), pitch ld4_dS in units of
+// four elements, the WHOLE pitch written (pads as zeros) -- the bf16 configuration's A^T . dS gathers it as it is, so the
+// fp32 dS and the separate cast pass disappear (the bias gradient below is still the column sum of the fp32 values)
+// (gfx950's v_cvt_pk_bf16_f32: two values per instruction, the bits of bf16_rne for every finite input -- the integer sequence
+//  costs ~10 VALU instructions per value, which this latency-bound kernel feels: 1.57 against 1.29 ms at 600 wide)
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 pack_bf16x4(const float4& s) {
+    const hw_f32x2 lo = {s.x, s.y}, hi = {s.z, s.w};
+    uint2 o;
+    o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, hw_bf16x2));
+    o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, hw_bf16x2));
+    return o;
+}
+
+template <bool S16>
 __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t n, int ld4, const float4* __restrict__ G,
                                                           const float4* __restrict__ T, const float4* __restrict__ Hc,
-                                                          const float4* __restrict__ H, float4* __restrict__ dS,
+                                                          const float4* __restrict__ H, void* __restrict__ dSv,
                                                           int ld4_dS, float4* __restrict__ dU, float4* __restrict__ dHc) {
+    float4* dS = (float4*)dSv;
     const int64_t total4 = n * ld4;
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total4; e += (int64_t)gridDim.x * TPB) {
         const float4 g = G[e], t = T[e], hc = Hc[e], h = H[e];
         float4 s, u, c;
-#define GEOGCN_HW(m)                                   \
-    s.m = (g.m * t.m) * (1.0f - hc.m * hc.m);          \
-    u.m = ((g.m * (hc.m - h.m)) * t.m) * (1.0f - t.m); \
-    c.m = g.m * (1.0f - t.m);
+#define GEOGCN_HW(m) hw_grad(g.m, t.m, hc.m, h.m, s.m, u.m, c.m);
         GEOGCN_HW(x) GEOGCN_HW(y) GEOGCN_HW(z) GEOGCN_HW(w)
 #undef GEOGCN_HW
         int64_t es = e;
-        if (ld4_dS != ld4) {
+        if (S16 || ld4_dS != ld4) {
             const int64_t row = e / ld4;
-            es = row * ld4_dS + (e - row * ld4);
+            const int q = (int)(e - row * ld4);
+            es = row * ld4_dS + q;
+            if constexpr (S16) {
+                for (int pq = ld4 + q; pq < ld4_dS; pq += ld4) ((uint2*)dSv)[row * ld4_dS + pq] = make_uint2(0u, 0u);
+            }
         }
-        dS[es] = s;
+        if constexpr (S16) ((uint2*)dSv)[es] = pack_bf16x4(s);
+        else dS[es] = s;
         dU[e] = u;
         dHc[e] = c;
     }
@@ -125,11 +154,13 @@ __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t n, int ld4, co
 // Same arithmetic, plus the column sums of dS and dU (the two bias gradients) in the same pass: block b owns
 // a contiguous chunk of rows, thread (ri, q) walks float4 column q of every rpi-th row; the per-thread sums are
 // combined over ri in fixed order and written as one partial row per block (summed by colsum_final_kernel).
+template <bool S16>
 __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int ld4, const float4* __restrict__ G,
                                                                  const float4* __restrict__ T, const float4* __restrict__ Hc,
-                                                                 const float4* __restrict__ H, float4* __restrict__ dS,
+                                                                 const float4* __restrict__ H, void* __restrict__ dSv,
                                                                  int ld4_dS, float4* __restrict__ dU, float4* __restrict__ dHc,
                                                                  int64_t rows_per_block, float4* __restrict__ P) {
+    float4* dS = (float4*)dSv;
     __shared__ float4 red[2][TPB];
     const int W = ld4, rpi = TPB / W;
     const int q = threadIdx.x % W, ri = threadIdx.x / W;
@@ -140,15 +171,18 @@ __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int 
             const int64_t e = row * ld4 + q;
             const float4 g = G[e], t = T[e], hc = Hc[e], h = H[e];
             float4 s, u, c;
-#define GEOGCN_HW(m)                                   \
-    s.m = (g.m * t.m) * (1.0f - hc.m * hc.m);          \
-    u.m = ((g.m * (hc.m - h.m)) * t.m) * (1.0f - t.m); \
-    c.m = g.m * (1.0f - t.m);                          \
-    aS.m += s.m;                                       \
+#define GEOGCN_HW(m)                              \
+    hw_grad(g.m, t.m, hc.m, h.m, s.m, u.m, c.m);  \
+    aS.m += s.m;                                  \
     aU.m += u.m;
             GEOGCN_HW(x) GEOGCN_HW(y) GEOGCN_HW(z) GEOGCN_HW(w)
 #undef GEOGCN_HW
-            dS[row * ld4_dS + q] = s;
+            if constexpr (S16) {
+                ((uint2*)dSv)[row * ld4_dS + q] = pack_bf16x4(s);
+                for (int pq = W + q; pq < ld4_dS; pq += W) ((uint2*)dSv)[row * ld4_dS + pq] = make_uint2(0u, 0u);
+            } else {
+                dS[row * ld4_dS + q] = s;
+            }
             dU[e] = u;
             dHc[e] = c;
         }
@@ -527,9 +561,26 @@ size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F) {
     return (size_t)hw_parts(n) * 2 * (size_t)((F + 3) / 4) * 4 * sizeof(float);
 }
 
+static int highway_bwd_impl(bool s16, int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
+                            int64_t ld, void* dS, int64_t ld_dS, float* dU, float* dHcarry, float* dbS, float* dbU, void* ws,
+                            size_t ws_bytes, void* stream);
+
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
                            int64_t ld, float* dS, int64_t ld_dS, float* dU, float* dHcarry, float* dbS, float* dbU,
                            void* ws, size_t ws_bytes, void* stream) {
+    return highway_bwd_impl(false, n, F, G, T, Hc, H, ld, dS, ld_dS, dU, dHcarry, dbS, dbU, ws, ws_bytes, stream);
+}
+
+int geogcn_highway_bwd_bf16s_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
+                                 int64_t ld, uint16_t* dS16, int64_t ld_dS16, float* dU, float* dHcarry, float* dbS, float* dbU,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(F <= 4 * TPB, GEOGCN_E_SIZE, "highway_bwd_bf16s_f32: F=%d is wider than the fused column sums handle", F);
+    return highway_bwd_impl(true, n, F, G, T, Hc, H, ld, dS16, ld_dS16, dU, dHcarry, dbS, dbU, ws, ws_bytes, stream);
+}
+
+static int highway_bwd_impl(bool s16, int64_t n, int32_t F, const float* G, const float* T, const float* Hc, const float* H,
+                            int64_t ld, void* dS, int64_t ld_dS, float* dU, float* dHcarry, float* dbS, float* dbU, void* ws,
+                            size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "highway_bwd_f32: negative size");
     if (F == 0) return 0;
     if (n == 0) {
@@ -538,9 +589,10 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
         if (dbU) { const int rc = zero_fill_async(dbU, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream); if (rc) return rc; }
         return 0;
     }
-    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dS, dU, dHcarry);
-    GEOGCN_REQUIRE(ld_dS % 4 == 0 && ld_dS >= ld, GEOGCN_E_ALIGN, "highway_bwd_f32: ld_dS=%lld must be a multiple of 4, >= ld",
-                   (long long)ld_dS);
+    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dU, dHcarry);
+    GEOGCN_REQUIRE(dS && (uintptr_t)dS % 16 == 0, GEOGCN_E_NULL, "highway_bwd_f32: dS is null or not 16-byte aligned");
+    GEOGCN_REQUIRE(ld_dS % (s16 ? 8 : 4) == 0 && ld_dS >= ld, GEOGCN_E_ALIGN,
+                   "highway_bwd_f32: ld_dS=%lld must be a multiple of %d, >= ld", (long long)ld_dS, s16 ? 8 : 4);
     GEOGCN_REQUIRE((dbS == nullptr) == (dbU == nullptr), GEOGCN_E_ARG, "highway_bwd_f32: pass both bias gradients or neither");
     hipStream_t st = (hipStream_t)stream;
     const int ld4 = (int)(ld / 4);
@@ -550,9 +602,14 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
         const int nparts = (int)cdiv(n, rpb);
         GEOGCN_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)nparts * 2 * ld * sizeof(float), GEOGCN_E_ARG,
                        "highway_bwd_f32: workspace too small");
-        hipLaunchKernelGGL(highway_bwd_colsum_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, ld4, (const float4*)G,
-                           (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS, (int)(ld_dS / 4), (float4*)dU,
-                           (float4*)dHcarry, rpb, (float4*)ws);
+        if (s16)
+            hipLaunchKernelGGL(highway_bwd_colsum_kernel<true>, dim3((unsigned)nparts), dim3(TPB), 0, st, n, ld4, (const float4*)G,
+                               (const float4*)T, (const float4*)Hc, (const float4*)H, dS, (int)(ld_dS / 4), (float4*)dU,
+                               (float4*)dHcarry, rpb, (float4*)ws);
+        else
+            hipLaunchKernelGGL(highway_bwd_colsum_kernel<false>, dim3((unsigned)nparts), dim3(TPB), 0, st, n, ld4, (const float4*)G,
+                               (const float4*)T, (const float4*)Hc, (const float4*)H, dS, (int)(ld_dS / 4), (float4*)dU,
+                               (float4*)dHcarry, rpb, (float4*)ws);
         GEOGCN_LAUNCH_CHECK("highway_bwd_colsum_kernel");
         hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, (const float*)ws,
                            (int64_t)2 * ld, dbS);
@@ -561,12 +618,16 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
         GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
         return 0;
     }
-    hipLaunchKernelGGL(highway_bwd_kernel, dim3(stream_grid(n * ld / 4)), dim3(TPB), 0, st, n, ld4, (const float4*)G,
-                       (const float4*)T, (const float4*)Hc, (const float4*)H, (float4*)dS, (int)(ld_dS / 4), (float4*)dU,
-                       (float4*)dHcarry);
+    GEOGCN_REQUIRE(!(s16 && dbS), GEOGCN_E_ARG, "highway_bwd_bf16s_f32: bias gradients need ld == roundup4(F) <= %d", 4 * TPB);
+    if (s16)
+        hipLaunchKernelGGL(highway_bwd_kernel<true>, dim3(stream_grid(n * ld / 4)), dim3(TPB), 0, st, n, ld4, (const float4*)G,
+                           (const float4*)T, (const float4*)Hc, (const float4*)H, dS, (int)(ld_dS / 4), (float4*)dU, (float4*)dHcarry);
+    else
+        hipLaunchKernelGGL(highway_bwd_kernel<false>, dim3(stream_grid(n * ld / 4)), dim3(TPB), 0, st, n, ld4, (const float4*)G,
+                           (const float4*)T, (const float4*)Hc, (const float4*)H, dS, (int)(ld_dS / 4), (float4*)dU, (float4*)dHcarry);
     GEOGCN_LAUNCH_CHECK("highway_bwd_kernel");
     if (dbS) {          // very wide layers: separate deterministic column sums
-        int rc = geogcn_colsum_f32(n, F, dS, ld_dS, dbS, ws, ws_bytes, stream);
+        int rc = geogcn_colsum_f32(n, F, (const float*)dS, ld_dS, dbS, ws, ws_bytes, stream);
         if (rc) return rc;
         return geogcn_colsum_f32(n, F, dU, ld, dbU, ws, ws_bytes, stream);
     }

@@ -277,8 +277,13 @@ class MultiplicativeGatingLayer(L.MergeLayer):
         # one pass: gradients w.r.t. both PRE-activations and the carry
         # ... and the two bias gradients (column sums of dS / dU) while the data is in registers
         fuse_b = gate_l.b is not None and h1_l.b is not None
+        # bf16 configuration on one GPU: the branch gradient dS is only ever gathered by A^T . dS as bf16 -- store it so
+        # (saves the fp32 write and the cast pass over it; the exchange of a partitioned graph stages fp32 and keeps the cast)
+        s16 = (tuning.FUSE_BF16_DS and K.bf16_gather(kwargs.get('gemm_precision')) and kwargs.get('comm') is None
+               and kwargs.get('A') is not None and isinstance(h1_l, ConvolutionDenseLayer2)
+               and hasattr(K, 'highway_bwd_bf16_ok') and K.highway_bwd_bf16_ok(grad, fuse_b))
         dS, dU, dH = K.highway_bwd(grad, t, h1, h2, dbS=h1_l.b.grad if fuse_b else None,
-                                   dbU=gate_l.b.grad if fuse_b else None)
+                                   dbU=gate_l.b.grad if fuse_b else None, **({'dS_bf16': True} if s16 else {}))
         if into[2] is not None:
             K.add_inplace(dH, into[2])
             dH = into[2]

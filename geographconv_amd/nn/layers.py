@@ -473,7 +473,8 @@ class DenseLayer(Layer):
             if A_bwd is A.bwd and getattr(A, 'head_dense', None) is not None:
                 dZ = K.spmm_t(A, dS)          # an operand whose transpose is split (dense head panel + CSR tail)
             else:
-                dZ = K.spmm(A_bwd, K.cast_bf16(dS) if K.bf16_gather(kwargs.get('gemm_precision')) else dS)
+                as_is = not K.bf16_gather(kwargs.get('gemm_precision')) or not isinstance(dS, K.DMat)   # (HMat: already bf16)
+                dZ = K.spmm(A_bwd, dS if as_is else K.cast_bf16(dS))
         return self._backward_post(x, dZ, into, need_input_grad, kwargs, tape)
 
     def _backward_post(self, x, dZ, into, need_input_grad, kwargs, tape=None):

@@ -36,6 +36,10 @@ FUSE_GEMMS = True
 # epilogue's T / H loads cost more than the separate pass: 1.82 ms fused against 1.10 + 0.41), 'all', 'none'
 FUSE_HIGHWAY = 'f32'
 
+# bf16 configuration, one GPU: highway_bwd stores the branch gradient dS as bf16 (what A^T . dS gathers) instead of fp32 + a cast
+# pass (-0.37 ms per 600-wide block; same bits)
+FUSE_BF16_DS = True
+
 # dropout after the sparse-input layer in the epilogue of X . W0 (geogcn_spmm_csr_hot_dropout_f32): one launch instead of
 # product + mask kernel + apply pass (-0.2 ms per TWUS step); same Philox bits, same arithmetic
 FUSE_DROPOUT = True

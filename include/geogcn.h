@@ -246,6 +246,12 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
                            float* dbS /* nullable: column sums of dS = grad of the conv bias */,
                            float* dbU /* nullable: column sums of dU = grad of the gate bias */,
                            void* ws, size_t ws_bytes, void* stream);
+/* the same with dS stored as bfloat16 (round to nearest even; ld_dS16 in elements, a multiple of 8, the whole pitch written,
+ * pads as zeros): in the bf16 configuration dS is only ever gathered by A^T . dS (geogcn_spmm_csr_bf16b), so the fp32 copy
+ * and the geogcn_cast_bf16_f32 pass over it are not needed.  dbS is still the column sum of the fp32 values.  F <= 1024.     */
+int geogcn_highway_bwd_bf16s_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
+                                 const float* H, int64_t ld, uint16_t* dS16, int64_t ld_dS16, float* dU, float* dHcarry,
+                                 float* dbS, float* dbU, void* ws, size_t ws_bytes, void* stream);
 /* workspace of the fused column sums (deterministic two-pass); 0 when they are not requested */
 size_t geogcn_highway_bwd_workspace_bytes(int64_t n, int32_t F);
 /* dS = G [* keep_mask * scale] * act'(Y) with act' expressed through the layer OUTPUT Y:

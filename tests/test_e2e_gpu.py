@@ -27,10 +27,10 @@ def cmu():
     return dict(A=A, X=X, Y=Y, tr=tr, dev=dev, te=te, C=C, hid=hid, params=params, mask=mask)
 
 
-def _clf(c, p=0.5, reg=0.0, highway=True, hid=None, params=None, hip_graph=None):
+def _clf(c, p=0.5, reg=0.0, highway=True, hid=None, params=None, hip_graph=None, **kw):
     from geographconv_amd.gcnmodel import GraphConv
     from geographconv_amd.nn import layers as L
-    clf = GraphConv(c['X'].shape[1], c['C'], hid or c['hid'], reg, p, highway=highway, hip_graph=hip_graph)
+    clf = GraphConv(c['X'].shape[1], c['C'], hid or c['hid'], reg, p, highway=highway, hip_graph=hip_graph, **kw)
     clf.build_model(c['A'], seed=77)
     L.set_all_param_values(clf.l_out, params or c['params'])
     return clf
@@ -422,6 +422,27 @@ def test_dropout_in_the_first_layers_epilogue_equals_the_separate_kernels(cmu, m
         outs.append(([float(v) for v in out[:4]], np.asarray(out[4]).copy(), clf.get_grads()))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+
+
+def test_bf16_configuration_branch_gradient_stored_as_bf16(cmu, monkeypatch):
+    """tuning.FUSE_BF16_DS: in the bf16 configuration highway_bwd writes the convolution branch's gradient as bf16 (what
+    A^T . dS gathers) instead of fp32 + a cast pass: three training steps are bitwise the run with the separate cast."""
+    from geographconv_amd import tuning
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tuning, 'FUSE_BF16_DS', fused)
+        clf = _clf(c, gemm_precision='bf16')
+        clf.inject_dropout_mask(c['mask'])
+        hist = []
+        for step in range(3):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+        runs.append((hist, np.asarray(out[4]).copy(), clf.get_grads(), L.get_all_param_values(clf.l_out)))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    assert all(np.array_equal(a, b) for a, b in zip(runs[0][3], runs[1][3]))
 
 
 def test_compact_cross_entropy_gradient_equals_the_scattered_one(cmu, monkeypatch):

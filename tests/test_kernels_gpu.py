@@ -719,6 +719,15 @@ def test_highway_and_tanh_kernels(dev, n, F):
     bS2 = torch.zeros_like(bS)
     ops.highway_bwd(d(G), d(T), d(Hc), d(H), dbS=bS2, dbU=torch.zeros_like(bU))
     assert torch.equal(bS, bS2)
+    # dS stored as bf16 (bf16 configuration): the bits of cast_bf16 over the fp32 dS, whole pitch written, everything else as is
+    for kw in (dict(), dict(dbS=torch.zeros_like(bS), dbU=torch.zeros_like(bU))):
+        h = ops.HMat(n, F, dev)
+        h.t.fill_(7.0)
+        dSh, dUh, dHh = ops.highway_bwd(d(G), d(T), d(Hc), d(H), dS=h, dS_bf16=True, **kw)
+        assert dSh is h and torch.equal(h.t, ops.cast_bf16(dS).t)
+        assert torch.equal(dUh.t, dU.t) and torch.equal(dHh.t, dHc.t)
+        if kw:
+            assert torch.equal(kw['dbS'], bS) and torch.equal(kw['dbU'], bU)
     # tanh backward, with and without the dropout mask folded in
     got = ops.tanh_bwd(d(G), d(Hc)).numpy()
     assert np.allclose(got, G * (1 - Hc * Hc), rtol=1e-5, atol=1e-7)
