@@ -879,13 +879,18 @@ class HotCSR:
         self.hot_rows = torch.from_numpy(hot).to(dev)
 
 
-def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE):
-    """out = act(A . B + bias), hot rows of B from LDS (geogcn_spmm_csr_hot_f32)."""
+def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, col0=0, F=None):
+    """out = act(A . B + bias), hot rows of B from LDS (geogcn_spmm_csr_hot_f32).  `col0`, `F`: only the column slab
+    [col0, col0 + F) of B / bias / out (col0 a multiple of 4) -- a layer wider than the kernel's 384 columns runs as slabs."""
     if B.n != A.shape[1]:
         raise ValueError("spmm_hot: A is %s but B has %d rows" % (A.shape, B.n))
     out = DMat.empty(A.shape[0], B.F, B.device) if out is None else out
-    check(_ffi.lib().geogcn_spmm_csr_hot_f32(A.shape[0], _p(A.rowptr), _p(A.rowsplit), _p(A.colidx), _p(A.val), _p(B.t), B.ld,
-                                             _p(A.hot_rows), A.n_hot, _p(out.t), out.ld, B.F, _p(bias), act, _stream()),
+    F = B.F - col0 if F is None else int(F)
+    if col0 % 4 or col0 < 0 or col0 + F > B.F:
+        raise ValueError("spmm_hot: bad column slab [%d, %d) of %d" % (col0, col0 + F, B.F))
+    at = lambda t: None if t is None else C.c_void_p(t.data_ptr() + 4 * col0)
+    check(_ffi.lib().geogcn_spmm_csr_hot_f32(A.shape[0], _p(A.rowptr), _p(A.rowsplit), _p(A.colidx), _p(A.val), at(B.t), B.ld,
+                                             _p(A.hot_rows), A.n_hot, at(out.t), out.ld, F, at(bias), act, _stream()),
           'spmm_csr_hot_f32')
     return out
 
@@ -897,12 +902,18 @@ def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = Non
     (Measured and removed: the dense head panel on the MFMA pipe + CSR tail continuing the rows -- 1.69 ms against
     1.32 -- and its column-slab variant)"""
     if isinstance(x.fwd, CSR) and x.fwd.nnz >= tuning.HOT_MIN_NNZ and not x.symmetric:
-        cap = int(_ffi.lib().geogcn_spmm_hot_capacity(W.F))
+        # a layer wider than the LDS kernel takes (384 columns) runs as two column slabs of it when they are float4-aligned
+        # (600 wide: 2 x 1.33 ms against 3.93 ms for the plain row gather)
+        slabs = 1 if int(_ffi.lib().geogcn_spmm_hot_capacity(W.F)) > 0 else (2 if W.F % 8 == 0 else 0)
+        cap = int(_ffi.lib().geogcn_spmm_hot_capacity(W.F // slabs)) if slabs else 0
         if cap > 0:
             hot = x._hot.get(cap)
             if hot is None:
                 hot = x._hot[cap] = HotCSR(x.fwd, x.fwd.val.cpu().numpy(), cap)
-            return spmm_hot(hot, W, out=out, bias=bias, act=act)
+            out = DMat.empty(hot.shape[0], W.F, W.device) if out is None else out
+            for s in range(slabs):
+                spmm_hot(hot, W, out=out, bias=bias, act=act, col0=s * (W.F // slabs), F=W.F // slabs)
+            return out
     return spmm(x.fwd, W, out=out, bias=bias, act=act)
 
 

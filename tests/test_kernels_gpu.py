@@ -608,6 +608,33 @@ def test_spmm_hot_rows_in_lds(dev, n_docs, n_words, mean, F, n_hot):
     assert int(_ffi.lib().geogcn_spmm_hot_capacity(2000)) == 0
 
 
+@pytest.mark.parametrize("F", [600, 768, 392])
+def test_spmm_x_wide_layer_runs_as_two_column_slabs_of_the_lds_kernel(dev, F, monkeypatch):
+    """A first layer wider than the LDS kernel's 384 columns (configs[4]: 600): ops.spmm_x runs the kernel on two column
+    slabs of W0 / bias / output -- each slab bitwise what the kernel gives on a copy of those columns -- instead of falling
+    back to the plain row gather."""
+    from geographconv_amd import ops, tuning
+    monkeypatch.setattr(tuning, 'HOT_MIN_NNZ', 0)
+    X = sps.csr_matrix(_bow(6000, 900, 30, seed=3))
+    x = ops.SparseOperand.from_scipy(X, dev)
+    W = _rand((900, F), 4, 0.1)
+    b = _rand((F,), 5, 0.1)
+    dWm = ops.DMat.from_numpy(W, dev)
+    db = torch.from_numpy(b).to(dev)
+    got = ops.spmm_x(x, dWm, bias=db, act=ops.ACT_TANH)
+    ref = np.tanh(X.astype(np.float64) @ W.astype(np.float64) + b)
+    tol = 3e-6 * np.asarray(abs(X).astype(np.float64) @ np.abs(W)) + 1e-6
+    assert np.all(np.abs(got.numpy() - ref) <= tol)
+    half = F // 2
+    (cap, hot), = x._hot.items()                                   # ONE reordered copy of X, sized for a slab
+    assert hot.n_hot > 0 and hot.n_hot <= cap
+    for s in range(2):
+        Ws = ops.DMat.from_numpy(W[:, s * half:(s + 1) * half], dev)
+        bs = torch.from_numpy(b[s * half:(s + 1) * half].copy()).to(dev)
+        one = ops.spmm_hot(hot, Ws, bias=bs, act=ops.ACT_TANH)
+        assert torch.equal(one.t[:, :half], got.t[:, s * half:(s + 1) * half])
+
+
 @pytest.mark.parametrize("n_docs,n_words,mean,F,p", [(20000, 1500, 30, 300, 0.5), (7001, 700, 25, 64, 0.2), (3000, 300, 12, 128, 0.8)])
 def test_spmm_hot_with_the_dropout_in_its_epilogue(dev, n_docs, n_words, mean, F, p, monkeypatch):
     """geogcn_spmm_csr_hot_dropout_f32 == geogcn_spmm_csr_hot_f32 + geogcn_dropout_mask_philox + geogcn_dropout_apply_f32,
