@@ -295,6 +295,132 @@ template <int KP, int BM, int WCT, int DEPTH, int PROBE = 0>
 static void run_pipe(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC,
                      int64_t ldc, const std::vector<float>& hA, const std::vector<unsigned short>& hB, int grid);
 
+// Variant: the first half of the NEXT tile's rows is requested after the last k-step of this tile, BEFORE its epilogue's stores
+// (gfx9 counts loads and stores in one vmcnt: a load issued behind 80 stores waits for all of them), and the next column pass's
+// first B fragments likewise before the stores of the pass that precedes it.
+template <int KP, int BM, int WCT, int DEPTH>
+__global__ __launch_bounds__(256, 2) void astat_early_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+                                                             const unsigned short* __restrict__ Bp, int N, float* __restrict__ C,
+                                                             int64_t ldc, int n_mt) {
+    constexpr int PITCH = KP * 2 + 16;
+    constexpr int F4R = KP / 4;
+    constexpr int ITERS = BM * F4R / 256;
+    constexpr int IPC = ITERS / 2;
+    constexpr int MR = BM / 16;
+    constexpr int NK = KP / 32;
+    constexpr int D1 = DEPTH + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char As[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int K4 = (K + 3) & ~3;
+    const uint32_t ld4 = (uint32_t)lda * 4u;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, 640 * KP * 2, 0x00020000);
+    auto tile_rsrc = [&](int mt) {
+        const int64_t m0 = (int64_t)mt * BM;
+        const int64_t rows_left = mt < n_mt ? M - m0 : 0;
+        const uint64_t base = reinterpret_cast<uint64_t>(A + (mt < n_mt ? m0 : 0) * lda);
+        const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+        const int64_t nbytes = (rows_left < BM ? rows_left : BM) * lda * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000);
+    };
+    auto load_chunk = [&](float4 (&v)[IPC], __amdgpu_buffer_rsrc_t rs, int ch) {
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int i = 0; i < IPC; ++i) {
+            const int idx = tt + 256 * (ch * IPC + i);
+            const int r = idx / F4R, c = idx - r * F4R;
+            const uint32_t off = c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : 0x80000000u;
+            const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+            v[i] = make_float4(t.x, t.y, t.z, t.w);
+        }
+    };
+    auto store_chunk = [&](const float4 (&v)[IPC], int ch) {
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int i = 0; i < IPC; ++i) {
+            const int idx = tt + 256 * (ch * IPC + i);
+            const int r = idx / F4R, c = idx - r * F4R;
+            uint2 w;
+            w.x = bf16_pack(v[i].x, v[i].y);
+            w.y = bf16_pack(v[i].z, v[i].w);
+            *reinterpret_cast<uint2*>(As + r * PITCH + c * 8) = w;
+        }
+    };
+    float4 v[IPC];
+    load_chunk(v, tile_rsrc(blockIdx.x), 0);
+    for (int mt = blockIdx.x; mt < n_mt; mt += gridDim.x) {
+        const int64_t m0 = (int64_t)mt * BM;
+        // chunk 0 of this tile is in flight (or has arrived) in v
+        store_chunk(v, 0);
+        load_chunk(v, tile_rsrc(mt), 1);
+        store_chunk(v, 1);
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(mt + gridDim.x);
+        bf16x8 ring[D1][WCT];
+        auto bload = [&](bf16x8 (&b)[WCT], int tile0, int kt) {
+            const int kk = kt < NK ? kt : NK - 1;
+#pragma unroll
+            for (int j = 0; j < WCT; ++j)
+                b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) bload(ring[d], (wid * 2) * WCT, d);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int tile0 = (wid * 2 + ps) * WCT;
+            const int ncol0 = tile0 * 16;
+            f32x4 acc[MR][WCT];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto kstep = [&](const bf16x8 (&b)[WCT], int kt) {
+                bf16x8 af[MR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (i * 16 + li) * PITCH + kt * 64 + lg * 16);
+#pragma unroll
+                for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], af[i], acc[i][j], 0, 0, 0);
+            };
+#pragma unroll 1
+            for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                for (int u = 0; u < D1; ++u) {
+                    if (k0 + u + DEPTH < NK) bload(ring[(u + DEPTH) % D1], tile0, k0 + u + DEPTH);
+                    if (k0 + u < NK) kstep(ring[u], k0 + u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // what the NEXT phase needs first is requested before this pass's stores
+            constexpr int kLast = (NK - 1) % D1;      // (ring slot of the last k-step: the prefetch below restarts at slot 0 ... DEPTH-1)
+            (void)kLast;
+            if (ps == 0) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) bload(ring[d], tile0 + WCT, d);
+            } else {
+                load_chunk(v, nrs, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int64_t row = m0 + i * 16 + li;
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) {
+                    const int col0 = ncol0 + j * 16 + lg * 4;
+                    if (row < M && col0 < N)
+                        *reinterpret_cast<float4*>(C + row * ldc + col0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+}
+
 static unsigned short rne(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -386,6 +512,44 @@ static void run_pipe(const char* name, const float* dA, int64_t lda, int64_t M, 
            bytes / ms / 1e9, worst);
 }
 
+template <int KP, int BM, int WCT, int DEPTH>
+static void run_early(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC,
+                      int64_t ldc, const std::vector<float>& hA, const std::vector<unsigned short>& hB, int grid) {
+    constexpr int PITCH = KP * 2 + 16;
+    const int n_mt = (int)((M + BM - 1) / BM);
+    const size_t lds = (size_t)BM * PITCH;
+    auto kern = astat_early_kernel<KP, BM, WCT, DEPTH>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(dC, 0, (size_t)M * ldc * 4));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    double worst = 0;
+    const int64_t rows[] = {0, 1, 63, 64, 12345, M - 65, M - 1};
+    std::vector<float> hc(N);
+    for (int64_t r : rows) {
+        CK(hipMemcpy(hc.data(), dC + r * ldc, (size_t)N * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            double sacc = 0;
+            for (int k = 0; k < K; ++k) sacc += (double)bf(rne(hA[r * lda + k])) * (double)bf(hB[(size_t)n * KP + k]);
+            worst = fmax(worst, fabs(sacc - hc[n]) / (1e-3 + fabs(sacc)));
+        }
+    }
+    const double flops = 2.0 * M * N * K, bytes = 4.0 * M * (K + N);
+    printf("%-34s grid %4d  lds %6zu B  %.3f ms  %.0f TF  %.2f TB/s of A + C   max rel err %.2e\n", name, grid, lds, ms, flops / ms / 1e9,
+           bytes / ms / 1e9, worst);
+}
+
 int main() {
     const int64_t M = 440000;
     const int K = 600, N = 600, KP = 608, NP = 640;
@@ -419,12 +583,9 @@ int main() {
     CK(hipMemcpy(dF, hF.data(), hF.size() * 2, hipMemcpyHostToDevice));
     for (int grid : {512}) {
         run<608, 64, 5, 2, 2, 1>("BM 64, 2x5, B fragment order, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
-        run<608, 32, 5, 2, 1, 1>("BM 32 (4 blocks per CU), B 1 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 1024);
-        run<608, 32, 5, 2, 2, 1>("BM 32 (4 blocks per CU), B 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 1024);
-        run_pipe<608, 64, 5, 1, 0>("pipelined A, B 1 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
-        run_pipe<608, 64, 5, 2, 0>("pipelined A, B 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
-        run_pipe<608, 64, 5, 1, 4>("  pipelined, no C stores", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
-        run_pipe<608, 64, 5, 1, 2>("  pipelined, no A loads", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
+        run_early<608, 64, 5, 2>("requests before the stores, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
+        run_early<608, 64, 5, 3>("requests before the stores, 3 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
+        run<608, 64, 5, 2, 2, 1>("BM 64, 2x5, B fragment order, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
     }
     {
         int nb = 0;
