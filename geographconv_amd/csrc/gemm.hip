@@ -457,6 +457,183 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
     }
 }
 
+// ---- the highway block's fused products on WHOLE ROWS of A (round 3) ---------------------------------------------------
+// For N_nodes x 300 x [300 | 300] (the dual launch) and dZ.Wh^T + dU.Wt^T (the k-concatenated one) the operand that matters is
+// skinny: K = 300.  A block takes 64 whole rows of A -- one contiguous 77 KB read into LDS (64 x 308 floats: two blocks per CU) --
+// and no barrier follows until the tile is done: every wave multiplies all 64 rows by its own 80 columns per pass (5 column
+// tiles, 80 accumulator registers), B fragments coming straight from the L2-resident weights, which a prep kernel lays out in
+// FRAGMENT order ([column tile][16-k step][lane][4 floats]: a wave's fragment load is 1 KB of consecutive bytes), two steps
+// ahead.  The instruction stream of a step is 80 MFMAs, 4 ds_read_b128 and 5 buffer loads -- the staged kernel above spends a
+// barrier, two LDS images and 18 fragment reads on 160.  Same MFMA and the same k grouping as gemm_kernel (lane (li, lg) holds
+// k = 16 s + 4 lg + t for the t-th MFMA of step s), one accumulator over both reductions of the k-concatenated form: results
+// are bit-identical.  tools/micro/f32_astat.hip: the dual launch 1.41 ms = 112 TF against 1.65 ms = 96 TF.
+__global__ __launch_bounds__(TPB) void prep_b_frag_f32_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int NK,
+                                                              int n_tiles, int b_is_nk, float* __restrict__ out) {
+    const int64_t total = (int64_t)n_tiles * NK * 256;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int el = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        const int64_t f = e >> 8;
+        const int kt = (int)(f % NK), nt = (int)(f / NK);
+        const int n = nt * 16 + (lane & 15), k = kt * 16 + (lane >> 4) * 4 + el;
+        out[e] = (k < K && n < N) ? (b_is_nk ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]) : 0.f;
+    }
+}
+
+constexpr int kRowsBM = 64, kRowsWCT = 5, kRowsDepth = 2;
+
+struct RowsArgs {
+    int64_t M;
+    int n_mt;
+    int n_kseg;                         // 1, or 2 A operands reduced into one accumulator (then ONE column pass)
+    const float* A[2]; int64_t lda[2]; int K[2];
+    const float* Bf[2];                 // fragment-ordered weights of slot q = N segment | K segment
+    int n_nseg; int passes[2];          // column passes of each N segment (4 waves x 5 tiles x 16 columns per pass)
+    float* C[2]; int64_t ldc[2]; const float* bias[2]; int64_t N[2]; int act_on[2];
+    int accumulate;
+};
+
+template <int KP, int ACT>
+__global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
+    constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
+    constexpr int PITCH = KP + 4;               // floats per LDS row: an odd number of float4s -> conflict-free ds_read_b128
+    constexpr int F4R = KP / 4;
+    constexpr int ITERS = BM * F4R / TPB;
+    constexpr int MR = BM / 16, NK = KP / 16;
+    static_assert(BM * F4R % TPB == 0, "a tile must divide over the block");
+    extern __shared__ __attribute__((aligned(16))) float As[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int P = a.n_nseg == 2 ? a.passes[0] + a.passes[1] : a.passes[0];
+    for (int mt = blockIdx.x; mt < a.n_mt; mt += gridDim.x) {
+        const int64_t m0 = (int64_t)mt * BM;
+        f32x4 acc[MR][WCT];
+#pragma unroll 1
+        for (int ks = 0; ks < a.n_kseg; ++ks) {
+            if (ks) __syncthreads();            // everybody done with the first operand's rows
+            {
+                // (the offsets are the same for every tile: left alone, hipcc computes them once and keeps ~40 registers alive
+                //  across the MFMA loop -- an opaque copy of the thread index makes them per-tile work)
+                int tt = tid;
+                asm volatile("" : "+v"(tt));
+                const float* Ap = ks ? a.A[1] : a.A[0];
+                const int64_t lda = ks ? a.lda[1] : a.lda[0];
+                const int K4 = ((ks ? a.K[1] : a.K[0]) + 3) & ~3;       // pad columns up to roundup4(K) are zero; beyond: not read
+                const __amdgpu_buffer_rsrc_t rs = tile_rsrc(Ap + m0 * lda, std::min<int64_t>(BM, a.M - m0) * lda * 4);
+                const uint32_t ld4 = (uint32_t)lda * 4u;
+                float4 v[ITERS];
+#pragma unroll
+                for (int i = 0; i < ITERS; ++i) {
+                    const int idx = tt + TPB * i;
+                    const int r = idx / F4R, c = idx - r * F4R;
+                    v[i] = buffer_load4(rs, c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : kOobOffset);
+                }
+#pragma unroll
+                for (int i = 0; i < ITERS; ++i) {
+                    const int idx = tt + TPB * i;
+                    const int r = idx / F4R, c = idx - r * F4R;
+                    *reinterpret_cast<float4*>(As + r * PITCH + c * 4) = v[i];
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int ps = 0; ps < P; ++ps) {
+                const int seg = ps >= a.passes[0] ? 1 : 0;                  // wave-uniform
+                const int lps = seg ? ps - a.passes[0] : ps;
+                const int tile0 = (wid * (seg ? a.passes[1] : a.passes[0]) + lps) * WCT;
+                const int slot = seg | ks;
+                const int n_tiles = 4 * (seg ? a.passes[1] : a.passes[0]) * WCT;
+                const __amdgpu_buffer_rsrc_t brs = tile_rsrc(slot ? a.Bf[1] : a.Bf[0], (int64_t)n_tiles * NK * 1024);
+                if (ks == 0) {
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                // B fragments DEPTH steps ahead in a ring of DEPTH + 1 register sets; the k loop stays ROLLED (DEPTH + 1 steps
+                // per trip, ring slots are compile-time constants inside a trip) and the scheduler is fenced per step; requests
+                // past the last step re-read the last one (no branch around a load)
+                auto bload = [&](f32x4 (&b)[WCT], int kt) {
+                    const int kk = kt < NK ? kt : NK - 1;
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j)
+                        b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
+                };
+                auto kstep = [&](const f32x4 (&b)[WCT], int kt) {
+                    f32x4 af[MR];
+#pragma unroll
+                    for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + (i * 16 + li) * PITCH + kt * 16 + lg * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < MR; ++i)
+#pragma unroll
+                            for (int j = 0; j < WCT; ++j)
+                                // operands swapped (as in gemm_kernel): a lane owns 4 consecutive columns of one row of C
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][t], af[i][t], acc[i][j], 0, 0, 0);
+                };
+                f32x4 ring[D1][WCT];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+#pragma unroll 1
+                for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                    for (int u = 0; u < D1; ++u) {
+                        bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH);
+                        if (k0 + u < NK) kstep(ring[u], k0 + u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (ks != a.n_kseg - 1) continue;
+                // epilogue: the arithmetic of gemm_kernel, in its order
+                float* Cout = seg ? a.C[1] : a.C[0];
+                const int64_t ldc = seg ? a.ldc[1] : a.ldc[0];
+                const float* bias = seg ? a.bias[1] : a.bias[0];
+                const int64_t Nseg = seg ? a.N[1] : a.N[0];
+                const bool act_on = (seg ? a.act_on[1] : a.act_on[0]) != 0;
+                const int64_t ncol0 = (int64_t)tile0 * 16;
+                float bcol[WCT][4];
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) {
+                    const int64_t col0 = ncol0 + j * 16 + lg * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bcol[j][r] = (bias && col0 + r < Nseg) ? bias[col0 + r] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    const int64_t row = m0 + i * 16 + li;
+                    float* crow = Cout + row * ldc;
+                    const bool row_ok = row < a.M;
+                    float4 oldv[WCT];
+                    if (a.accumulate) {
+#pragma unroll
+                        for (int j = 0; j < WCT; ++j) {
+                            const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                            oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (row_ok && col0 < Nseg) oldv[j] = *reinterpret_cast<const float4*>(crow + col0);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) {
+                        const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                        float x[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            x[r] = acc[i][j][r] + bcol[j][r];
+                            if (ACT == GEOGCN_ACT_NONE || act_on) x[r] = apply_act<ACT>(x[r]);
+                        }
+                        if (a.accumulate) { x[0] += oldv[j].x; x[1] += oldv[j].y; x[2] += oldv[j].z; x[3] += oldv[j].w; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col0 + r >= Nseg) x[r] = 0.f;
+                        if (row_ok && col0 < Nseg) *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();          // everybody done reading this tile's rows
+    }
+}
+
 // split-K combine: C = act(sum_z slab[z] + bias) [+ C]
 template <int ACT>
 __global__ __launch_bounds__(TPB) void splitk_reduce_kernel(int64_t M, int64_t N, int nsplit,
@@ -682,7 +859,89 @@ inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int 
     }
 }
 
+// ---- whole-rows kernel: which calls take it, its workspace, its launch ---------------------------------------------------------
+// Only the fused launches (two N segments or two K segments): a single 300-wide product runs as fast on the staged kernel
+// (0.74 against 0.75 ms).  Every segment must fill its column passes (a pass is 320 columns: 300 -> 320 is the padding the
+// staged kernel has as well; 256 would multiply 64 columns of zeros: at most an eighth may be padding) and K must pad to an instantiated depth.
+inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
+inline int rows_kp(const GemmCall& c, bool transA) {
+#ifdef GEOGCN_F32_NO_ROWS_KERNEL          // A/B build only (GEOGCN_BUILD_DEFINES): every call on the staged kernel
+    return 0;
+#endif
+    if (transA || c.panel_w || (c.n_nseg == 1 && c.n_kseg == 1) || c.M < 32768) return 0;
+    const int64_t kp = cdiv(c.K[0], 16) * 16;
+    if (kp != 304 && kp != 256) return 0;
+    if (c.n_kseg == 2 && (cdiv(c.K[1], 16) * 16 != kp || c.N[0] > 320)) return 0;      // one accumulator: one column pass
+    for (int q = 0; q < c.n_nseg; ++q) {
+        if (c.N[q] > 640) return 0;
+        const int64_t cols = (int64_t)rows_passes(c.N[q]) * 320;
+        if ((cols - c.N[q]) * 8 > cols) return 0;              // at most an eighth of a pass multiplies zero columns
+    }
+    return (int)kp;
+}
+inline size_t rows_slot_bytes(int64_t N, int kp) { return (size_t)4 * rows_passes(N) * kRowsWCT * (kp / 16) * 1024; }
+inline size_t rows_ws_bytes(const GemmCall& c, int kp) {
+    return c.n_kseg == 2 ? 2 * rows_slot_bytes(c.N[0], kp) : rows_slot_bytes(c.N[0], kp) + (c.n_nseg == 2 ? rows_slot_bytes(c.N[1], kp) : 0);
+}
+
+template <int KP>
+int launch_rows(const RowsArgs& a, int act, hipStream_t st) {
+    constexpr int lds = kRowsBM * (KP + 4) * (int)sizeof(float);
+    const int G = (int)std::min<int64_t>((int64_t)kNumCU * 2, a.n_mt);
+#define GEOGCN_R(ACT)                                                                                            \
+    do {                                                                                                         \
+        auto kern = gemm_rows_kernel<KP, ACT>;                                                                   \
+        static bool attr_done = false;                                                                           \
+        if (!attr_done) {                                                                                        \
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);                                      \
+        GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");                                                                 \
+    } while (0)
+    if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
+    else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_R(GEOGCN_ACT_SIGMOID);
+    else GEOGCN_R(GEOGCN_ACT_NONE);
+#undef GEOGCN_R
+    return 0;
+}
+
+int run_rows(int kp, bool transB, const GemmCall& c, void* ws, hipStream_t st) {
+    RowsArgs a{};
+    a.M = c.M;
+    a.n_mt = (int)cdiv(c.M, kRowsBM);
+    a.n_kseg = c.n_kseg;
+    a.n_nseg = c.n_nseg;
+    a.accumulate = c.accumulate;
+    float* w = (float*)ws;
+    const int nks = kp / 16;
+    for (int q = 0; q < 2; ++q) {
+        a.A[q] = c.A[q]; a.lda[q] = c.lda[q]; a.K[q] = (int)c.K[q];
+        a.C[q] = c.C[q]; a.ldc[q] = c.ldc[q]; a.bias[q] = c.bias[q]; a.N[q] = c.N[q];
+        a.act_on[q] = c.act[q] != GEOGCN_ACT_NONE;
+        a.passes[q] = c.N[q] > 0 ? rows_passes(c.N[q]) : 0;
+    }
+    // slot q = N segment | K segment: its weights in fragment order
+    const int n_slots = (c.n_nseg == 2 || c.n_kseg == 2) ? 2 : 1;
+    for (int q = 0; q < n_slots; ++q) {
+        const int64_t N = c.n_kseg == 2 ? c.N[0] : c.N[q];
+        const int64_t K = c.n_kseg == 2 ? c.K[q] : c.K[0];
+        const int n_tiles = 4 * rows_passes(N) * kRowsWCT;
+        const unsigned grid = (unsigned)std::min<int64_t>(cdiv((int64_t)n_tiles * nks * 256, TPB), 1024);
+        hipLaunchKernelGGL(prep_b_frag_f32_kernel, dim3(grid), dim3(TPB), 0, st, c.B[q], c.ldb[q], (int)K, (int)N, nks, n_tiles,
+                           transB ? 1 : 0, w);
+        GEOGCN_LAUNCH_CHECK("prep_b_frag_f32_kernel");
+        a.Bf[q] = w;
+        w += (size_t)n_tiles * nks * 256;
+    }
+    const int act = c.act[0] != GEOGCN_ACT_NONE ? c.act[0] : c.act[1];
+    if (kp == 304) return launch_rows<304>(a, act, st);
+    return launch_rows<256>(a, act, st);
+}
+
 int run_call(bool transA, bool transB, const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (const int kp = rows_kp(c, transA); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp))
+        return run_rows(kp, transB, c, ws, st);          // (too small a workspace -- an older caller: the staged kernel)
     int bm, bn;
     choose_tiles(transA, transB, c.M, c.maxN(), c.n_nseg, bm, bn);
     if (transA) return dispatch_tiles<true, false>(bm, bn, c, ws, ws_bytes, st);
@@ -728,8 +987,23 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
 }
 
 size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K) {
-    if (!transA || M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0) return 0;
+    if (M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0) return 0;
+    if (!transA) {          // the whole-rows kernel's fragment-ordered weights (0: the call runs on the staged kernel)
+        GemmCall c{};
+        c.M = M; c.n_nseg = 2; c.n_kseg = 1; c.N[0] = N0; c.N[1] = N1; c.K[0] = K;
+        const int kp = rows_kp(c, false);
+        return kp ? rows_ws_bytes(c, kp) : 0;
+    }
     return transA_ws_bytes(M, std::max(N0, N1), 2, K);
+}
+
+size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1) {
+    (void)transB;
+    if (M <= 0 || N <= 0 || K0 <= 0 || K1 <= 0) return 0;
+    GemmCall c{};
+    c.M = M; c.n_nseg = 1; c.n_kseg = 2; c.N[0] = N; c.K[0] = K0; c.K[1] = K1;
+    const int kp = rows_kp(c, false);
+    return kp ? rows_ws_bytes(c, kp) : 0;
 }
 
 static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
@@ -853,7 +1127,7 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
 // C = A0.op(B0) + A1.op(B1) [+ C]: one accumulator over both reductions, exact fp32
 int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                         float* C, int64_t ldc, int32_t accumulate, void* stream) {
+                         float* C, int64_t ldc, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "gemm_kcat_f32";
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (M == 0 || N == 0) return 0;
@@ -869,7 +1143,7 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
     c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
     c.C[0] = C; c.ldc[0] = ldc;
     c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate;
-    return run_call(false, transB != 0, c, nullptr, 0, (hipStream_t)stream);
+    return run_call(false, transB != 0, c, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

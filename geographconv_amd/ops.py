@@ -444,8 +444,13 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
         if accumulate:
             raise ValueError("gemm_kcat: accumulate needs an existing output")
         out = DMat.empty(A0.n, N, A0.device)
-    check(_ffi.lib().geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
-                                          _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _stream()), 'gemm_kcat_f32')
+    lib = _ffi.lib()
+    ws = _gemm_ws.get(A0.device)
+    if ws is None:
+        ws = _gemm_ws[A0.device] = Workspace(A0.device)
+    w = ws.get(lib.geogcn_gemm_kcat_workspace_bytes(int(transB), A0.n, N, A0.F, A1.F))
+    check(lib.geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
+                                   _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _p(w), w.numel(), _stream()), 'gemm_kcat_f32')
     return out
 
 

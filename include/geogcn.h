@@ -217,7 +217,10 @@ int geogcn_gemm_panels_f32(int32_t transB, int64_t M, int64_t N, int64_t K, cons
  * transA = 0: the forward pair Z = H.Wh (raw, into the SpMM operand's pitch) and T = sigmoid(H.Wt + bt) -- every A
  * tile is multiplied by both weights inside one XCD (second read from L2).  transA = 1: dWh = H^T.dZ and
  * dWt = H^T.dU, one pass over H (split-K into `ws`, geogcn_gemm_dual_workspace_bytes; slabs combined in fixed order).
- * B0 is K x N0 (ldb0), B1 is K x N1 (ldb1).  If both act0 and act1 are non-linear they must be equal.          */
+ * B0 is K x N0 (ldb0), B1 is K x N1 (ldb1).  If both act0 and act1 are non-linear they must be equal.
+ * transA = 0 with a workspace of geogcn_gemm_dual_workspace_bytes: shapes like the GCN's (M >= 32,768 rows, K padding to 256 or
+ * 304, N0 and N1 filling 320-column passes) run on the whole-rows kernel -- 64 rows of A per block read once, the weights
+ * re-laid in fragment order into `ws` -- with bit-identical results; without it (ws too small / NULL) on the staged kernel.  */
 size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K);
 int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda,
                          const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
@@ -226,10 +229,12 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
 /* Two products into one accumulator (what autodiff derives for the input of the highway block: dH = dZ.Wh^T + dU.Wt^T
  * [+ the carry gradient already in C]):  C[M x N] = A0 . op(B0) + A1 . op(B1) [+ C].  A0 is M x K0, A1 is M x K1;
  * transB = 1: B0 is N x K0, B1 is N x K1 (the weights as stored); transB = 0: B0 is K0 x N, B1 is K1 x N.
- * One pass over C instead of two accumulating calls.                                                        */
+ * One pass over C instead of two accumulating calls.  `ws` (geogcn_gemm_kcat_workspace_bytes; may be NULL / 0): as for the
+ * dual launch -- with it, eligible shapes run on the whole-rows kernel (same accumulation order, bit-identical).      */
+size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1);
 int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                         float* C, int64_t ldc, int32_t accumulate, void* stream);
+                         float* C, int64_t ldc, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */

@@ -451,6 +451,52 @@ def test_gemm_dual_transposed_equals_two_calls_bitwise(dev, R, M, N0, N1):
     assert torch.all(o0.t[:, N0:] == 0) and torch.all(o1.t[:, N1:] == 0)
 
 
+@pytest.mark.parametrize("M,K,N0,N1", [(40000, 300, 300, 300), (33001, 300, 300, 600), (32768, 256, 300, 300), (50001, 290, 620, 289)])
+def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
+    """The fused highway launches on gemm_rows_kernel (64 whole rows of A per block, weights in fragment order; taken when the
+    caller supplies the workspace): the dual launch and the k-concatenated one are BIT-identical to the staged kernel -- the
+    same calls with a NULL workspace -- through bias, sigmoid, accumulate, both weight layouts, gather-pitch outputs and a row
+    count that is not a multiple of 64."""
+    import ctypes as C
+    from geographconv_amd import _ffi, ops
+    lib = _ffi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    A = ops.DMat.from_numpy(_rand((M, K), 1), dev)
+    W0, W1 = ops.DMat.from_numpy(_rand((K, N0), 2, 0.1), dev), ops.DMat.from_numpy(_rand((K, N1), 3, 0.1), dev)
+    b1 = torch.from_numpy(_rand((ops.pad4(N1),), 4)).to(dev)
+    assert lib.geogcn_gemm_dual_workspace_bytes(0, M, N0, N1, K) > 0            # this shape is taken by the rows kernel
+    got0 = ops.DMat.empty(M, N0, dev, ld=ops.gather_ld(N0))
+    got0.t.zero_()
+    got0, got1 = ops.gemm_dual(A, W0, W1, out0=got0, bias1=b1, act1=ops.ACT_SIGMOID)
+    ref0 = ops.DMat.empty(M, N0, dev, ld=ops.gather_ld(N0))
+    ref0.t.zero_()
+    ref1 = ops.DMat(M, N1, dev)
+    _ffi.check(lib.geogcn_gemm_dual_f32(0, M, N0, N1, K, ops._p(A.t), A.ld, ops._p(W0.t), W0.ld, ops._p(W1.t), W1.ld,
+                                        ops._p(ref0.t), ref0.ld, ops._p(ref1.t), ref1.ld, None, 0, ops._p(b1), ops.ACT_SIGMOID,
+                                        None, 0, st), 'dual, staged')
+    assert torch.equal(got0.t, ref0.t) and torch.equal(got1.t, ref1.t)
+    assert torch.all(got1.t[:, N1:] == 0)
+    # and against the fp64 product
+    ref = A.numpy().astype(np.float64) @ W0.numpy().astype(np.float64)
+    assert np.all(np.abs(got0.numpy() - ref) <= 2e-6 * (np.abs(A.numpy()) @ np.abs(W0.numpy())) + 1e-6)
+    # k-concatenated: dH = dZ . Wh^T + dU . Wt^T [+ carry], weights as stored (N x K) and transposed
+    if N0 <= 320:
+        G0, G1 = A, ops.DMat.from_numpy(_rand((M, K), 5), dev)
+        for transB in (True, False):
+            V0 = ops.DMat.from_numpy(_rand((N0, K) if transB else (K, N0), 6, 0.1), dev)
+            V1 = ops.DMat.from_numpy(_rand((N0, K) if transB else (K, N0), 7, 0.1), dev)
+            assert lib.geogcn_gemm_kcat_workspace_bytes(int(transB), M, N0, K, K) > 0
+            for acc in (False, True):
+                carry = _rand((M, N0), 8)
+                out = ops.DMat.from_numpy(carry, dev)
+                want = ops.DMat.from_numpy(carry, dev)
+                ops.gemm_kcat(G0, V0, G1, V1, out=out, transB=transB, accumulate=acc)
+                _ffi.check(lib.geogcn_gemm_kcat_f32(int(transB), M, N0, K, K, ops._p(G0.t), G0.ld, ops._p(V0.t), V0.ld, ops._p(G1.t),
+                                                    G1.ld, ops._p(V1.t), V1.ld, ops._p(want.t), want.ld, int(acc), None, 0, st),
+                           'kcat, staged')
+                assert torch.equal(out.t, want.t), (transB, acc)
+
+
 @pytest.mark.parametrize("M,N,K0,K1", [(1000, 300, 300, 300), (4100, 600, 600, 600), (777, 300, 129, 300), (333, 16, 40, 64),
                                       (70000, 300, 300, 300)])
 def test_gemm_kcat_two_products_one_accumulator(dev, M, N, K0, K1):

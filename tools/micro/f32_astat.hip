@@ -1,0 +1,201 @@
+// Micro-benchmark (NOT part of the product): the whole-rows ("A-stationary") kernel of tools/micro/bf16_astat.hip for the EXACT
+// fp32 contractions (v_mfma_f32_16x16x4_f32), C[M x N] = A[M x K] . W, M = 440,000, K = 300, N = 300 (one product) or 600 (the
+// highway block's dual launch).  64 whole rows of A per block in LDS (fp32: 64 x 308 floats = 79 KB, two blocks per CU), no
+// barrier inside a tile, B fragments in fragment order ([column tile][16-k step][lane][4 floats]) straight from L2.  Same MFMA and
+// the same k grouping as gemm.hip (lane (li, lg) holds k = 16 s + 4 lg + t for the t-th MFMA of a step): bit-identical results.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/f32_astat.hip -o tools/micro/bin/f32_astat && tools/micro/bin/f32_astat
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) {                                                \
+            printf("%s: %s\n", #x, hipGetErrorString(e_));                     \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+template <int KP, int BM, int WCT, int DEPTH, int PROBE = 0>
+__global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+                                                           const float* __restrict__ Bf, int N, float* __restrict__ C, int64_t ldc,
+                                                           int n_mt, int passes) {
+    constexpr int PITCH = KP + 4;               // floats per LDS row: 77 float4 -> odd -> conflict-free ds_read_b128
+    constexpr int F4R = KP / 4;
+    constexpr int ITERS = (BM * F4R + 255) / 256;
+    constexpr int MR = BM / 16, NK = KP / 16, D1 = DEPTH + 1;
+    extern __shared__ __attribute__((aligned(16))) float As[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int K4 = (K + 3) & ~3;
+    const uint32_t ld4 = (uint32_t)lda * 4u;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bf), 0, 4 * passes * WCT * NK * 1024, 0x00020000);
+    for (int mt = blockIdx.x; mt < n_mt; mt += gridDim.x) {
+        const int64_t m0 = (int64_t)mt * BM;
+        {
+            int tt = tid;
+            asm volatile("" : "+v"(tt));
+            const int64_t rows_left = M - m0;
+            const uint64_t base = reinterpret_cast<uint64_t>(A + m0 * lda);
+            const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+            const int64_t nbytes = (rows_left < BM ? rows_left : BM) * lda * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0,
+                                                                               __builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000);
+            f32x4 v[ITERS];
+#pragma unroll
+            for (int i = 0; i < ((PROBE & 2) ? 0 : ITERS); ++i) {
+                const int idx = tt + 256 * i;
+                const int r = idx / F4R, c = idx - r * F4R;
+                const uint32_t off = (idx < BM * F4R && c * 4 < K4) ? (uint32_t)r * ld4 + (uint32_t)c * 16u : 0x80000000u;
+                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < ((PROBE & 2) ? 0 : ITERS); ++i) {
+                const int idx = tt + 256 * i;
+                const int r = idx / F4R, c = idx - r * F4R;
+                if (idx < BM * F4R) *reinterpret_cast<f32x4*>(As + r * PITCH + c * 4) = v[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ps = 0; ps < passes; ++ps) {
+            const int tile0 = (wid * passes + ps) * WCT;
+            const int ncol0 = tile0 * 16;
+            f32x4 acc[MR][WCT];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto bload = [&](f32x4 (&b)[WCT], int kt) {
+                const int kk = kt < NK ? kt : NK - 1;
+#pragma unroll
+                for (int j = 0; j < WCT; ++j)
+                    b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
+            };
+            auto kstep = [&](const f32x4 (&b)[WCT], int kt) {
+                f32x4 af[MR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + (i * 16 + li) * PITCH + kt * 16 + lg * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MR; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][t], af[i][t], acc[i][j], 0, 0, 0);
+            };
+            f32x4 ring[D1][WCT];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+#pragma unroll 1
+            for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                for (int u = 0; u < D1; ++u) {
+                    bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH);
+                    if (k0 + u < NK) kstep(ring[u], k0 + u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int64_t row = m0 + i * 16 + li;
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) {
+                    const int col0 = ncol0 + j * 16 + lg * 4;
+                    if ((PROBE & 4) ? (acc[i][j][0] == 123.4f) : (row < M && col0 < N))
+                        *reinterpret_cast<f32x4*>(C + row * ldc + col0) = acc[i][j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int KP, int BM, int WCT, int DEPTH, int PROBE>
+static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const float* dB, int N, float* dC, int64_t ldc,
+                const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
+    const int n_mt = (int)((M + BM - 1) / BM);
+    const int passes = N <= 4 * WCT * 16 ? 1 : 2;
+    const size_t lds = (size_t)BM * (KP + 4) * 4;
+    auto kern = astat_f32_kernel<KP, BM, WCT, DEPTH, PROBE>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(dC, 0, (size_t)M * ldc * 4));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    double worst = 0;
+    const int64_t rows[] = {0, 1, 63, 64, 12345, M - 65, M - 1};
+    std::vector<float> hc(N);
+    for (int64_t r : rows) {
+        CK(hipMemcpy(hc.data(), dC + r * ldc, (size_t)N * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            double s = 0, mag = 0;
+            for (int k = 0; k < K; ++k) {
+                s += (double)hA[r * lda + k] * (double)hW[(size_t)k * N + n];
+                mag += fabs((double)hA[r * lda + k] * (double)hW[(size_t)k * N + n]);
+            }
+            worst = fmax(worst, fabs(s - hc[n]) / (1e-6 + mag));
+        }
+    }
+    const double flops = 2.0 * M * N * K;
+    printf("%-40s grid %4d  passes %d  %.3f ms  %.1f TF   max err / sum|terms| %.2e\n", name, grid, passes, ms, flops / ms / 1e9, worst);
+}
+
+int main() {
+    const int64_t M = 440000;
+    const int K = 300, KP = 304;
+    const int64_t lda = 300;
+    std::vector<float> hA((size_t)M * lda);
+    uint32_t s = 12345;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f;
+    };
+    for (auto& x : hA) x = rnd();
+    float *dA, *dC;
+    CK(hipMalloc(&dA, hA.size() * 4));
+    CK(hipMalloc(&dC, (size_t)M * 640 * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    for (int N : {300, 600}) {
+        std::vector<float> hW((size_t)K * N);
+        for (auto& x : hW) x = rnd() * 0.1f;
+        const int passes = N <= 320 ? 1 : 2, n_tiles = 4 * passes * 5, NK = KP / 16;
+        std::vector<float> hF((size_t)n_tiles * NK * 256, 0.f);
+        for (int nt = 0; nt < n_tiles; ++nt)
+            for (int kt = 0; kt < NK; ++kt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = nt * 16 + (lane & 15), k = kt * 16 + (lane >> 4) * 4 + e;
+                        if (n < N && k < K) hF[(((size_t)nt * NK + kt) * 64 + lane) * 4 + e] = hW[(size_t)k * N + n];
+                    }
+        float* dF;
+        CK(hipMalloc(&dF, hF.size() * 4));
+        CK(hipMemcpy(dF, hF.data(), hF.size() * 4, hipMemcpyHostToDevice));
+        printf("N = %d (%.1f GFLOP)\n", N, 2.0 * M * N * K / 1e9);
+        run<304, 64, 5, 1, 0>("whole rows, B 1 step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 2>("  ablation: no A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 4>("  ablation: no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 6>("  ablation: MFMAs + LDS + B only", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        CK(hipFree(dF));
+    }
+    return 0;
+}
