@@ -140,9 +140,9 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     hbm("tanh(A_hat . Z + bh) with the highway mix in the epilogue  (spmm_rows_kernel<.., HW> + long-row combine)", 'spmm_highway',
         spmm_algorithmic_bytes(N, N, nnz, F) + 3 * 4 * N * F, "algorithmic bytes = the plain product's + T, H read and Hout written")
     fl = 2.0 * N * F * F
-    mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_kernel NN, dual)", 'gemm_dual_nn', 2 * fl)
+    mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_rows_kernel: 64 whole rows of A per block, dual)", 'gemm_dual_nn', 2 * fl)
     mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)", 'gemm_dual_tn', 2 * fl)
-    mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_kernel NT, K-concatenated)", 'gemm_kcat', 2 * fl)
+    mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl)
     return out
 
 
@@ -174,6 +174,12 @@ def timed_region(clf, step, steps, warmup, barrier, F_spmm, g):
     timer = ops.SpmmTimer(capacity=max(16, 8 * steps))
     timer.attach(g['A'].fwd, only_F=F_spmm)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # (a generation-2 collection of the interpreter takes 10-20 ms with the graph's host arrays alive: it would stall the
+    #  launching thread in the middle of a step -- one 49 ms step among 28 ms ones was seen once; collect now, not in the region)
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -183,6 +189,8 @@ def timed_region(clf, step, steps, warmup, barrier, F_spmm, g):
         marks[i + 1].record()
     barrier()
     t = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     timer.detach()
     kern_ms = timer.read_ms()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
