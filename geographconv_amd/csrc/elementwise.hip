@@ -167,9 +167,9 @@ __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int 
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
     float4 aS = make_float4(0.f, 0.f, 0.f, 0.f), aU = aS;
     if (ri < rpi) {
-        for (int64_t row = r0 + ri; row < r1; row += rpi) {
+        // two rows per trip: eight loads in flight per thread instead of four (the sums are still taken in row order)
+        auto one = [&](int64_t row, const float4& g, const float4& t, const float4& hc, const float4& h) {
             const int64_t e = row * ld4 + q;
-            const float4 g = G[e], t = T[e], hc = Hc[e], h = H[e];
             float4 s, u, c;
 #define GEOGCN_HW(m)                              \
     hw_grad(g.m, t.m, hc.m, h.m, s.m, u.m, c.m);  \
@@ -185,6 +185,18 @@ __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int 
             }
             dU[e] = u;
             dHc[e] = c;
+        };
+        int64_t row = r0 + ri;
+        for (; row + rpi < r1; row += 2 * rpi) {
+            const int64_t e0 = row * ld4 + q, e1 = (row + rpi) * ld4 + q;
+            const float4 g0 = G[e0], t0 = T[e0], hc0 = Hc[e0], h0 = H[e0];
+            const float4 g1 = G[e1], t1 = T[e1], hc1 = Hc[e1], h1 = H[e1];
+            one(row, g0, t0, hc0, h0);
+            one(row + rpi, g1, t1, hc1, h1);
+        }
+        if (row < r1) {
+            const int64_t e = row * ld4 + q;
+            one(row, G[e], T[e], Hc[e], H[e]);
         }
     }
     red[0][threadIdx.x] = aS;
