@@ -1,4 +1,7 @@
 # same-box A/B of the whole-rows fp32 GEMM kernel (run through gpurun from the repo root)
+# the 'old' side is the same library built without the kernel, made beforehand (it travels with the snapshot):
+#   GEOGCN_BUILD_DEFINES=GEOGCN_F32_NO_ROWS_KERNEL python -m geographconv_amd.build --force && cp geographconv_amd/libgeogcn.so tools/micro/bin/libgeogcn_norows_f32.so
+#   python -m geographconv_amd.build --force
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_u_f32_rows_ab.txt
 : > $O

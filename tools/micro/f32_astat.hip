@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restri
 #pragma unroll
                 for (int j = 0; j < WCT; ++j) {
                     const int col0 = ncol0 + j * 16 + lg * 4;
-                    if ((PROBE & 4) ? (acc[i][j][0] == 123.4f) : (row < M && col0 < N))
-                        *reinterpret_cast<f32x4*>(C + row * ldc + col0) = acc[i][j];
+                    if ((PROBE & 4) ? (acc[i][j][0] == 123.4f) : (row < M && col0 < N)) {
+                        if (PROBE & 8) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(C + row * ldc + col0));   // PROBE 8
+                        else *reinterpret_cast<f32x4*>(C + row * ldc + col0) = acc[i][j];
+                    }
                 }
             }
         }
@@ -192,6 +194,8 @@ int main() {
         printf("N = %d (%.1f GFLOP)\n", N, 2.0 * M * N * K / 1e9);
         run<304, 64, 5, 1, 0>("whole rows, B 1 step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 8>("whole rows, non-temporal C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 2>("  ablation: no A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 4>("  ablation: no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 6>("  ablation: MFMAs + LDS + B only", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
