@@ -32,9 +32,10 @@ def dist_backend():
 # ---- fusion A/B (both on; tests flip them to prove the fused launches equal the separate ones) ----------------------
 # highway block: (Z, T) = (H.Wh, sigmoid(H.Wt + bt)), (dWh, dWt), dH in one GEMM launch each (-0.46 ms per TWUS step)
 FUSE_GEMMS = True
-# gating mix T*Hc + (1-T)*H in the SpMM's epilogue: 'f32' = for the fp32 gathered operand only (on the bf16 operand the
-# epilogue's T / H loads cost more than the separate pass: 1.82 ms fused against 1.10 + 0.41), 'all', 'none'
-FUSE_HIGHWAY = 'f32'
+# gating mix T*Hc + (1-T)*H in the SpMM's epilogue: 'all' (default), 'f32' = for the fp32 gathered operand only, 'none'.
+# (On the bf16 operand the fused epilogue was slower in round 2 -- 1.82 ms against 1.10 + 0.41 at 300 wide; re-measured at the end
+#  of round 3, same box, two alternations: 6x600 bf16 step 69.95 -> 69.56 ms, 3x300 bf16 18.06 -> 17.98: now ahead, so 'all'.)
+FUSE_HIGHWAY = 'all'
 
 # bf16 configuration, one GPU: highway_bwd stores the branch gradient dS as bf16 (what A^T . dS gathers) instead of fp32 + a cast
 # pass (-0.37 ms per 600-wide block; same bits)
