@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host-side AddressSanitizer run of the C-ABI library (aux row 2): libgeogcn.so rebuilt with
 # -fsanitize=address on the HOST code (device code unchanged: -fno-gpu-sanitize), the sanitizer runtime preloaded into python,
-# then the randomised entry-point sweeps (tests/test_fuzz_gpu.py: 75 cases over every entry point and whole training steps) and
+# then the randomised entry-point sweeps (tests/test_fuzz_gpu.py: 75 cases over every entry point and whole training steps), the kernel tests and
 # the ABI argument sweep run against it.  Catches host heap errors in plan builders, workspace arithmetic, argument checks.
 #   build here (no GPU needed):   bash tools/asan_run.sh build
 #   run on the GPU box:           gpurun -- 'bash tools/asan_run.sh run'      -> gpurun_out/asan_fuzz.log
@@ -30,7 +30,7 @@ export LD_PRELOAD="$RT $(ls /usr/lib/x86_64-linux-gnu/libstdc++.so.6)"      # (l
 # (libasan's dlopen interceptor becomes the caller of torch's lazy dlopen()s: their $ORIGIN run-paths no longer apply)
 export LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:${LD_LIBRARY_PATH:-}
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0
-{ echo "# host ASAN run: $(date -u) runtime $RT"; python -m pytest tests/test_fuzz_gpu.py tests/test_abi.py -q -m "gpu or not gpu" -p no:cacheprovider 2>&1 | tail -25; } > gpurun_out/asan_fuzz.log 2>&1
+{ echo "# host ASAN run: $(date -u) runtime $RT"; python -m pytest tests/test_fuzz_gpu.py tests/test_abi.py tests/test_kernels_gpu.py -q -m "gpu or not gpu" -p no:cacheprovider 2>&1 | tail -25; } > gpurun_out/asan_fuzz.log 2>&1
 unset LD_PRELOAD
 cp /tmp/libgeogcn_plain.so geographconv_amd/libgeogcn.so
 grep -c "ERROR: AddressSanitizer" gpurun_out/asan_fuzz.log
