@@ -442,6 +442,7 @@ class TorchDistComm(Comm):
             # at 2 ranks both schemes move the same bytes and the all-gather needs no repacking; from 3 ranks on
             # the all-to-all moves (w-1)/w * 2/w of what the all-gather delivers to every rank
             self.exchange = 'a2a' if self.world >= 3 else 'allgather'
+        self._auto_default = self.exchange
         if self.exchange not in ('a2a', 'allgather', 'halo'):
             raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a', 'allgather' or 'halo', got %r" % self.exchange)
         self.balance = bool(balance)        # all-gather / halo schemes: cost-balanced row split (False: uniform, the A/B)
@@ -467,10 +468,15 @@ class TorchDistComm(Comm):
             self.halo_rows = halo_sizes(A_csr, bounds, self._symmetric)
             remote = self.part.N - np.diff(bounds)
             limit = tuning.DIST_HALO_MAX_FRACTION_2_RANKS if self.world == 2 else tuning.DIST_HALO_MAX_FRACTION
-            if self._auto and self.halo_rows.max() <= limit * max(1, remote.min()):
-                self.exchange = 'halo'
+            if self._auto:        # (decided per graph: a second graph without locality goes back to the default scheme)
+                self.exchange = 'halo' if self.halo_rows.max() <= limit * max(1, remote.min()) else self._auto_default
+                if self.exchange != 'halo':
+                    self.halo = None
         if self.exchange in ('allgather', 'halo') and self.balance:
             self.part = RowPartition(self.part.N, self.world, self.rank, bounds=bounds)
+            self._bufs = {}
+        elif not self.part.uniform:          # (a2a after an earlier graph had moved this communicator to a balanced split)
+            self.part = RowPartition(self.part.N, self.world, self.rank)
             self._bufs = {}
         if self.exchange == 'halo':
             self._build_halo(A_csr)

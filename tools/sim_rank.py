@@ -72,6 +72,7 @@ class SimComm(TorchDistComm):
         self._auto = exchange == 'auto'
         if self._auto:
             self.exchange = 'a2a' if world >= 3 else 'allgather'
+        self._auto_default = self.exchange
         self.halo = self.halo_rows = None
         self._bufs = {}
 
