@@ -605,7 +605,11 @@ struct TnArgs {
     int n_mt, n_nt, nsplit;
 };
 
-template <int BM, int BN>
+// PF = stages of global loads in flight per thread (register ring).  One block per CU and 20 MFMAs of 16 cycles per wave and
+// stage: with ONE stage in flight (round 2) a stage took one memory latency, 1.45 us, whatever the bandwidth -- 573 stages per block
+// = 0.85 ms at 600 wide for 2.1 GB of operands; three in flight let the loads of stages s+1 .. s+3 overlap.
+// (the 160 x 320 tile has 100 accumulator registers: two stages in flight there, or the ring spills)
+template <int BM, int BN, int PF = (BM * BN > 128 * 320 ? 2 : 3)>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
     constexpr int NTH = 512, kASplit = 192;                  // threads [0,192): A patches, [192,512): B patches
     constexpr int MR = BM / 32, NR = BN / 64;                // 2 x 4 waves, wave tile (BM/2) x (BN/4)
@@ -645,8 +649,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
     const bool col_ok = active && (c4 * 4 < ((ctot + 3) & ~(int64_t)3) - c0);
     // (the two operands use different descriptors: built per lane group, uniform within a wave except wave 2/3
     //  boundary at thread 192 = wave 3 start, so every wave is uniform)
-    float4 r[8];
-    auto gload = [&](int kt) {
+    float4 ring[PF][8];
+    auto gload = [&](float4 (&r)[8], int kt) {
         const int64_t k0 = kbeg + (int64_t)kt * BKH;
         const __amdgpu_buffer_rsrc_t rs = tn_rsrc(P + k0 * ld + c0, ((kend - k0) * ld - c0) * 4);
         const uint32_t ld4 = (uint32_t)ld * 4u;
@@ -656,17 +660,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
             r[i] = tn_load4(rs, col_ok ? off : kOob);
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const float4 (&r)[8]) {
         if (!active) return;
         unsigned char* img = smem_raw + buf * kStage + (isA ? 0 : kImgA);
-        const float* f = reinterpret_cast<const float*>(r);          // r[i] = row i of the patch: f[4*i + e]
+        // r[i] = row i of the patch; column e of the patch = component e of every row.  (Components are picked by name: a
+        // pointer cast over the array would take its address and, with a ring of such arrays, park the ring in scratch memory)
+        auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             uint4 w;
-            w.x = bf16_pack(f[0 + e], f[4 + e]);
-            w.y = bf16_pack(f[8 + e], f[12 + e]);
-            w.z = bf16_pack(f[16 + e], f[20 + e]);
-            w.w = bf16_pack(f[24 + e], f[28 + e]);
+            w.x = bf16_pack(comp(r[0], e), comp(r[1], e));
+            w.y = bf16_pack(comp(r[2], e), comp(r[3], e));
+            w.z = bf16_pack(comp(r[4], e), comp(r[5], e));
+            w.w = bf16_pack(comp(r[6], e), comp(r[7], e));
             *reinterpret_cast<uint4*>(img + (c4 * 4 + e) * ROWB + k8 * 16) = w;
         }
     };
@@ -677,17 +683,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) {
-        gload(0);
-        sstore(0);
-    }
+    // ring slot of stage s: s % PF.  Stages past the end of the slab read as zeros (empty descriptor) and are never multiplied.
+#pragma unroll
+    for (int d = 0; d < PF; ++d) gload(ring[d], d);
+    sstore(0, ring[0]);
+    gload(ring[0], PF);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll 1
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int kt = kt0 + u;          // (steps past nk in the last trip multiply and store nothing; no `break`: the ring's
+        const bool live = kt < nk;       //  slots must stay compile-time constants, or the ring lands in scratch memory)
         const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
         const unsigned char* As = smem_raw + cur * kStage;
         const unsigned char* Bs = As + kImgA;
+        if (live) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Bs + (wn * (BN / 4) + j * 16 + li) * ROWB + lg * 16);
@@ -697,9 +709,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af, acc[i][j], 0, 0, 0);   // transposed: see above
             }
         }
-        if (more) sstore(cur ^ 1);
+        }
+        // stage kt + 1 was requested PF steps ago: into the other LDS image, and its slot takes stage kt + 1 + PF
+        if (more) sstore(cur ^ 1, ring[(u + 1) % PF]);
+        gload(ring[(u + 1) % PF], kt + 1 + PF);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         cur ^= 1;
+      }
     }
     // slab z: lane (li, lg) holds C[row = li][col = 4*lg + r] of each 16x16 sub-tile
     float* Wz = a.W + (int64_t)z * a.M * a.ldw;
