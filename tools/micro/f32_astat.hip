@@ -121,6 +121,114 @@ __global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restri
     }
 }
 
+// Variant: the NEXT tile's rows are requested before this tile's MFMA loop and sit in registers (19 float4 per thread) until the
+// tile is done; then one barrier, 19 LDS writes, one barrier.  The HBM read of A leaves the critical path.
+template <int KP, int BM, int WCT, int DEPTH>
+__global__ __launch_bounds__(256, 2) void astat_f32_prefetch_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+                                                                    const float* __restrict__ Bf, int N, float* __restrict__ C,
+                                                                    int64_t ldc, int n_mt, int passes) {
+    constexpr int PITCH = KP + 4;
+    constexpr int F4R = KP / 4;
+    constexpr int ITERS = BM * F4R / 256;
+    constexpr int MR = BM / 16, NK = KP / 16, D1 = DEPTH + 1;
+    extern __shared__ __attribute__((aligned(16))) float As[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int K4 = (K + 3) & ~3;
+    const uint32_t ld4 = (uint32_t)lda * 4u;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bf), 0, 4 * passes * WCT * NK * 1024, 0x00020000);
+    auto tile_rsrc = [&](int mt) {
+        const int64_t m0 = (int64_t)mt * BM;
+        const int64_t rows_left = mt < n_mt ? M - m0 : 0;
+        const uint64_t base = reinterpret_cast<uint64_t>(A + (mt < n_mt ? m0 : 0) * lda);
+        const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+        const int64_t nbytes = (rows_left < BM ? rows_left : BM) * lda * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000);
+    };
+    auto load_tile = [&](f32x4 (&v)[ITERS], int mt) {
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(mt);
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int idx = tt + 256 * i;
+            const int r = idx / F4R, c = idx - r * F4R;
+            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : 0x80000000u), 0, 0));
+        }
+    };
+    auto store_tile = [&](const f32x4 (&v)[ITERS]) {
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int idx = tt + 256 * i;
+            const int r = idx / F4R, c = idx - r * F4R;
+            *reinterpret_cast<f32x4*>(As + r * PITCH + c * 4) = v[i];
+        }
+    };
+    f32x4 v[ITERS];
+    load_tile(v, blockIdx.x);
+    store_tile(v);
+    __syncthreads();
+    for (int mt = blockIdx.x; mt < n_mt; mt += gridDim.x) {
+        const int64_t m0 = (int64_t)mt * BM;
+        load_tile(v, mt + gridDim.x);                 // (zeros past the end of the list)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int ps = 0; ps < passes; ++ps) {
+            const int tile0 = (wid * passes + ps) * WCT;
+            const int ncol0 = tile0 * 16;
+            f32x4 acc[MR][WCT];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto bload = [&](f32x4 (&b)[WCT], int kt) {
+                const int kk = kt < NK ? kt : NK - 1;
+#pragma unroll
+                for (int j = 0; j < WCT; ++j)
+                    b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
+            };
+            auto kstep = [&](const f32x4 (&b)[WCT], int kt) {
+                f32x4 af[MR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + (i * 16 + li) * PITCH + kt * 16 + lg * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MR; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][t], af[i][t], acc[i][j], 0, 0, 0);
+            };
+            f32x4 ring[D1][WCT];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+#pragma unroll 1
+            for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                for (int u = 0; u < D1; ++u) {
+                    bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH);
+                    if (k0 + u < NK) kstep(ring[u], k0 + u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int64_t row = m0 + i * 16 + li;
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) {
+                    const int col0 = ncol0 + j * 16 + lg * 4;
+                    if (row < M && col0 < N) *reinterpret_cast<f32x4*>(C + row * ldc + col0) = acc[i][j];
+                }
+            }
+        }
+        __syncthreads();
+        store_tile(v);
+        __syncthreads();
+    }
+}
+
 template <int KP, int BM, int WCT, int DEPTH, int PROBE>
 static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const float* dB, int N, float* dC, int64_t ldc,
                 const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
@@ -161,6 +269,29 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     printf("%-40s grid %4d  passes %d  %.3f ms  %.1f TF   max err / sum|terms| %.2e\n", name, grid, passes, ms, flops / ms / 1e9, worst);
 }
 
+template <int KP, int BM, int WCT, int DEPTH>
+static void run_pf(const char* name, const float* dA, int64_t lda, int64_t M, int K, const float* dB, int N, float* dC, int64_t ldc, int grid) {
+    const int n_mt = (int)((M + BM - 1) / BM);
+    const int passes = N <= 4 * WCT * 16 ? 1 : 2;
+    const size_t lds = (size_t)BM * (KP + 4) * 4;
+    auto kern = astat_f32_prefetch_kernel<KP, BM, WCT, DEPTH>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    printf("%-40s grid %4d  passes %d  %.3f ms  %.1f TF\n", name, grid, passes, ms, 2.0 * M * N * K / ms / 1e9);
+}
+
 int main() {
     const int64_t M = 440000;
     const int K = 300, KP = 304;
@@ -194,6 +325,8 @@ int main() {
         printf("N = %d (%.1f GFLOP)\n", N, 2.0 * M * N * K / 1e9);
         run<304, 64, 5, 1, 0>("whole rows, B 1 step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run_pf<304, 64, 5, 2>("next tile's rows prefetched into registers", dA, lda, M, K, dF, N, dC, N, 512);
+        run_pf<304, 64, 5, 1>("  ... B 1 step ahead", dA, lda, M, K, dF, N, dC, N, 512);
         run<304, 64, 5, 2, 8>("whole rows, non-temporal C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 2>("  ablation: no A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
