@@ -830,6 +830,7 @@ class GraphConv():
         np.random.seed(seed)
         logging.info('training for {} epochs with batch size {}'.format(n_epochs, batch_size))
         watch = _DevLossWatch(max_down)
+        self.fit_history, self.best_epoch = [], -1      # not in the reference: the training curve, for callers and tests
         y_train, y_dev = Y[train_indices], Y[val_indices]
         for v in (y_train, y_dev):              # fit()'s own copies (fancy indexing): frozen => hashed once, not per epoch
             v.setflags(write=False)
@@ -837,7 +838,10 @@ class GraphConv():
             out = self.f_train(X, y_train, y_dev, H, train_indices, val_indices)
             l_train, acc_train, l_val, acc_val = (v.item() for v in out[:4])
             if watch.update(l_val, acc_val):
+                # AFTER f_train's update, as get_all_param_values at gcnmodel.py:437 sees the shared variables
                 watch.snapshot = self.store.p.clone()
+                self.best_epoch = epoch
+            self.fit_history.append((l_train, acc_train, l_val, acc_val, watch.n_down))
             if verbose:
                 logging.info('epoch {} train loss {:.2f} train acc {:.2f} val loss {:.2f} val acc {:.2f} best val acc {:.2f} maxdown {}'.format(
                     epoch, l_train, acc_train, l_val, acc_val, watch.best_acc, watch.n_down))

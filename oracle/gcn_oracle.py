@@ -329,3 +329,38 @@ def conv_layer_fwd_bwd(H, W, b, A, G):
     dW = H.T @ dZ
     dH = dZ @ W.T
     return Hc, dH, dW, db
+
+
+# --------------------------------------------------------------------------------------------
+# the training loop (gcnmodel.py:418-450)
+# --------------------------------------------------------------------------------------------
+def fit(params, st, step, n_epochs=10000, max_down=10, report_k_epoch=1):
+    """GraphConv.fit restated line for line (gcnmodel.py:421-449).  ``step(params, st) -> (new_params, outs)`` stands for the
+    compiled f_train of gcnmodel.py:430 (its parameter update included; outs[:4] = loss_tr, acc_tr, loss_dev, acc_dev), so
+    the loop can be driven by oracle.f_train or by a scripted sequence of dev losses.  Returns a dict: 'best_params' (what
+    gcnmodel.py:448-449 restores -- the values AFTER the update of the best epoch, because get_all_param_values at :437
+    runs after f_train has applied its updates), 'best_epoch', 'stop_epoch' (last epoch run), 'stopped_early',
+    'best_val_loss', 'best_val_acc' and the per-epoch 'history' of (loss_tr, acc_tr, loss_dev, acc_dev, n_validation_down)."""
+    import sys
+    best_params = None                                       # gcnmodel.py:421
+    best_val_loss = sys.maxsize                              # :422
+    best_val_acc = 0.0                                       # :423
+    n_validation_down = 0                                    # :424
+    best_epoch, stopped, history, n = -1, False, [], -1
+    for n in range(n_epochs):                                # :429
+        params, outs = step(params, st)                      # :430  (updates applied inside f_train)
+        l_train, acc_train, l_val, acc_val = (float(v) for v in outs[:4])       # :431-432  .item()
+        if l_val < best_val_loss:                            # :434  strict; a NaN never improves
+            best_val_loss = l_val                            # :435
+            best_val_acc = acc_val                           # :436
+            best_params = [np.array(p, copy=True) for p in params]              # :437  values after this epoch's update
+            n_validation_down = 0                            # :438
+            best_epoch = n
+        else:
+            n_validation_down += 1                           # :441
+        history.append((l_train, acc_train, l_val, acc_val, n_validation_down))
+        if n_validation_down > max_down and n > 2 * report_k_epoch * max_down:  # :445
+            stopped = True
+            break                                            # :447
+    return dict(best_params=best_params, best_epoch=best_epoch, stop_epoch=n, stopped_early=stopped,
+                best_val_loss=best_val_loss, best_val_acc=best_val_acc, history=history, last_params=params)
