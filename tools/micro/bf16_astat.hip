@@ -434,6 +434,128 @@ static float bf(unsigned short h) {
     return f;
 }
 
+
+// ---- round 4: LOADER / CONSUMER wave specialisation ------------------------------------------------------------------------------
+// One 512-thread block per CU, two LDS buffers of 64 rows (2 x 78.8 KB).  Waves 4..7 are LOADERS: they keep the next-but-one
+// tile's 38 float4 per thread in flight in registers (requested before the barrier that ends an iteration), round them to bf16 and
+// write them into the buffer the consumers are NOT reading.  Waves 0..3 are CONSUMERS: MFMAs on the current buffer + C stores,
+// never waiting on global memory except for the L2-resident B fragments.  One barrier per tile.  The three phases of a tile (A
+// load, MFMA, C store) overlap by construction instead of relying on two co-resident blocks drifting apart.
+template <int KP, int WCT, int DEPTH, int NCW, int PROBE = 0>
+__global__ __launch_bounds__(NCW * 64 + 256, 1) void astat_lc_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+                                                          const unsigned short* __restrict__ Bp, int N, float* __restrict__ C,
+                                                          int64_t ldc, int n_mt) {
+    constexpr int BM = 64, PITCH = KP * 2 + 16, F4R = KP / 4, MR = BM / 16, NK = KP / 32, D1 = DEPTH + 1;
+    constexpr int NL = 256, ITERS = BM * F4R / NL;
+    static_assert(BM * F4R % NL == 0, "a tile must divide over the loader threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char As[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the role branch below is wave-uniform
+    const int n_my = blockIdx.x < (unsigned)n_mt ? (n_mt - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    constexpr int PASSES = 8 / NCW;             // 8 wave-passes of WCT column tiles cover the 640 columns
+    if (wid >= NCW) {
+        const int K4 = (K + 3) & ~3;
+        const uint32_t ld4 = (uint32_t)lda * 4u;
+        auto tile_rsrc = [&](int i) {          // i-th tile of this block; past the end: an empty descriptor (loads return zeros)
+            const int mt = (int)blockIdx.x + i * (int)gridDim.x;
+            const bool ok = i < n_my;
+            const int64_t m0 = ok ? (int64_t)mt * BM : 0;
+            const int64_t rows_left = ok ? M - m0 : 0;
+            const uint64_t base = reinterpret_cast<uint64_t>(A + m0 * lda);
+            const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+            const int64_t nbytes = (rows_left < BM ? rows_left : BM) * lda * 4;
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000);
+        };
+        // every register slot is recycled on its own: slot q's value (tile i+1) is rounded and written to LDS, then the slot
+        // immediately requests its piece of tile i+2 -- between 37 and 38 KB-pieces per thread are in flight at all times
+        auto cycle = [&](f32x4 (&v)[ITERS], int buf, int next_tile, bool first) {
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(next_tile);
+            int tt = tid - NCW * 64;
+            asm volatile("" : "+v"(tt));
+            unsigned char* dst = As + buf * (BM * PITCH);
+#pragma unroll
+            for (int q = 0; q < ((PROBE & 2) ? 0 : ITERS); ++q) {
+                const int idx = tt + NL * q;
+                const int r = idx / F4R, c = idx - r * F4R;
+                if (!first) {
+                    uint2 w;
+                    w.x = bf16_pack(v[q][0], v[q][1]);
+                    w.y = bf16_pack(v[q][2], v[q][3]);
+                    *reinterpret_cast<uint2*>(dst + r * PITCH + c * 8) = w;
+                }
+                const uint32_t off = c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : 0x80000000u;
+                v[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+            }
+        };
+        f32x4 v[ITERS];
+        cycle(v, 0, 0, true);                 // request tile 0
+        cycle(v, 0, 1, false);                // tile 0 -> buffer 0, request tile 1
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < n_my; ++i) {
+            cycle(v, (i + 1) & 1, i + 2, false);      // tile i+1 -> the buffer the consumers are not reading; request tile i+2
+            __syncthreads();
+        }
+    } else {
+        const int li = lane & 15, lg = lane >> 4;
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, 640 * KP * 2, 0x00020000);
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < n_my; ++i) {
+            const int64_t m0 = (int64_t)((int)blockIdx.x + i * (int)gridDim.x) * BM;
+            const unsigned char* Ab = As + (i & 1) * (BM * PITCH);
+#pragma unroll 1
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int ncol0 = (wid * PASSES + ps) * WCT * 16;
+                f32x4 acc[MR][WCT];
+#pragma unroll
+                for (int a = 0; a < MR; ++a)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto bload = [&](bf16x8 (&b)[WCT], int kt) {
+                    const int kk = (PROBE & 1) ? 0 : (kt < NK ? kt : NK - 1);      // PROBE 1: one (L1-resident) fragment set
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j)
+                        b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((PROBE & 1) ? j : ncol0 / 16 + j) * NK + kk) * 1024, 0));
+                };
+                auto kstep = [&](const bf16x8 (&b)[WCT], int kt) {
+                    bf16x8 af[MR];
+#pragma unroll
+                    for (int a = 0; a < MR; ++a) af[a] = *reinterpret_cast<const bf16x8*>(Ab + (a * 16 + li) * PITCH + kt * 64 + lg * 16);
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                        for (int a = 0; a < MR; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], af[a], acc[a][j], 0, 0, 0);
+                };
+                bf16x8 ring[D1][WCT];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+#pragma unroll 1
+                for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                    for (int u = 0; u < D1; ++u) {
+                        bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH);
+                        if (k0 + u < NK) kstep(ring[u], k0 + u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < MR; ++a) {
+                    const int64_t row = m0 + a * 16 + li;
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) {
+                        const int col0 = ncol0 + j * 16 + lg * 4;
+                        if ((PROBE & 4) ? (acc[a][j][0] == 123.4f) : (row < M && col0 < N))
+                            *reinterpret_cast<float4*>(C + row * ldc + col0) = make_float4(acc[a][j][0], acc[a][j][1], acc[a][j][2], acc[a][j][3]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int KP, int BM, int WCT, int PASSES, int DEPTH, int FR, int PROBE = 0>
 static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC, int64_t ldc,
                 const std::vector<float>& hA, const std::vector<unsigned short>& hB, int grid) {
@@ -550,6 +672,44 @@ static void run_early(const char* name, const float* dA, int64_t lda, int64_t M,
            bytes / ms / 1e9, worst);
 }
 
+template <int KP, int WCT, int DEPTH, int NCW, int PROBE>
+static void run_lc(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC, int64_t ldc,
+                   const std::vector<float>& hA, const std::vector<unsigned short>& hB, int grid) {
+    constexpr int PITCH = KP * 2 + 16, BM = 64;
+    const int n_mt = (int)((M + BM - 1) / BM);
+    const size_t lds = (size_t)2 * BM * PITCH;
+    auto kern = astat_lc_kernel<KP, WCT, DEPTH, NCW, PROBE>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(dC, 0, (size_t)M * ldc * 4));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(NCW * 64 + 256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(NCW * 64 + 256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    double worst = 0;
+    const int64_t rows[] = {0, 1, 63, 64, 12345, 16384 + 77, 64 * 256 * 13 + 5, M - 65, M - 1};
+    std::vector<float> hc(N);
+    for (int64_t r : rows) {
+        CK(hipMemcpy(hc.data(), dC + r * ldc, (size_t)N * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            double sacc = 0;
+            for (int k = 0; k < K; ++k) sacc += (double)bf(rne(hA[r * lda + k])) * (double)bf(hB[(size_t)n * KP + k]);
+            worst = fmax(worst, fabs(sacc - hc[n]) / (1e-3 + fabs(sacc)));
+        }
+    }
+    const double flops = 2.0 * M * N * K, bytes = 4.0 * M * (K + N);
+    printf("%-34s grid %4d  lds %6zu B  %.3f ms  %.0f TF  %.2f TB/s of A + C   max rel err %.2e\n", name, grid, lds, ms, flops / ms / 1e9,
+           bytes / ms / 1e9, worst);
+}
+
 int main() {
     const int64_t M = 440000;
     const int K = 600, N = 600, KP = 608, NP = 640;
@@ -583,8 +743,12 @@ int main() {
     CK(hipMemcpy(dF, hF.data(), hF.size() * 2, hipMemcpyHostToDevice));
     for (int grid : {512}) {
         run<608, 64, 5, 2, 2, 1>("BM 64, 2x5, B fragment order, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
-        run_early<608, 64, 5, 2>("requests before the stores, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
-        run_early<608, 64, 5, 3>("requests before the stores, 3 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
+        run_lc<608, 5, 2, 4, 0>("LC 4 consumers x 2 passes, B 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 1>("  probe: B fragments L1-resident", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 3>("  probe: B L1-resident, no A loads", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 5>("  probe: B L1-resident, no C stores", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 7>("  probe: B L1-resident, MFMA only", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run<608, 64, 5, 2, 2, 1, 1>("baseline, B fragments L1-resident", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
         run<608, 64, 5, 2, 2, 1>("BM 64, 2x5, B fragment order, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
     }
     {
