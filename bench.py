@@ -25,7 +25,9 @@ repartition with two all-to-alls from 3 ranks -- DESIGN.md section 5).  The JSON
   step_ms        : median / p10 / p90 of the per-step times (events per step, same region);
   cpu_baseline   : the NumPy/SciPy oracle (oracle/gcn_oracle.py, kind "port": SpMM single-threaded like Theano's
                    StructuredDot, BLAS sgemm on all threads) timed on this box's host cores (rank 0, N=1 only);
-  cpu_baseline_mt: the same step with the sparse products on all cores (oracle/cpu_mt.c, OpenMP).
+  cpu_baseline_mt: the same step with EVERY pass on all cores (oracle/cpu_mt.py::f_train: sparse products and the fused
+                   elementwise / softmax / column-sum passes in OpenMP, dense products in BLAS) -- the "fair multi-core CPU";
+  clocks         : shader / memory clock, socket power and temperature sampled while further steps run after the timed region.
 """
 from __future__ import annotations
 
@@ -42,6 +44,68 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_*_bf16, dense (MI355X_MICROARCH.md: ~2.5 PF; 2:1 sparsity figures are not a peak)
+
+
+class ClockSampler:
+    """SURVEY.md section 8d "clocks / power state logged": a thread that reads the amdgpu hwmon files of the device (shader clock
+    freq1_input, memory clock freq2_input, socket power power1_input, temperature) every ~15 ms while `n` extra training steps
+    run AFTER the timed region (the same workload; never inside the region, so that the sampler cannot perturb `value`)."""
+
+    def __init__(self, index=0):
+        import glob
+        self.files = {}
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
+        if cards:
+            hw = cards[min(index, len(cards) - 1)]
+            for key, name in (('sclk_mhz', 'freq1_input'), ('mclk_mhz', 'freq2_input'), ('power_w', 'power1_input'),
+                              ('power_cap_w', 'power1_cap'), ('temp_c', 'temp2_input')):
+                f = os.path.join(hw, name)
+                if os.path.exists(f):
+                    self.files[key] = f
+            self.level = os.path.join(os.path.dirname(os.path.dirname(hw)), 'power_dpm_force_performance_level')
+        self.samples = {k: [] for k in self.files}
+        self._stop = False
+
+    def _read(self, f):
+        try:
+            return float(open(f).read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _loop(self):
+        scale = {'sclk_mhz': 1e-6, 'mclk_mhz': 1e-6, 'power_w': 1e-6, 'power_cap_w': 1e-6, 'temp_c': 1e-3}
+        while not self._stop:
+            for k, f in self.files.items():
+                v = self._read(f)
+                if v is not None:
+                    self.samples[k].append(v * scale[k])
+            time.sleep(0.015)
+
+    def run(self, step, n, sync):
+        if not self.files:
+            return {"error": "no amdgpu hwmon files on this box"}
+        import threading
+        th = threading.Thread(target=self._loop, daemon=True)
+        sync()
+        th.start()
+        for _ in range(n):
+            step()
+        sync()
+        self._stop = True
+        th.join()
+        out = {"how": "amdgpu hwmon (freq1_input / freq2_input / power1_input / temp2_input) polled every ~15 ms by a thread while "
+                      "%d further f_train steps ran after the timed region" % n, "samples": len(next(iter(self.samples.values()), []))}
+        for k, v in self.samples.items():
+            if v:
+                v = sorted(v)
+                out[k] = {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)} if k != 'power_cap_w' else round(v[0], 1)
+        try:
+            out["power_dpm_force_performance_level"] = open(self.level).read().strip()
+        except OSError:
+            pass
+        return out
 
 
 def log(*a):
@@ -95,11 +159,26 @@ def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample, multithreaded=False):
     params = O.random_params(X.shape[1], hid, C, True, seed=7)
     mask = (np.random.RandomState(3).rand(X.shape[0], hid[0]) < 0.5).astype(np.float32)
     st = O.AdamState(params)
+    n_conv = len(hid)
+    if multithreaded:
+        # the "fair multi-core CPU" of SURVEY.md section 8d: EVERY pass of the step on all cores (oracle/cpu_mt.py::f_train:
+        # sparse products, fused elementwise / softmax / column-sum passes in OpenMP, dense products in BLAS)
+        Xt = sps.csr_matrix(X.T)
+        t0 = time.time()
+        cpu_mt.f_train(O, params, st, X, Xt, Y[tr], Y[dev], A, At, tr, dev, hid, 0.5, mask)
+        t = time.time() - t0
+        return {"value": n_conv * nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": _cpu_model(), "kind": "port",
+                "seconds": round(t, 2),
+                "cores_per_phase": {"sparse products (OpenMP, oracle/cpu_mt.c)": cpu_mt.threads(),
+                                    "bias+tanh / highway mix / softmax / gradients / column sums (OpenMP, oracle/cpu_mt.c)": cpu_mt.threads(),
+                                    "dense products (BLAS sgemm through NumPy)": threads, "Adam on 3.3 M parameters, loss sums (NumPy)": 1},
+                "sample": "1 full f_train step (same workload, same unit: %d conv layers x nnz / step time) on the full %s graph, "
+                          "every pass multi-threaded (oracle/cpu_mt.py::f_train; equals oracle.f_train to rounding: "
+                          "tests/test_oracle.py); a reported baseline, not the target" % (n_conv, shape)}
     with ctx:
         t0 = time.time()
         O.f_train(params, st, X, Y[tr], Y[dev], A, tr, dev, hid, True, 0.5, mask)
         t = time.time() - t0
-    n_conv = len(hid)
     return {"value": n_conv * nnz / t, "unit": "edges/s", "cores": threads, "cpu_model": _cpu_model(), "kind": "port", "seconds": round(t, 2),
             "sample": "1 full f_train step (same workload, same unit: %d conv layers x nnz / step time) on the full %s "
                       "graph; %s, BLAS sgemm uses %d threads" % (n_conv, shape, spmm_note, threads)}
@@ -108,9 +187,14 @@ def cpu_baseline(shape, A, X, Y, tr, dev, hid, C, sample, multithreaded=False):
 def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     """The other hot kernels timed INSIDE real training steps (ops.StepTimers: an event pair around each wrapper call on the
     launch stream, `n_steps` extra steps after the timed region; median over the calls): the step's own operands, cache state
-    and clocks.  HBM-bound ones are priced with their algorithmic bytes, the GEMMs with their flops against the fp32 MFMA peak."""
+    and clocks.  HBM-bound ones are priced with their algorithmic bytes (every operand once; in the bf16
+    configuration the gathered operand of a graph product is 2 bytes per element), GEMMs with their flops against the dense MFMA
+    peak of the precision they run in AND with their operand bytes against HBM (`frac_hbm`): a bf16 product of these shapes is
+    nearer to the second roofline than to the first."""
     from geographconv_amd import ops
     F = hid[0]
+    bf16 = precision == 'bf16'
+    zb = 2 if bf16 else 4                          # bytes per element of the operand a graph product gathers
     with ops.StepTimers() as st:
         for _ in range(n_steps):
             step()
@@ -125,10 +209,13 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ms[key] / 1e6 / HBM_PEAK_GBPS,
                         "calls_per_step": calls[key], "how": how % (calls[key] * n_steps, n_steps), "note": note})
 
-    def mfma(name, key, flops, note=''):
+    def mfma(name, key, flops, operand_bytes, prec, note=''):
         if key in ms:
-            out.append({"kernel": name, "bound": "mfma", "ms": ms[key], "flops": flops, "achieved": flops / ms[key] / 1e9,
-                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / ms[key] / 1e9 / MFMA_F32_PEAK_TFLOPS,
+            peak = MFMA_BF16_PEAK_TFLOPS if prec == 'bf16' else MFMA_F32_PEAK_TFLOPS
+            out.append({"kernel": name, "bound": "mfma", "precision": prec, "ms": ms[key], "flops": flops, "achieved": flops / ms[key] / 1e9,
+                        "peak": peak, "unit": "TFLOP/s", "frac": flops / ms[key] / 1e9 / peak,
+                        "operand_bytes": operand_bytes, "achieved_hbm": operand_bytes / ms[key] / 1e6, "peak_hbm": HBM_PEAK_GBPS,
+                        "unit_hbm": "GB/s", "frac_hbm": operand_bytes / ms[key] / 1e6 / HBM_PEAK_GBPS,
                         "calls_per_step": calls[key], "how": how % (calls[key] * n_steps, n_steps), "note": note})
     X, A = g['X'], g['A']
     nnzX, V, nnz = X.fwd.nnz, X.shape[1], A.fwd.nnz
@@ -138,12 +225,41 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
         xw + 4 * N * F + N * F, "algorithmic bytes = the plain product's + the dropped copy and the byte mask written")
     hbm("X^T . dS0  (head panel GEMM + xt_tail_kernel + combine)", 'spmm_t', 8 * nnzX + 4 * N * F + 4 * V * F)
     hbm("tanh(A_hat . Z + bh) with the highway mix in the epilogue  (spmm_rows_kernel<.., HW> + long-row combine)", 'spmm_highway',
-        spmm_algorithmic_bytes(N, N, nnz, F) + 3 * 4 * N * F, "algorithmic bytes = the plain product's + T, H read and Hout written")
+        spmm_algorithmic_bytes(N, N, nnz, F, zb) + 3 * 4 * N * F,
+        "algorithmic bytes = the plain product's (gathered operand: %d bytes per element) + T, H read and Hout written" % zb)
     fl = 2.0 * N * F * F
-    mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_rows_kernel: 64 whole rows of A per block, dual)", 'gemm_dual_nn', 2 * fl)
-    mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)", 'gemm_dual_tn', 2 * fl)
-    mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl)
+    wb = 4 * F * F                                 # one weight matrix
+    act = 4 * N * F                                # one N x F fp32 activation
+    mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_rows_kernel: 64 whole rows of A per block, dual)", 'gemm_dual_nn', 2 * fl,
+         3 * act + 2 * wb, 'f32')
+    mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)", 'gemm_dual_tn', 2 * fl, 3 * act + 2 * wb, 'f32')
+    mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl,
+         4 * act + 2 * wb, 'f32', "operand bytes: dZ, dU read, the carry read and dH written")
+    # single products (every GEMM of the bf16 / bf16x3 configurations, the output layer's in all): label = shape and form
+    for key in sorted(k for k in ms if k.startswith('gemm:')):
+        _, form, prec, M_, N_, K_, cb, acc = key.split(':')
+        M_, N_, K_, cb, acc = int(M_), int(N_), int(K_), int(cb), int(acc)
+        if 2.0 * M_ * N_ * K_ < 1e9:
+            continue
+        opb = 4 * (M_ * K_ + K_ * N_) + cb * M_ * N_ * (2 if acc else 1)
+        kern = {'f32': 'gemm_kernel', 'bf16x3': 'gemm_bf16_kernel<NS=3>', 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
+        mfma("%s product %d x %d x %d (%s; C %s%s)" % ({'nn': 'A . B', 'nt': 'A . B^T', 'tn': 'A^T . B'}[form], M_, N_, K_, kern,
+                                                         'bf16' if cb == 2 else 'fp32', ', accumulating' if acc else ''),
+             key, 2.0 * M_ * N_ * K_, opb, 'bf16' if prec == 'bf16' else 'f32',
+             "bf16x3 is priced against the fp32 peak (its result is fp32-class)" if prec == 'bf16x3' else '')
     return out
+
+
+def baseline_config(shape, hid, precision, world):
+    """Which entry of BASELINE.json `configs` this invocation is -- or that it is none of them."""
+    hid = list(hid)
+    if shape == 'cmu' and hid == [300, 300, 300] and precision == 'f32' and world == 1:
+        return 'BASELINE configs[1]'
+    if shape == 'twus' and hid == [300, 300, 300] and precision == 'f32':
+        return 'BASELINE configs[2]' if world == 1 else 'BASELINE configs[3]'
+    if shape == 'twus' and hid == [600] * 6 and precision == 'bf16':
+        return 'BASELINE configs[4]' + ('' if world == 8 else ' on %d GPU%s instead of 8' % (world, '' if world == 1 else 's'))
+    return 'NOT a BASELINE config: a variant (shape %s, hid %s, GEMM precision %s)' % (shape, 'x'.join(map(str, hid)), precision)
 
 
 def _free_port():
@@ -376,8 +492,9 @@ def main():
                 pm = json.load(open(pmc_file))
                 traffic = pm.get('hbm_bytes_per_launch')
                 traffic_source = ("NOT measured in this run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of this command "
-                                  "at state %s, %s; 2 x FETCH_SIZE + WRITE_SIZE per launch; the counter tallies L2 -> fabric requests, "
-                                  "Infinity-Cache hits included" % (pm.get('state', 'r01_h'), os.path.relpath(pmc_file, ROOT)))
+                                  "at state %s (commit %s; table %s), %s; 2 x FETCH_SIZE + WRITE_SIZE per launch; the counter tallies "
+                                  "L2 -> fabric requests, Infinity-Cache hits included" % (pm.get('state'), pm.get('commit'), pm.get('summary'),
+                                                                                         os.path.relpath(pmc_file, ROOT)))
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> + spmm_long_reduce_kernel (A_hat^T . dS, F=%d%s)" % (
@@ -396,6 +513,12 @@ def main():
                                                    args.gemm_precision)
             except Exception as e:                       # evidence only: never fail the headline line over it
                 roofline["others_error"] = repr(e)
+        clocks = None
+        if world == 1:
+            try:
+                clocks = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 10, torch.cuda.synchronize)
+            except Exception as e:
+                clocks = {"error": repr(e)}
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
         dist_info = None
         if world > 1 or force_dist:
@@ -410,11 +533,11 @@ def main():
                         "p90": step_ms[int(round(0.9 * (len(step_ms) - 1)))], "min": step_ms[0], "max": step_ms[-1],
                         "how": "torch.cuda.Event after every step of the timed region (device time between consecutive steps)"},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.gemm_precision != "bf16" else "bf16", "data": "synthetic",
-            "config": {"workload": "%s synthetic CSR (BASELINE configs[2]%s): N=%d, nnz(A_hat)=%d, "
+            "config": {"workload": "%s synthetic CSR (%s): N=%d, nnz(A_hat)=%d, "
                                    "X %dx%d nnz=%d, C=%d; %s highway GCN, dropout %.2f, Adam; full-graph f_train step"
                                    % ({'twus': 'TwitterUS-shape power-law', 'cmu': 'CMU-shape power-law',
                                        'twus_sbm': 'TwitterUS-size community-structured'}[args.shape],
-                                      '' if args.shape == 'twus' else ' shape variant', N, nnz, N, X.shape[1], X.nnz, C,
+                                      baseline_config(args.shape, args.hid, args.gemm_precision, world), N, nnz, N, X.shape[1], X.nnz, C,
                                       'x'.join(map(str, args.hid)), args.dropout),
                        "edges_per_step": n_conv * nnz,
                        "edges_traversed_per_step": 2 * (n_conv - 1) * nnz + nnz + nnz_bwd_out,
@@ -429,6 +552,7 @@ def main():
                                 "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
                        "train_loss_last": float(last[0])},
             "roofline": roofline,
+            "clocks": clocks,
         }
         if alt is not None:
             out["alt"] = alt

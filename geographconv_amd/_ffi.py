@@ -114,6 +114,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 2          # == GEOGCN_ABI_VERSION of include/geogcn.h (tests/test_abi.py holds the two together)
+
+
 def header_symbols():
     """Every function name include/geogcn.h declares."""
     with open(HEADER_PATH) as f:
@@ -145,8 +148,9 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.geogcn_version() != 1:
-        raise GeoGcnError("libgeogcn.so ABI version %d != 1" % handle.geogcn_version())
+    if handle.geogcn_version() != ABI_VERSION:
+        raise GeoGcnError("libgeogcn.so ABI version %d != %d (a stale library: python -m geographconv_amd.build --force)"
+                          % (handle.geogcn_version(), ABI_VERSION))
     _lib = handle
     return _lib
 

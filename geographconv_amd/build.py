@@ -18,8 +18,9 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libgeogcn.so')
 SOURCES = ['core.hip', 'spmm.hip', 'spmm_hot.hip', 'xt.hip', 'gemm.hip', 'gemm_bf16.hip', 'elementwise.hip', 'softmax_adam.hip', 'comm.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
-         '-Wall', '-Wno-unused-function']
+# (no -munsafe-fp-atomics: the two float atomics of the library -- softmax_adam.hip, exact by construction -- ask for the
+#  hardware add themselves with unsafeAtomicAdd; any future atomicAdd gets the safe default)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # ablation / experiment builds: GEOGCN_BUILD_DEFINES="GEOGCN_BF16_PROBE_BUILD ..." python -m geographconv_amd.build --force
 FLAGS += ['-D' + d for d in os.environ.get('GEOGCN_BUILD_DEFINES', '').split()]
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(TPB) void ce_bwd_kernel(int C, const float* __restr
     const int yy = y[j];
     for (int c = lane; c < C; c += kWave) {
         const float g = (P[row * ldp + c] - (c == yy ? 1.0f : 0.0f)) * inv_n;
-        atomicAdd(D + row * ldd + c, g);
+        unsafeAtomicAdd(D + row * ldd + c, g);      // the hardware fp32 add, chosen HERE (exact: see above), not by a build-wide flag
     }
 }
 
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(TPB) void ce_bwd_db_kernel(int C, const float* __re
             if (c < C) {
                 const float g = (P[row * ldp + c] - (c == yy ? 1.0f : 0.0f)) * inv_n;
                 if constexpr (COMPACT) D[j * ldd + c] = g;
-                else atomicAdd(D + row * ldd + c, g);
+                else unsafeAtomicAdd(D + row * ldd + c, g);     // (adds onto zero / k identical values: exact, order-free)
                 acc[k] += g;
             } else if (COMPACT && c < cpad) {
                 D[j * ldd + c] = 0.f;

@@ -76,8 +76,11 @@ class _TargetRows:
             tape[self]['n_full'] = y.n
             # identity of the index vector for the backward's cached S^T: content for host vectors, the tensor itself
             # for device tensors
-            tape[self]['target_key'] = ('t', id(idx), int(idx.data_ptr())) if not isinstance(idx, (np.ndarray, list, tuple)) \
+            # (a tensor's identity alone is not enough: freed tensors hand their id and address on, in-place edits keep both --
+            #  the key carries the version counter and the cache entry keeps the tensor itself alive)
+            tape[self]['target_key'] = ('t', id(idx), int(idx.data_ptr()), int(idx._version)) if not isinstance(idx, (np.ndarray, list, tuple)) \
                 else ('h', _content_key(np.asarray(idx)))
+            tape[self]['target_src'] = idx
         return out
 
     def backward(self, grad, tape, into, **kwargs):
@@ -86,11 +89,12 @@ class _TargetRows:
         if s.get('target_idx') is not None:
             if isinstance(grad, L.PreAct):
                 raise NotImplementedError("a fused pre-activation gradient cannot pass through a row gather")
-            grad = K.spmm(_selection_transpose_for(self, s['target_idx'], s['n_full'], grad.device, s.get('target_key')), grad)
+            grad = K.spmm(_selection_transpose_for(self, s['target_idx'], s['n_full'], grad.device, s.get('target_key'),
+                                                   s.get('target_src')), grad)
         return super().backward(grad, tape, into, **kwargs)
 
 
-def _selection_transpose_for(layer, t_idx, n_full, device, ident=None):
+def _selection_transpose_for(layer, t_idx, n_full, device, ident=None, src=None):
     """S^T (row = node, column = position in the index vector) as a device CSR, built ONCE per index vector and kept on
     the layer: building it means a device-to-host copy, a host CSR and a plan allocation -- a sync and a hipMalloc that
     must not happen every step (and would invalidate a hipGraph capture)."""
@@ -101,7 +105,7 @@ def _selection_transpose_for(layer, t_idx, n_full, device, ident=None):
     idx = t_idx.cpu().numpy().astype(np.int64)
     sel_t = sps.csr_matrix((np.ones(len(idx), dtype=np.float32), (idx, np.arange(len(idx)))), shape=(n_full, len(idx)))
     csr = backend.active().CSR(sel_t, device)
-    layer._sel_t = (key, t_idx, csr)
+    layer._sel_t = (key, t_idx, csr, src)         # `src`: the caller's own index object, pinned so that its id stays its own
     return csr
 
 
@@ -281,7 +285,8 @@ class MultiplicativeGatingLayer(L.MergeLayer):
         # (saves the fp32 write and the cast pass over it; the exchange of a partitioned graph stages fp32 and keeps the cast)
         s16 = (tuning.FUSE_BF16_DS and K.bf16_gather(kwargs.get('gemm_precision')) and kwargs.get('comm') is None
                and kwargs.get('A') is not None and isinstance(h1_l, ConvolutionDenseLayer2)
-               and hasattr(K, 'highway_bwd_bf16_ok') and K.highway_bwd_bf16_ok(grad, fuse_b))
+               and (fuse_b or h1_l.b is None)       # (an un-fused bias gradient would take the column sums of a bf16 matrix)
+               and K.highway_bwd_bf16_ok(grad, fuse_b))
         dS, dU, dH = K.highway_bwd(grad, t, h1, h2, dbS=h1_l.b.grad if fuse_b else None,
                                    dbU=gate_l.b.grad if fuse_b else None, **({'dS_bf16': True} if s16 else {}))
         if into[2] is not None:
@@ -695,12 +700,12 @@ class GraphConv():
         fuse_db = self.l_out.b is not None and self.l_out.b.grad is not None and P.F <= 1024
         # dlogits is zero outside the training rows: A^T . dlogits only needs the training COLUMNS of A^T -- and, on one
         # GPU, only the training ROWS of dlogits are ever formed (compact: n_train x C instead of a zero-filled N x C)
-        A_tr, compact = self._train_columns_operand(g, A, train_indices)
-        if compact and fuse_db:
+        # (ONE call: the cache holds one operand per graph, and the compact kernel needs the fused bias gradient -- asking
+        #  for the compact form first and the plain one after it would rebuild both, with their plans, every step)
+        A_tr, compact = self._train_columns_operand(g, A, train_indices, allow_compact=fuse_db)
+        if compact:
             dlogits = K.softmax_ce_rows_bwd(P, tr_idx, tr_y, 1.0 / max(1, n_tr), self.l_out.b.grad)
         else:
-            if compact:
-                A_tr = self._train_columns_operand(g, A, train_indices, allow_compact=False)[0]
             dlogits = K.softmax_ce_bwd(P, tr_idx, tr_y, inv_n=1.0 / max(1, n_tr),
                                        out=K.DMat.empty(P.n, P.F, P.device, ld=K.gather_ld(P.F)),
                                        **({'db': self.l_out.b.grad} if fuse_db else {}))

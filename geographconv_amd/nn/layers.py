@@ -349,8 +349,10 @@ class DenseLayer(Layer):
         mask and stores both the activation and its dropped copy; the DropoutLayer then only picks the result up."""
         K = backend.active()
         drop = getattr(self, 'dropout_consumer', None)
+        # (only when that DropoutLayer is part of THIS evaluation -- get_output passes the layer set --: drawing its mask for
+        #  a sub-network that stops below it would advance its Philox stream once too often)
         if (drop is not None and tape is not None and not kwargs.get('deterministic', False) and drop.p > 0 and drop.rescale
-                and tuning.FUSE_DROPOUT):
+                and tuning.FUSE_DROPOUT and drop in kwargs.get('evaluated_layers', ())):
             injected = kwargs.get('dropout_mask')
             n = input.shape[0]
             pos = {} if injected is not None else drop.stream_position(n, self.num_units, self.W.data.device, kwargs)
@@ -567,6 +569,8 @@ class DropoutLayer(Layer):
             tape[self] = {'mask': pre[2]}              # the layer below already drew the mask and applied it
             return pre[1]
         mask = dropout_mask
+        if mask is None and pre is not None:
+            mask = pre[2]        # drawn for this pass already (the stream has moved on), but applied to another tensor: reuse, do not redraw
         if mask is None:
             pos = self.stream_position(input.n, input.F, input.device, dict(kwargs))
             if 'calls_dev' in pos:
@@ -692,6 +696,7 @@ def get_output(layer_or_layers, inputs=None, tape=None, **kwargs):
             raise ValueError("a bare input value needs a network with exactly one InputLayer")
         values[ins[0]] = inputs
     started = set()
+    kwargs = dict(kwargs, evaluated_layers=frozenset(all_layers))       # (fusions across layers ask whether their partner takes part)
     for pos, layer in enumerate(all_layers):
         if layer in values:
             continue

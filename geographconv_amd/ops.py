@@ -368,6 +368,15 @@ GEMM_PRECISIONS = {'f32': _ffi.GEMM_F32, 'bf16x3': _ffi.GEMM_BF16X3, 'bf16': _ff
 GEMM_PRECISION = tuning.GEMM_PRECISION
 
 
+def _gemm_label(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None):
+    # 'gemm:<form>:<precision>:<M>:<N>:<K>:<bytes per element of C>:<accumulate>' (bench.py prices the entry from it)
+    M, K = (A.F, A.n) if transA else (A.n, A.F)
+    N = B.n if transB else B.F
+    return 'gemm:%s:%s:%d:%d:%d:%d:%d' % ('tn' if transA else 'nt' if transB else 'nn', precision or GEMM_PRECISION, M, N, K,
+                                          2 if isinstance(out, HMat) or (isinstance(out, Panels) and out.bf16) else 4, int(bool(accumulate)))
+
+
+@_timed(_gemm_label)
 def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=None, act=ACT_NONE,
          accumulate=False, precision=None):
     """out = act(op(A) . op(B) + bias) [+ out]  -- T.dot / Gemm (reference gcnmodel.py:126,149,285)."""
@@ -940,6 +949,9 @@ def spmm_x_dropout(x: SparseOperand, W: DMat, bias, act, p, mask_in=None, seed=0
     if hot is None:
         hot = x._hot[cap] = HotCSR(x.fwd, x.fwd.val.cpu().numpy(), cap)
     n = hot.shape[0]
+    if mask_in is not None and not (isinstance(mask_in, torch.Tensor) and mask_in.dtype == torch.uint8 and tuple(mask_in.shape) == (n, W.F)
+                                    and mask_in.is_contiguous() and mask_in.device == W.t.device):
+        return None              # the kernel reads 32-bit words at mask + row * F + 4 q: anything else goes to the separate kernels
     H0, Hd = DMat.empty(n, W.F, W.device), DMat.empty(n, W.F, W.device)
     mask = mask_in if mask_in is not None else torch.empty((n, W.F), dtype=torch.uint8, device=W.device)
     check(lib.geogcn_spmm_csr_hot_dropout_f32(n, _p(hot.rowptr), _p(hot.rowsplit), _p(hot.colidx), _p(hot.val), _p(W.t), W.ld,

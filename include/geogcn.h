@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define GEOGCN_ABI_VERSION 1
+/* 2: round 3 changed exported signatures incompatibly (geogcn_spmm_plan_create: chunks_with_owner instead of a rowsplit pointer;
+ * geogcn_gemm_kcat_f32: ws / ws_bytes before stream; geogcn_spmm_plan_attach_timer replaced geogcn_timer_attach_spmm). */
+#define GEOGCN_ABI_VERSION 2
 
 #define GEOGCN_E_NULL   (-1)   /* required pointer is NULL            */
 #define GEOGCN_E_SIZE   (-2)   /* negative / inconsistent size        */

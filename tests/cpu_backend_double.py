@@ -55,6 +55,10 @@ def bf16_gather(precision=None):
     return False          # the double computes everything in fp32
 
 
+def highway_bwd_bf16_ok(G, with_bias):
+    return False
+
+
 def spmm(A, B, out=None, bias=None, act=ACT_NONE, F=None):
     F = B.F if F is None else F
     if out is None:

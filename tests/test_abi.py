@@ -28,9 +28,15 @@ def test_library_exports_every_declared_symbol(built):
     assert not extra, extra
 
 
+def header_abi_version():
+    import re
+    with open(_ffi.HEADER_PATH) as f:
+        return int(re.search(r'^#define GEOGCN_ABI_VERSION (\d+)', f.read(), flags=re.M).group(1))
+
+
 def test_library_loads_and_reports_version(built):
     lib = _ffi.lib()
-    assert lib.geogcn_version() == 1
+    assert lib.geogcn_version() == _ffi.ABI_VERSION == header_abi_version()
     assert isinstance(lib.geogcn_last_error(), bytes)
 
 

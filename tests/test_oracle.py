@@ -174,6 +174,33 @@ def test_multithreaded_cpu_leg_equals_the_oracle_products():
     assert O.spmm_t(A, G).dtype == np.float32 and O.spmm.__name__ == 'spmm'      # restored
 
 
+def test_multithreaded_cpu_step_equals_the_oracle_step():
+    """oracle/cpu_mt.py::f_train (bench.py's `cpu_baseline_mt`: every pass of the step on all cores) against oracle.f_train:
+    three steps with and without dropout -- losses, hit counts, probabilities, every gradient, the Adam update."""
+    import scipy.sparse as sps
+    from oracle import cpu_mt
+    cpu_mt.build()
+    A, X, Y = synth.small_graph(1500, 6.0, 200, 12, 9, seed=3)
+    hid = [24, 24, 24]
+    params = O.random_params(200, hid, 9, True, seed=4)
+    tr, dev = np.arange(0, 900), np.arange(900, 1200)
+    mask = (np.random.RandomState(5).rand(1500, 24) < 0.5).astype(np.float32)
+    At, Xt = sps.csr_matrix(A.T), sps.csr_matrix(X.T)
+    for p in (0.5, 0.0):
+        st1, st2 = O.AdamState(params), O.AdamState(params)
+        cur1, cur2 = [q.copy() for q in params], [q.copy() for q in params]
+        for step in range(3):
+            cur1, o1, g1 = O.f_train(cur1, st1, X, Y[tr], Y[dev], A, tr, dev, hid, True, p, mask)
+            cur2, o2, g2 = cpu_mt.f_train(O, cur2, st2, X, Xt, Y[tr], Y[dev], A, At, tr, dev, hid, p, mask)
+            assert abs(o1[0] - o2[0]) <= 2e-6 * abs(o1[0]) and abs(o1[2] - o2[2]) <= 2e-6 * abs(o1[2])
+            assert o1[1] == o2[1] and o1[3] == o2[3]
+            assert np.abs(o1[4] - o2[4]).max() <= 1e-6
+            for a, b in zip(g1, g2):
+                assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max() + 1e-10
+            for a, b in zip(cur1, cur2):
+                assert np.abs(a - b).max() <= 2e-3 * 0.02 + 1e-7
+
+
 def test_bf16_aware_mode_rounds_where_the_bf16_configuration_rounds():
     """`gemm_operands='bf16'` (BASELINE configs[4]; no reference counterpart): RNE rounding incl. ties, idempotence, a dense
     product whose operands are already bf16 is unchanged, the mode stays within a bf16-class distance of the fp32 forward,

@@ -14,7 +14,7 @@ cd $ROOT
 if [ "${1:-}" = build ]; then
   mkdir -p /tmp/asan_obj
   for f in core spmm spmm_hot xt gemm gemm_bf16 elementwise softmax_adam comm; do
-    hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -munsafe-fp-atomics -fsanitize=address -fno-gpu-sanitize \
+    hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize \
       -fno-omit-frame-pointer -Wno-unused-function -c geographconv_amd/csrc/$f.hip -o /tmp/asan_obj/$f.o || exit 1 &
   done
   wait
