@@ -83,20 +83,30 @@ class ClockSampler:
                     self.samples[k].append(v * scale[k])
             time.sleep(0.015)
 
-    def run(self, step, n, sync):
+    def run(self, step, seconds, sync):
+        """Steps for `seconds` of wall time (the SMU's power / clock telemetry is a moving average over roughly a second: ten steps
+        would report the idle state before them), sampling throughout; the figures of the LAST second are reported."""
         if not self.files:
             return {"error": "no amdgpu hwmon files on this box"}
         import threading
         th = threading.Thread(target=self._loop, daemon=True)
         sync()
         th.start()
-        for _ in range(n):
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
             step()
+            n += 1
+            if n % 8 == 0:
+                sync()               # (keeps the launch queue short, so that wall time tracks device time)
         sync()
         self._stop = True
         th.join()
+        wall = time.perf_counter() - t0
+        keep = max(1, int(len(next(iter(self.samples.values()), [])) * min(1.0, 1.0 / wall)))
+        self.samples = {k: v[-keep:] for k, v in self.samples.items()}
         out = {"how": "amdgpu hwmon (freq1_input / freq2_input / power1_input / temp2_input) polled every ~15 ms by a thread while "
-                      "%d further f_train steps ran after the timed region" % n, "samples": len(next(iter(self.samples.values()), []))}
+                      "%d further f_train steps ran for %.1f s after the timed region; min / median / max over the last second (the "
+                      "SMU telemetry is a moving average)" % (n, wall), "samples": keep}
         for k, v in self.samples.items():
             if v:
                 v = sorted(v)
@@ -516,7 +526,7 @@ def main():
         clocks = None
         if world == 1:
             try:
-                clocks = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 10, torch.cuda.synchronize)
+                clocks = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 3.0, torch.cuda.synchronize)
             except Exception as e:
                 clocks = {"error": repr(e)}
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz

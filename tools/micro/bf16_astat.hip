@@ -506,7 +506,7 @@ __global__ __launch_bounds__(NCW * 64 + 256, 1) void astat_lc_kernel(const float
             const int64_t m0 = (int64_t)((int)blockIdx.x + i * (int)gridDim.x) * BM;
             const unsigned char* Ab = As + (i & 1) * (BM * PITCH);
 #pragma unroll 1
-            for (int ps = 0; ps < PASSES; ++ps) {
+            for (int ps = 0; ps < ((PROBE & 8) ? 0 : PASSES); ++ps) {       // PROBE 8: the consumers only keep the barriers
                 const int ncol0 = (wid * PASSES + ps) * WCT * 16;
                 f32x4 acc[MR][WCT];
 #pragma unroll
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(NCW * 64 + 256, 1) void astat_lc_kernel(const float
                     for (int j = 0; j < WCT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 auto bload = [&](bf16x8 (&b)[WCT], int kt) {
                     const int kk = (PROBE & 1) ? 0 : (kt < NK ? kt : NK - 1);      // PROBE 1: one (L1-resident) fragment set
+                    if ((PROBE & 16) && kt >= DEPTH) return;                        // PROBE 16: no B loads after the prologue
 #pragma unroll
                     for (int j = 0; j < WCT; ++j)
                         b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((PROBE & 1) ? j : ncol0 / 16 + j) * NK + kk) * 1024, 0));
@@ -522,7 +523,13 @@ __global__ __launch_bounds__(NCW * 64 + 256, 1) void astat_lc_kernel(const float
                 auto kstep = [&](const bf16x8 (&b)[WCT], int kt) {
                     bf16x8 af[MR];
 #pragma unroll
-                    for (int a = 0; a < MR; ++a) af[a] = *reinterpret_cast<const bf16x8*>(Ab + (a * 16 + li) * PITCH + kt * 64 + lg * 16);
+                    for (int a = 0; a < MR; ++a)          // PROBE 32: one LDS fragment per row tile, whatever the k-step
+                        af[a] = *reinterpret_cast<const bf16x8*>(Ab + (a * 16 + li) * PITCH + ((PROBE & 32) ? 0 : kt) * 64 + lg * 16);
+                    if (PROBE & 64) {                     // PROBE 64: no MFMAs (the operands are consumed by one add each)
+#pragma unroll
+                        for (int j = 0; j < WCT; ++j) acc[0][j][0] += __builtin_bit_cast(f32x4, b[j])[0] + __builtin_bit_cast(f32x4, af[j % MR])[1];
+                        return;
+                    }
 #pragma unroll
                     for (int j = 0; j < WCT; ++j)
 #pragma unroll
@@ -552,6 +559,148 @@ __global__ __launch_bounds__(NCW * 64 + 256, 1) void astat_lc_kernel(const float
                 }
             }
             __syncthreads();
+        }
+    }
+}
+
+
+// ---- round 4, second form: 128 rows per tile -------------------------------------------------------------------------------------
+// What the probes above showed: per 64-row tile a CU pulls the WHOLE weight matrix (760 KB in fragment order) from L2 -- five times
+// the bytes of A -- and that L2 -> L1 stream, not missing overlap, is what the tile phases wait on.  The only lever is rows per tile:
+// 128 rows halve it.  LDS then holds ONE buffer (128 x 1,232 B = 157.7 KB), so the loader waves keep the NEXT tile in registers,
+// already rounded to bf16 (76 uint2 per thread), and write it to LDS between two barriers when the consumers are done with the
+// current one (~1 us of a ~30 us tile).  Consumers: 8 x 5 tiles of 16 x 16 per wave and pass = 160 accumulator registers, A
+// fragments read in two halves of four, B one step ahead.
+template <int KP, int PROBE = 0>
+__global__ __launch_bounds__(512, 1) void astat_lc128_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+                                                             const unsigned short* __restrict__ Bp, int N, float* __restrict__ C,
+                                                             int64_t ldc, int n_mt) {
+    constexpr int BM = 128, WCT = 5, PITCH = KP * 2 + 16, F4R = KP / 4, MR = BM / 16, NK = KP / 32;
+    constexpr int NL = 256, PIECES = BM * F4R / NL, SLOTS = 8;
+    static_assert(BM * F4R % NL == 0, "a tile must divide over the loader threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char As[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_my = blockIdx.x < (unsigned)n_mt ? (n_mt - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (wid >= 4) {
+        const int K4 = (K + 3) & ~3;
+        const uint32_t ld4 = (uint32_t)lda * 4u;
+        auto tile_rsrc = [&](int i) {
+            const int mt = (int)blockIdx.x + i * (int)gridDim.x;
+            const bool ok = i < n_my;
+            const int64_t m0 = ok ? (int64_t)mt * BM : 0;
+            const int64_t rows_left = ok ? M - m0 : 0;
+            const uint64_t base = reinterpret_cast<uint64_t>(A + m0 * lda);
+            const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+            const int64_t nbytes = (rows_left < BM ? rows_left : BM) * lda * 4;
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000);
+        };
+        uint2 hold[PIECES];
+        auto fetch = [&](int i) {              // tile i: HBM -> fp32 staging slots -> bf16 pairs in `hold`
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(i);
+            int tt = tid - 256;
+            asm volatile("" : "+v"(tt));
+            f32x4 st[SLOTS];
+            auto req = [&](int q) {
+                const int idx = tt + NL * q;
+                const int r = idx / F4R, c = idx - r * F4R;
+                const uint32_t off = c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : 0x80000000u;
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+            };
+            if (PROBE & 2) {
+#pragma unroll
+                for (int q = 0; q < PIECES; ++q) hold[q] = make_uint2(0u, 0u);
+                return;
+            }
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) st[q] = req(q);
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                const f32x4 v = st[q % SLOTS];
+                hold[q].x = bf16_pack(v[0], v[1]);
+                hold[q].y = bf16_pack(v[2], v[3]);
+                if (q + SLOTS < PIECES) st[q % SLOTS] = req(q + SLOTS);
+            }
+        };
+        auto flush = [&]() {                   // `hold` -> LDS
+            int tt = tid - 256;
+            asm volatile("" : "+v"(tt));
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                const int idx = tt + NL * q;
+                const int r = idx / F4R, c = idx - r * F4R;
+                *reinterpret_cast<uint2*>(As + r * PITCH + c * 8) = hold[q];
+            }
+        };
+        fetch(0);
+        flush();
+        __syncthreads();                        // B0: tile 0 in LDS
+#pragma unroll 1
+        for (int i = 0; i < n_my; ++i) {
+            fetch(i + 1);                       // while the consumers multiply tile i
+            __syncthreads();                    // A: consumers are done with the LDS tile
+            flush();
+            __syncthreads();                    // B: tile i+1 in LDS
+        }
+    } else {
+        const int li = lane & 15, lg = lane >> 4;
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, 640 * KP * 2, 0x00020000);
+        __syncthreads();                        // B0
+#pragma unroll 1
+        for (int i = 0; i < n_my; ++i) {
+            const int64_t m0 = (int64_t)((int)blockIdx.x + i * (int)gridDim.x) * BM;
+#pragma unroll 1
+            for (int ps = 0; ps < 2; ++ps) {
+                const int ncol0 = (wid * 2 + ps) * WCT * 16;
+                f32x4 acc[MR][WCT];
+#pragma unroll
+                for (int a = 0; a < MR; ++a)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto bload = [&](bf16x8 (&b)[WCT], int kt) {
+                    const int kk = (PROBE & 1) ? 0 : (kt < NK ? kt : NK - 1);
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j)
+                        b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((PROBE & 1) ? j : ncol0 / 16 + j) * NK + kk) * 1024, 0));
+                };
+                auto kstep = [&](const bf16x8 (&b)[WCT], int kt) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bf16x8 af[4];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) af[a] = *reinterpret_cast<const bf16x8*>(As + ((h * 4 + a) * 16 + li) * PITCH + kt * 64 + lg * 16);
+#pragma unroll
+                        for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+                                acc[h * 4 + a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], af[a], acc[h * 4 + a][j], 0, 0, 0);
+                    }
+                };
+                bf16x8 ring[2][WCT];
+                bload(ring[0], 0);
+#pragma unroll 1
+                for (int k0 = 0; k0 < NK; k0 += 2) {
+                    bload(ring[1], k0 + 1);
+                    kstep(ring[0], k0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bload(ring[0], k0 + 2);
+                    if (k0 + 1 < NK) kstep(ring[1], k0 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int a = 0; a < MR; ++a) {
+                    const int64_t row = m0 + a * 16 + li;
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) {
+                        const int col0 = ncol0 + j * 16 + lg * 4;
+                        if ((PROBE & 4) ? (acc[a][j][0] == 123.4f) : (row < M && col0 < N))
+                            *reinterpret_cast<float4*>(C + row * ldc + col0) = make_float4(acc[a][j][0], acc[a][j][1], acc[a][j][2], acc[a][j][3]);
+                    }
+                }
+            }
+            __syncthreads();                    // A
+            __syncthreads();                    // B
         }
     }
 }
@@ -710,6 +859,44 @@ static void run_lc(const char* name, const float* dA, int64_t lda, int64_t M, in
            bytes / ms / 1e9, worst);
 }
 
+template <int KP, int PROBE>
+static void run_lc128(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC, int64_t ldc,
+                      const std::vector<float>& hA, const std::vector<unsigned short>& hB, int grid) {
+    constexpr int PITCH = KP * 2 + 16, BM = 128;
+    const int n_mt = (int)((M + BM - 1) / BM);
+    const size_t lds = (size_t)BM * PITCH;
+    auto kern = astat_lc128_kernel<KP, PROBE>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(dC, 0, (size_t)M * ldc * 4));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    double worst = 0;
+    const int64_t rows[] = {0, 1, 63, 64, 127, 128, 12345, 16384 + 77, 128 * 256 * 7 + 5, M - 129, M - 65, M - 1};
+    std::vector<float> hc(N);
+    for (int64_t r : rows) {
+        CK(hipMemcpy(hc.data(), dC + r * ldc, (size_t)N * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            double sacc = 0;
+            for (int k = 0; k < K; ++k) sacc += (double)bf(rne(hA[r * lda + k])) * (double)bf(hB[(size_t)n * KP + k]);
+            worst = fmax(worst, fabs(sacc - hc[n]) / (1e-3 + fabs(sacc)));
+        }
+    }
+    const double flops = 2.0 * M * N * K, bytes = 4.0 * M * (K + N);
+    printf("%-34s grid %4d  lds %6zu B  %.3f ms  %.0f TF  %.2f TB/s of A + C   max rel err %.2e\n", name, grid, lds, ms, flops / ms / 1e9,
+           bytes / ms / 1e9, worst);
+}
+
 int main() {
     const int64_t M = 440000;
     const int K = 600, N = 600, KP = 608, NP = 640;
@@ -744,11 +931,16 @@ int main() {
     for (int grid : {512}) {
         run<608, 64, 5, 2, 2, 1>("BM 64, 2x5, B fragment order, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
         run_lc<608, 5, 2, 4, 0>("LC 4 consumers x 2 passes, B 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
-        run_lc<608, 5, 2, 4, 1>("  probe: B fragments L1-resident", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
-        run_lc<608, 5, 2, 4, 3>("  probe: B L1-resident, no A loads", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
-        run_lc<608, 5, 2, 4, 5>("  probe: B L1-resident, no C stores", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
-        run_lc<608, 5, 2, 4, 7>("  probe: B L1-resident, MFMA only", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
-        run<608, 64, 5, 2, 2, 1, 1>("baseline, B fragments L1-resident", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
+        run_lc<608, 5, 2, 4, 8>("probe: loaders alone", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 4>("no C stores (MFMA + LDS + B from L2)", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 4 + 1>("  ... B L1-resident", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 4 + 16>("  ... no B loads", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 4 + 16 + 32>("  ... no B loads, A frags cached", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 4 + 64>("  ... B from L2 + LDS reads, no MFMA", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 4 + 64 + 32>("  ... B from L2 only, no MFMA", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 2 + 4>("consumers alone: MFMA + LDS + B from L2", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 2 + 4 + 64>("consumers alone: B from L2 + LDS, no MFMA", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
+        run_lc<608, 5, 2, 4, 2 + 4 + 16>("consumers alone: MFMA + LDS, no B loads", dA, lda, M, K, dF, N, dC, ldc, hA, hB, 256);
         run<608, 64, 5, 2, 2, 1>("BM 64, 2x5, B fragment order, 2 ahead", dA, lda, M, K, dF, N, dC, ldc, hA, hB, grid);
     }
     {

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restri
     const int K4 = (K + 3) & ~3;
     const uint32_t ld4 = (uint32_t)lda * 4u;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bf), 0, 4 * passes * WCT * NK * 1024, 0x00020000);
+    f32x4 ring[DEPTH + 1][WCT];
     for (int mt = blockIdx.x; mt < n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
         {
@@ -75,12 +76,13 @@ __global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restri
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto bload = [&](f32x4 (&b)[WCT], int kt) {
+            auto bload_at = [&](f32x4 (&b)[WCT], int t0, int kt) {
                 const int kk = kt < NK ? kt : NK - 1;
 #pragma unroll
                 for (int j = 0; j < WCT; ++j)
-                    b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
+                    b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((t0 + j) * NK + kk) * 1024, 0));
             };
+            auto bload = [&](f32x4 (&b)[WCT], int kt) { bload_at(b, tile0, kt); };
             auto kstep = [&](const f32x4 (&b)[WCT], int kt) {
                 f32x4 af[MR];
 #pragma unroll
@@ -92,9 +94,14 @@ __global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restri
 #pragma unroll
                         for (int i = 0; i < MR; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][t], af[i][t], acc[i][j], 0, 0, 0);
             };
-            f32x4 ring[D1][WCT];
+            // PROBE 16 ("early"): the first DEPTH fragment sets of a pass are requested BEFORE the stores of the pass in front of it
+            // (gfx9 retires loads and stores through ONE in-order counter: a fragment requested behind 20 stores is not usable
+            // until every one of them has been acknowledged; requested ahead of them it is, and DEPTH steps of MFMAs -- 2 x 2,560
+            // cycles -- then run while the stores drain)
+            if (!(PROBE & 16) || (ps == 0 && mt == (int)blockIdx.x)) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+                for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+            }
 #pragma unroll 1
             for (int k0 = 0; k0 < NK; k0 += D1) {
 #pragma unroll
@@ -103,6 +110,12 @@ __global__ __launch_bounds__(256, 2) void astat_f32_kernel(const float* __restri
                     if (k0 + u < NK) kstep(ring[u], k0 + u);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (PROBE & 16) {
+                const int nt0 = (wid * passes + (ps + 1 < passes ? ps + 1 : 0)) * WCT;
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) bload_at(ring[d], nt0, d);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
@@ -323,13 +336,12 @@ int main() {
         CK(hipMalloc(&dF, hF.size() * 4));
         CK(hipMemcpy(dF, hF.data(), hF.size() * 4, hipMemcpyHostToDevice));
         printf("N = %d (%.1f GFLOP)\n", N, 2.0 * M * N * K / 1e9);
-        run<304, 64, 5, 1, 0>("whole rows, B 1 step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
-        run_pf<304, 64, 5, 2>("next tile's rows prefetched into registers", dA, lda, M, K, dF, N, dC, N, 512);
-        run_pf<304, 64, 5, 1>("  ... B 1 step ahead", dA, lda, M, K, dF, N, dC, N, 512);
-        run<304, 64, 5, 2, 8>("whole rows, non-temporal C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 16>("  requests before the stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 1, 16>("  requests before the stores, 1 ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 3, 16>("  requests before the stores, 3 ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
-        run<304, 64, 5, 2, 2>("  ablation: no A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<304, 64, 5, 2, 16>("  requests before the stores (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 4>("  ablation: no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<304, 64, 5, 2, 6>("  ablation: MFMAs + LDS + B only", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         CK(hipFree(dF));
