@@ -366,7 +366,7 @@ def main():
     ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32 = exact fp32 MFMA (the headline configuration)')
     ap.add_argument('--cpu-sample', default='step', choices=['step', 'layer', 'none'])
-    ap.add_argument('--exchange', default='auto', choices=['auto', 'a2a', 'allgather', 'halo'],
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'a2a', 'allgather', 'agpipe', 'halo'],
                     help='N > 1: exchange scheme whose time is `value` (auto: all-gather at 2 ranks, a2a from 3); the other '
                          'scheme is timed too and reported under `alt`')
     ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the `value` scheme')
@@ -419,12 +419,14 @@ def main():
     N, nnz = A.shape[0], int(A.nnz)
     if rank == 0:
         log('[bench] %s graph generated in %.1fs: N=%d nnz(A)=%d nnz(X)=%d' % (args.shape, time.time() - t0, N, nnz, X.nnz))
-    alt_comm = None
+    alt_comm = pipe_comm = None
     if world > 1 or force_dist:
         from geographconv_amd.dist import TorchDistComm
         comm = TorchDistComm(N, device, exchange=None if args.exchange == 'auto' else args.exchange)
         if world > 1 and not args.no_alt:
             alt_comm = TorchDistComm(N, device, exchange='allgather' if comm.exchange == 'a2a' else 'a2a')
+            # ... and the north_star's scheme with its all-gather pipelined by feature slabs
+            pipe_comm = TorchDistComm(N, device, exchange='agpipe') if comm.exchange != 'agpipe' else None
 
     def make_clf(c, dropout):
         m = GraphConv(X.shape[1], C, args.hid, 0.0, dropout, highway=True, device=device, comm=c,
@@ -467,21 +469,31 @@ def main():
     clf, g0, F_spmm, t, step_ms, kern_ms, last = run_scheme(comm)
     n_conv = len(args.hid)
     value = n_conv * nnz * args.steps / t
-    alt = None
-    if alt_comm is not None:
-        _m, _g, _F, t_alt, step_ms_alt, _k, last_alt = run_scheme(alt_comm)
-        alt = {"exchange": alt_comm.exchange, "value": n_conv * nnz * args.steps / t_alt, "unit": "edges/s",
+    alt = alt2 = None
+
+    def time_alt(c):
+        _m, _g, _F, t_alt, step_ms_alt, _k, last_alt = run_scheme(c)
+        res = {"exchange": c.exchange, "value": n_conv * nnz * args.steps / t_alt, "unit": "edges/s",
                "ms_per_step": t_alt / args.steps * 1e3, "step_ms_median": step_ms_alt[len(step_ms_alt) // 2],
                "train_loss_last": float(last_alt[0]),
-               "note": "same job, same K/W, the other exchange scheme (%s)" % (
-                   "the north_star's 1-D row split of A_hat + all-gather of H" if alt_comm.exchange == 'allgather'
-                   else "feature repartition with two all-to-alls")}
+               "note": "same job, same K/W, another exchange scheme (%s)" % {
+                   'allgather': "the north_star's 1-D row split of A_hat + all-gather of H",
+                   'agpipe': "the north_star's 1-D row split of A_hat + all-gather of H in %d feature slabs, slab q + 1 on the wire "
+                             "while slab q is multiplied" % c.slabs,
+                   'a2a': "feature repartition with two all-to-alls", 'halo': "halo exchange"}[c.exchange]}
         del _m, _g
+        return res
+    if alt_comm is not None:
+        alt = time_alt(alt_comm)
+    if pipe_comm is not None:
+        alt2 = time_alt(pipe_comm)
     check = None
     if world > 1 and not args.no_check:
         comms = {comm.exchange: comm}
         if alt_comm is not None:
             comms[alt_comm.exchange] = alt_comm
+        if pipe_comm is not None:
+            comms[pipe_comm.exchange] = pipe_comm
         check = partition_check(make_clf, comms, X, A, Y, tr, dev, rank)
 
     if rank == 0:
@@ -566,6 +578,8 @@ def main():
         }
         if alt is not None:
             out["alt"] = alt
+        if alt2 is not None:
+            out["alt2"] = alt2
         if check is not None:
             out["partition_check"] = check
         if world == 1 and args.cpu_sample != 'none':

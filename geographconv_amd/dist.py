@@ -443,8 +443,10 @@ class TorchDistComm(Comm):
             # the all-to-all moves (w-1)/w * 2/w of what the all-gather delivers to every rank
             self.exchange = 'a2a' if self.world >= 3 else 'allgather'
         self._auto_default = self.exchange
-        if self.exchange not in ('a2a', 'allgather', 'halo'):
-            raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a', 'allgather' or 'halo', got %r" % self.exchange)
+        if self.exchange not in ('a2a', 'allgather', 'agpipe', 'halo'):
+            raise ValueError("GEOGCN_DIST_EXCHANGE must be 'a2a', 'allgather', 'agpipe' or 'halo', got %r" % self.exchange)
+        # 'agpipe': the all-gather scheme cut into FEATURE SLABS ("gather slab j+1 || SpMM slab j")
+        self.slabs = max(1, int(tuning.DIST_AG_SLABS))
         self.balance = bool(balance)        # all-gather / halo schemes: cost-balanced row split (False: uniform, the A/B)
         self.halo = None                    # HaloPlan, built by graph_operand
         self.halo_rows = None               # rows received per exchange and rank under the halo scheme (prepare)
@@ -472,7 +474,7 @@ class TorchDistComm(Comm):
                 self.exchange = 'halo' if self.halo_rows.max() <= limit * max(1, remote.min()) else self._auto_default
                 if self.exchange != 'halo':
                     self.halo = None
-        if self.exchange in ('allgather', 'halo') and self.balance:
+        if self.exchange in ('allgather', 'agpipe', 'halo') and self.balance:
             self.part = RowPartition(self.part.N, self.world, self.rank, bounds=bounds)
             self._bufs = {}
         elif not self.part.uniform:          # (a2a after an earlier graph had moved this communicator to a balanced split)
@@ -548,6 +550,25 @@ class TorchDistComm(Comm):
             bufs = self._bufs[key] = (op, send)
         return bufs
 
+    def slab_width(self, F, bf16=False):
+        """agpipe: columns per feature slab (whole float4s / bf16 octets)."""
+        q = 8 if bf16 else 4
+        return ((int(F) + self.slabs - 1) // self.slabs + q - 1) // q * q
+
+    def _slab_buffers(self, F, tag, bf16=False):
+        """agpipe: (send, recv) of one exchange site.  send = my rows as `slabs` feature panels [slab][R][ws] (the layout the
+        GEMM's panel epilogue writes); recv[slab] = [world * R][ws], every rank's panel of that slab, one all-gather each."""
+        K = backend.active()
+        ws = self.slab_width(F, bf16)
+        key = ('agp', ws, tag, bool(bf16))
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            send = K.Panels(self.part.n_local, self.slabs * ws, self.part.R, self.slabs, ws, self.device, bf16=bf16)
+            recv = torch.zeros((self.slabs, self.part.n_gathered, ws), dtype=send.t.dtype, device=self.device)
+            bufs = self._bufs[key] = (send, recv)
+        bufs[0].F = int(F)
+        return bufs
+
     def _panels(self, kind, F, tag, bf16=False):
         K = backend.active()
         wp = self.panel_width(F, bf16)
@@ -576,6 +597,8 @@ class TorchDistComm(Comm):
             return buf.rows(lo, lo + self.part.n_local)         # the GEMM writes straight into my slot
         if not direct:
             return K.DMat.empty(self.part.n_local, F, self.device)
+        if self.exchange == 'agpipe':
+            return self._slab_buffers(F, tag, bf16)[0]          # the GEMM writes the slab panels itself
         return self._panels('send', F, tag, bf16)
 
     def stage_operand(self, m, F, tag=None, precision=None):
@@ -589,17 +612,17 @@ class TorchDistComm(Comm):
             else:
                 g.copy_from(m)
             return g
-        send = self._panels('send', F, tag, bf16)
+        send = self._slab_buffers(F, tag, bf16)[0] if self.exchange == 'agpipe' else self._panels('send', F, tag, bf16)
         if bf16:
             # fp32 staging buffer with the bf16 panels' geometry (their width is a multiple of 8, not of 4)
-            key = ('stage', send.wp, tag)
+            key = ('stage', send.wp, send.W, tag)
             stage = self._bufs.get(key)
             if stage is None:
                 stage = self._bufs[key] = torch.zeros(send.t.numel(), dtype=torch.float32, device=self.device)
-            K.pack_panels(m, self.part.R, self.world, send.wp, stage)
+            K.pack_panels(m, self.part.R, send.W, send.wp, stage)
             K.cast_bf16_flat(stage, send.t, send.wp)
         else:
-            K.pack_panels(m, self.part.R, self.world, send.wp, send.t)
+            K.pack_panels(m, self.part.R, send.W, send.wp, send.t)
         return send
 
     # -- the exchange around A . Z ----------------------------------------------------------------------
@@ -628,6 +651,20 @@ class TorchDistComm(Comm):
             h['work'] = self.dist.all_gather_into_tensor(buf.t, buf.t[self.rank * R:(self.rank + 1) * R], group=self.group,
                                                          async_op=True)
             return h
+        if self.exchange == 'agpipe':
+            send, recv = self._slab_buffers(F, tag, isinstance(z, K.Panels) and z.bf16)
+            if not isinstance(z, K.Panels):                      # a producer that could not write panels itself
+                K.pack_panels(z, self.part.R, send.W, send.wp, send.t)
+            elif z is not send:
+                raise ValueError("agpipe: the operand must be the panels matmul_target / stage_operand handed out")
+            R, ws = self.part.R, send.wp
+            # one all-gather per slab, issued back to back (RCCL runs them in order on its own stream): slab q + 1 is on the
+            # wire while graph_spmm_end multiplies slab q
+            h.update(recv=recv, ws=ws, bf16=send.bf16,
+                     works=[self.dist.all_gather_into_tensor(recv[q].view(-1), send.t[q * R * ws:(q + 1) * R * ws], group=self.group,
+                                                             async_op=True) for q in range(send.W)])
+            h['work'] = None
+            return h
         if not isinstance(z, K.Panels):                          # a producer that could not write panels itself
             send = self._panels('send', F, tag, False)
             K.pack_panels(z, self.part.R, self.world, send.wp, send.t)
@@ -639,7 +676,7 @@ class TorchDistComm(Comm):
 
     def graph_spmm_mid(self, h):
         """a2a: wait for panel `rank` of all rows, multiply, start the return exchange.  allgather: nothing to do."""
-        if h['mid'] or self.exchange in ('allgather', 'halo'):
+        if h['mid'] or self.exchange in ('allgather', 'agpipe', 'halo'):
             return h
         K = backend.active()
         part = self.part
@@ -670,6 +707,21 @@ class TorchDistComm(Comm):
             if h['work'] is not None:
                 h['work'].wait()
             return K.spmm(h['A'], h['buf'], bias=h['bias'], act=h['act'], F=h['F'])
+        if self.exchange == 'agpipe':
+            F, ws = h['F'], h['ws']
+            out = K.DMat.empty(self.part.n_local, F, self.device)
+            for q, work in enumerate(h['works']):
+                if work is not None:
+                    work.wait()                                  # the compute stream waits for slab q only
+                Fq = max(0, min(ws, F - q * ws))
+                if Fq == 0:
+                    continue
+                v = h['recv'][q]
+                B = K.HMat(v.shape[0], ws, t=v) if h['bf16'] else K.DMat(v.shape[0], ws, t=v)
+                bias = h['bias']
+                K.spmm(h['A'], B, out=out, out_col0=q * ws, bias=None if bias is None else bias[q * ws: q * ws + K.pad4(Fq)],
+                       act=h['act'], F=Fq)
+            return out
         self.graph_spmm_mid(h)
         h['work2'].wait()
         out = K.DMat.empty(self.part.n_local, h['F'], self.device)

@@ -317,11 +317,16 @@ class CSR:
             pass
 
 
-def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None, accumulate=False):
+def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F=None, accumulate=False, out_col0=0):
     """out = act(A . B + bias)  -- S.structured_dot (reference gcnmodel.py:39,130,153).  B is a DMat, or an
-    HMat (bf16 gathered operand, fp32 accumulation) in the bf16 configuration.  accumulate: out = act(out + A . B + bias)."""
+    HMat (bf16 gathered operand, fp32 accumulation) in the bf16 configuration.  accumulate: out = act(out + A . B + bias).
+    out_col0 (a multiple of 4): the F result columns go to columns [out_col0, out_col0 + F) of `out` (the feature-slab pipeline
+    of the partitioned all-gather: one product per slab into one output matrix; bias is then that slab's slice)."""
     lib = _ffi.lib()
     F = B.F if F is None else F
+    if out_col0:
+        if out is None or out_col0 % 4 or out_col0 + pad4(F) > out.ld or accumulate:
+            raise ValueError("spmm: out_col0 needs an existing output with room for the slab, a multiple of 4, no accumulate")
     if B.n != A.shape[1]:
         raise ValueError("spmm: A is %s but B has %d rows" % (A.shape, B.n))
     if out is None:
@@ -335,8 +340,9 @@ def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F
     fn, name = ((lib.geogcn_spmm_csr_bf16b, 'spmm_csr_bf16b') if isinstance(B, HMat)
                 else (lib.geogcn_spmm_csr_acc_f32, 'spmm_csr_acc_f32') if accumulate
                 else (lib.geogcn_spmm_csr_f32, 'spmm_csr_f32'))
+    cptr = _p(out.t) if not out_col0 else C.c_void_p(out.t.data_ptr() + 4 * int(out_col0))
     check(fn(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), _p(B.t), B.ld,
-             _p(out.t), out.ld, F, _p(bias), act, _p(ws), ws.numel(), _stream()), name)
+             cptr, out.ld, F, _p(bias), act, _p(ws), ws.numel(), _stream()), name)
     return out
 
 

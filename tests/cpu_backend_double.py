@@ -59,14 +59,14 @@ def highway_bwd_bf16_ok(G, with_bias):
     return False
 
 
-def spmm(A, B, out=None, bias=None, act=ACT_NONE, F=None):
+def spmm(A, B, out=None, bias=None, act=ACT_NONE, F=None, out_col0=0):
     F = B.F if F is None else F
     if out is None:
         out = DMat(A.shape[0], F, B.device)
-    r = np.asarray(A.m @ B.t.numpy()[:A.shape[1], :F])
+    r = np.asarray(A.m @ B.t.float().numpy()[:A.shape[1], :F])
     if bias is not None:
         r = r + bias.numpy()[:F]
-    out.t.numpy()[:, :F] = _act(r.astype(np.float32), act)        # (F may be narrower than the output buffer)
+    out.t.numpy()[:, out_col0:out_col0 + F] = _act(r.astype(np.float32), act)        # (F may be narrower than the output buffer)
     return out
 
 

@@ -21,6 +21,7 @@ def main():
     from tests.helpers import load_case, make_clf
     for name, exchange in [('tiny_highway', 'a2a'), ('tiny_plain_reg', 'a2a'), ('tiny_odd_widths', 'a2a'),
                            ('tiny_highway', 'allgather'), ('tiny_odd_widths', 'allgather'), ('tiny_highway', 'halo'),
+                           ('tiny_highway', 'agpipe'), ('tiny_plain_reg', 'agpipe'), ('tiny_odd_widths', 'agpipe'),
                            ('tiny_plain_reg', 'halo'), ('tiny_odd_widths', 'halo')]:
         z, A, X, params, cfg = load_case(name)
         comm = TorchDistComm(cfg['N'], device, exchange=exchange)
@@ -50,7 +51,7 @@ def main():
     Zh = np.random.RandomState(1).randn(6000, 44).astype(np.float32)
     bias = torch.from_numpy(np.random.RandomState(2).randn(44).astype(np.float32)).to(device)
     full = ops.spmm(ops.CSR(A, device), ops.DMat.from_numpy(Zh, device), bias=bias, act=ops.ACT_TANH)
-    for exchange in ('allgather', 'a2a', 'halo'):
+    for exchange in ('allgather', 'a2a', 'halo', 'agpipe'):
         comm = TorchDistComm(6000, device, exchange=exchange)
         comm.prepare(A)
         dA = comm.graph_operand(A)
@@ -62,7 +63,7 @@ def main():
     z_, A_, X_, params, cfg = load_case('tiny_highway')
     ref = None
     for comm in (None, TorchDistComm(cfg['N'], device, exchange='a2a'), TorchDistComm(cfg['N'], device, exchange='allgather'),
-                 TorchDistComm(cfg['N'], device, exchange='halo')):
+                 TorchDistComm(cfg['N'], device, exchange='halo'), TorchDistComm(cfg['N'], device, exchange='agpipe')):
         from geographconv_amd.gcnmodel import GraphConv
         clf = GraphConv(cfg['V'], cfg['C'], cfg['hid'], cfg['reg'], cfg['p'], highway=True, device=device, comm=comm,
                         gemm_precision='bf16')
@@ -91,7 +92,7 @@ def main():
     tr_, dv_ = np.sort(perm[:2500]).astype(np.int32), np.sort(perm[2500:3500]).astype(np.int32)
     mask_ = (rng.rand(5003, 52) < 0.5).astype(np.uint8)
     ref = None
-    for exchange in (None, 'a2a', 'allgather', 'halo'):
+    for exchange in (None, 'a2a', 'allgather', 'halo', 'agpipe'):
         comm = None if exchange is None else TorchDistComm(5003, device, exchange=exchange)
         clf = GraphConv(700, C_, hid, 0.0, 0.5, highway=True, device=device, comm=comm)
         clf.build_model(None, seed=77)
@@ -166,7 +167,7 @@ def main():
         if len(dv_) == 0:
             dv_ = tr_[:1].copy()
         mask_ = (rng.rand(N, hid[0]) < (1 - p)).astype(np.uint8) if p > 0 else np.ones((N, hid[0]), np.uint8)
-        for exchange in ('a2a', 'allgather', 'halo'):
+        for exchange in ('a2a', 'allgather', 'halo', 'agpipe'):
             comm = TorchDistComm(N, device, exchange=exchange)
             comm.prepare(A_)
             # (every third model also goes through a node reordering: invisible to the caller, partitioned or not)
@@ -190,7 +191,7 @@ def main():
         # the bf16 configuration (bf16 operand and wire) on the same model: partitioned vs this process's one-GPU bf16 run
         if seed % 2 == 0:
             ref = None
-            for exchange in (None, 'a2a', 'allgather', 'halo'):
+            for exchange in (None, 'a2a', 'allgather', 'halo', 'agpipe'):
                 comm = None if exchange is None else TorchDistComm(N, device, exchange=exchange)
                 if comm is not None:
                     comm.prepare(A_)

@@ -174,7 +174,7 @@ def _worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3), ("a2a", 8), ("allgather", 4), ("halo", 2),
+@pytest.mark.parametrize("exchange,world", [("a2a", 2), ("allgather", 2), ("a2a", 3), ("a2a", 8), ("allgather", 4), ("halo", 2), ("agpipe", 2), ("agpipe", 4),
                                             ("halo", 3), ("halo", 8)])
 def test_multi_rank_gloo_matches_single_process_oracle(exchange, world):
     import torch.multiprocessing as mp
@@ -251,7 +251,7 @@ def _asym_worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 2), ("halo", 3)])
+@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 2), ("halo", 3), ("agpipe", 3)])
 def test_multi_rank_asymmetric_adjacency(exchange, world):
     import torch.multiprocessing as mp
     from oracle import gcn_oracle as O
@@ -340,7 +340,7 @@ def _random_worker(rank, world, port, q, exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 3), ("a2a", 4), ("halo", 4)])
+@pytest.mark.parametrize("exchange,world", [("a2a", 3), ("allgather", 3), ("a2a", 4), ("halo", 4), ("agpipe", 3)])
 def test_multi_rank_gloo_random_models(exchange, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')

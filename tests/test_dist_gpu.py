@@ -135,7 +135,7 @@ def test_bench_launches_its_own_ranks_and_checks_itself():
     assert d['roofline']['kernel'] and np.isfinite(d['config']['train_loss_last'])
     assert d['config']['dist']['exchange'] == 'allgather' and d['alt']['exchange'] == 'a2a' and d['alt']['value'] > 0
     pc = d['partition_check']
-    for scheme in ('allgather', 'a2a'):
+    for scheme in ('allgather', 'a2a', 'agpipe'):
         c = pc[scheme]
         assert c['max_abs_dloss'] <= 2e-5 and c['max_abs_dacc'] <= 2e-4, (scheme, c)      # (one near-tie row of 5,685 at most)
         assert c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9995, (scheme, c)
@@ -148,7 +148,7 @@ def test_bench_partitioned_at_the_full_twitterus_shape():
     d = _run_bench_self_launched(['--gpus', '2', '--steps', '2', '--warmup', '1'], 2400)
     assert d['config']['world_size'] == 2 and 'N=440000' in d['config']['workload']
     pc = d['partition_check']
-    for scheme in ('allgather', 'a2a'):
+    for scheme in ('allgather', 'a2a', 'agpipe'):
         c = pc[scheme]
         assert c['max_abs_dloss'] <= 1e-5 and c['max_abs_dacc'] <= 4e-6, (scheme, c)      # (one near-tie row of 264,000 at most)
         assert c['max_abs_dP'] <= 5e-8 and c['argmax_agreement'] >= 0.99999, (scheme, c)
@@ -163,7 +163,7 @@ def test_bench_partitioned_config5_shape_bf16_full_size():
     d = _run_bench_self_launched(['--gpus', '2', '--hid', '600', '600', '600', '600', '600', '600', '--gemm-precision', 'bf16',
                                   '--steps', '1', '--warmup', '1'], 2400)
     assert d['config']['world_size'] == 2 and d['dtype'] == 'bf16' and '600x600x600x600x600x600' in d['config']['workload']
-    for scheme in ('allgather', 'a2a'):
+    for scheme in ('allgather', 'a2a', 'agpipe'):
         c = d['partition_check'][scheme]
         assert c['max_abs_dloss'] <= 1e-5 and c['max_abs_dacc'] <= 4e-6, (scheme, c)
         assert c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9999, (scheme, c)
