@@ -41,8 +41,26 @@ __device__ __forceinline__ void fma4(float4& acc, float a, const float4& b) {
     acc.w = fmaf(a, b.w, acc.w);
 }
 
+// Buffer addressing for the cold gathers: one wave-uniform descriptor of B in SGPRs and ONE 32-bit byte offset per
+// nonzero (column * pitch + lane * 16; the K4 pieces of a row differ by an immediate), instead of a 64-bit address per load.
+// That is what lets a 1024-thread workgroup (128 VGPRs per lane) keep FOUR gathered rows in flight per trip instead of two
+// -- the cold part of a row is a chain of dependent L2 round trips, and the trips halve.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hot_rsrc(const float* base, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+__device__ __forceinline__ float4 ld4b(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+constexpr uint32_t kHotOob = 0x80000000u;     // beyond any descriptor: the load returns zeros
+
 struct HotArgs {
     int n_rows;
+    int n_cols;                 // rows of B (buffer form: n_cols * ldb * 4 < 2^31)
     const int* rowptr;
     const int* rowsplit;        // [rowptr[r], rowsplit[r]) hot (colidx = LDS slot), [rowsplit[r], rowptr[r+1]) cold
     const int* colidx;
@@ -62,7 +80,7 @@ struct HotArgs {
     int64_t per_call, base;
 };
 
-template <int K4, int ACT, int DROP = 0>
+template <int K4, int ACT, int DROP = 0, int BUF = 1>
 __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 hot[];         // [n_hot][K4][16]
     const int lane = threadIdx.x % kGroup, g = threadIdx.x / kGroup;
@@ -100,7 +118,54 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
                 for (int k = 0; k < K4; ++k) fma4(acc[k], a0, hr[k * kGroup]);
             }
         }
-        // cold part: L2 / HBM gather, two nonzeros per trip
+        // cold part: L2 / HBM gather.  Buffer form: four nonzeros per trip (4 x K4 independent loads in flight per lane)
+        if constexpr (BUF) {
+            const __amdgpu_buffer_rsrc_t rs = hot_rsrc(a.B, (int64_t)a.n_cols * a.ldb * 4);
+            const uint32_t ld4 = (uint32_t)a.ldb * 4u;
+            constexpr int E = K4 <= 5 ? 4 : 3;          // (4 x 6 float4 in flight would spill at 128 VGPRs)
+            for (int base = h; base < e; base += kGroup) {
+                const int j = base + lane;
+                uint32_t co = 0;
+                float v = 0.f;
+                if (j < e) {
+                    co = (uint32_t)a.colidx[j] * ld4;          // byte offset of the gathered row
+                    v = a.val[j];
+                }
+                const int cnt = min(kGroup, e - base);
+                // the last piece of a row may lie beyond F (lanes whose float4 index is >= nF4): those loads are sent out of range
+                const uint32_t lane_off = (uint32_t)lane * 16u;
+                const bool last_ok = lane + kGroup * (K4 - 1) < nF4;
+                int t = 0;
+                for (; t + E <= cnt; t += E) {
+                    uint32_t off[E];
+                    float av[E];
+#pragma unroll
+                    for (int q = 0; q < E; ++q) {
+                        off[q] = (uint32_t)__shfl((int)co, t + q, kGroup) + lane_off;
+                        av[q] = __shfl(v, t + q, kGroup);
+                    }
+                    float4 vv[E][K4];
+#pragma unroll
+                    for (int q = 0; q < E; ++q)
+#pragma unroll
+                        for (int k = 0; k < K4; ++k)
+                            vv[q][k] = ld4b(rs, (k == K4 - 1 && !last_ok) ? kHotOob : off[q] + (uint32_t)(k * kGroup * 16));
+#pragma unroll
+                    for (int q = 0; q < E; ++q)            // stored order: nonzero t, t+1, ... into every accumulator
+#pragma unroll
+                        for (int k = 0; k < K4; ++k) fma4(acc[k], av[q], vv[q][k]);
+                }
+                for (; t < cnt; ++t) {
+                    const uint32_t o0 = (uint32_t)__shfl((int)co, t, kGroup) + lane_off;
+                    const float a0 = __shfl(v, t, kGroup);
+                    float4 v0[K4];
+#pragma unroll
+                    for (int k = 0; k < K4; ++k) v0[k] = ld4b(rs, (k == K4 - 1 && !last_ok) ? kHotOob : o0 + (uint32_t)(k * kGroup * 16));
+#pragma unroll
+                    for (int k = 0; k < K4; ++k) fma4(acc[k], a0, v0[k]);
+                }
+            }
+        } else
         for (int base = h; base < e; base += kGroup) {
             const int j = base + lane;
             int c = 0;
@@ -191,6 +256,14 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
     }
 }
 
+// which form runs: the buffer form whenever B is addressable with 31 bits -- except the widest kernel with the dropout epilogue,
+// whose epilogue already fills the 128 registers of a 1024-thread workgroup (the buffer form would spill there)
+template <int K4, int ACT, int DROP>
+auto hot_kernel_for(bool buf) -> void (*)(const HotArgs) {
+    if constexpr (K4 == 6 && DROP) return spmm_hot_kernel<K4, ACT, DROP, 0>;
+    else return buf ? spmm_hot_kernel<K4, ACT, DROP, 1> : spmm_hot_kernel<K4, ACT, DROP, 0>;
+}
+
 }  // namespace
 }  // namespace geogcn
 
@@ -206,7 +279,7 @@ int32_t geogcn_spmm_hot_capacity(int32_t F) {
 
 static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act, int drop, hipStream_t st) {
     const int n_rows = a.n_rows, F = a.F;
-    GEOGCN_REQUIRE(n_rows >= 0 && F > 0 && n_hot >= 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    GEOGCN_REQUIRE(n_rows >= 0 && F > 0 && n_hot >= 0 && a.n_cols >= 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (n_rows == 0) return 0;
     GEOGCN_REQUIRE(a.rowptr && a.rowsplit && a.C && a.B && (n_hot == 0 || a.hot_rows), GEOGCN_E_NULL, "%s: null pointer", fn);
     const int cap = geogcn_spmm_hot_capacity(F);
@@ -219,13 +292,15 @@ static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act
     const size_t lds = (size_t)std::max(1, n_hot) * K4 * kGroup * sizeof(float4);
     const int n_tiles = (int)cdiv(n_rows, kGroups);
     const dim3 grid((unsigned)std::min(n_tiles, kNumCU));
+    // buffer form when every byte of B is within a 31-bit offset (always at the reference's shapes: a vocabulary x hidden weight)
+    const bool buf = a.n_cols > 0 && (int64_t)a.n_cols * a.ldb * 4 < 0x7FFFFFFFll;
 #define GEOGCN_HOT(K, ACT, DROP)                                                                                    \
     do {                                                                                                            \
-        auto kern = spmm_hot_kernel<K, ACT, DROP>;                                                                  \
-        static bool attr_done = false;                                                                              \
-        if (!attr_done) {                                                                                           \
+        auto kern = hot_kernel_for<K, ACT, DROP>(buf);                                                              \
+        static bool attr_done[2] = {false, false};                                                                  \
+        if (!attr_done[buf]) {                                                                                      \
             GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_done = true;                                                                                       \
+            attr_done[buf] = true;                                                                                  \
         }                                                                                                           \
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);                                                 \
     } while (0)
@@ -250,16 +325,16 @@ static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act
     return 0;
 }
 
-int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+int geogcn_spmm_csr_hot_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
                             const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
                             int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream) {
     HotArgs a{};
-    a.n_rows = n_rows; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
+    a.n_rows = n_rows; a.n_cols = n_cols; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
     a.hot_rows = hot_rows; a.n_hot = n_hot; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
     return spmm_hot_launch("spmm_csr_hot_f32", a, n_hot, act, 0, (hipStream_t)stream);
 }
 
-int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
                                     const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
                                     float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act, float p_drop,
                                     const uint8_t* mask_in, uint8_t* mask_out, uint64_t seed, uint64_t offset,
@@ -275,7 +350,7 @@ int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, const int32_t* rowptr, const
                    GEOGCN_E_ALIGN, "%s: needs F %% 4 == 0 (one Philox counter / one mask word per float4), a 16-byte aligned Cd "
                    "and 4-byte aligned masks (F=%d)", fn, F);
     HotArgs a{};
-    a.n_rows = n_rows; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
+    a.n_rows = n_rows; a.n_cols = n_cols; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
     a.hot_rows = hot_rows; a.n_hot = n_hot; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
     a.Cd = Cd; a.mask_in = mask_in; a.mask_out = mask_out; a.keep_prob = 1.0f - p_drop; a.scale = 1.0f / (1.0f - p_drop);
     a.seed = seed; a.offset = offset; a.calls = calls_dev; a.per_call = per_call_elems; a.base = base_elems;

@@ -909,7 +909,7 @@ def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, ac
     if col0 % 4 or col0 < 0 or col0 + F > B.F:
         raise ValueError("spmm_hot: bad column slab [%d, %d) of %d" % (col0, col0 + F, B.F))
     at = lambda t: None if t is None else C.c_void_p(t.data_ptr() + 4 * col0)
-    check(_ffi.lib().geogcn_spmm_csr_hot_f32(A.shape[0], _p(A.rowptr), _p(A.rowsplit), _p(A.colidx), _p(A.val), at(B.t), B.ld,
+    check(_ffi.lib().geogcn_spmm_csr_hot_f32(A.shape[0], B.n, _p(A.rowptr), _p(A.rowsplit), _p(A.colidx), _p(A.val), at(B.t), B.ld,
                                              _p(A.hot_rows), A.n_hot, at(out.t), out.ld, F, at(bias), act, _stream()),
           'spmm_csr_hot_f32')
     return out
@@ -960,7 +960,7 @@ def spmm_x_dropout(x: SparseOperand, W: DMat, bias, act, p, mask_in=None, seed=0
         return None              # the kernel reads 32-bit words at mask + row * F + 4 q: anything else goes to the separate kernels
     H0, Hd = DMat.empty(n, W.F, W.device), DMat.empty(n, W.F, W.device)
     mask = mask_in if mask_in is not None else torch.empty((n, W.F), dtype=torch.uint8, device=W.device)
-    check(lib.geogcn_spmm_csr_hot_dropout_f32(n, _p(hot.rowptr), _p(hot.rowsplit), _p(hot.colidx), _p(hot.val), _p(W.t), W.ld,
+    check(lib.geogcn_spmm_csr_hot_dropout_f32(n, W.n, _p(hot.rowptr), _p(hot.rowsplit), _p(hot.colidx), _p(hot.val), _p(W.t), W.ld,
                                               _p(hot.hot_rows), hot.n_hot, _p(H0.t), _p(Hd.t), H0.ld, W.F, _p(bias), int(act),
                                               float(p), _p(mask_in), None if mask_in is not None else _p(mask), int(seed),
                                               int(offset), _p(calls_dev), int(per_call), int(base), _stream()),

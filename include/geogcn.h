@@ -29,7 +29,8 @@ extern "C" {
 #endif
 
 /* 2: round 3 changed exported signatures incompatibly (geogcn_spmm_plan_create: chunks_with_owner instead of a rowsplit pointer;
- * geogcn_gemm_kcat_f32: ws / ws_bytes before stream; geogcn_spmm_plan_attach_timer replaced geogcn_timer_attach_spmm). */
+ * geogcn_gemm_kcat_f32: ws / ws_bytes before stream; geogcn_spmm_plan_attach_timer replaced geogcn_timer_attach_spmm);
+ * round 4: geogcn_spmm_csr_hot_f32 / _hot_dropout_f32 take n_cols after n_rows. */
 #define GEOGCN_ABI_VERSION 2
 
 #define GEOGCN_E_NULL   (-1)   /* required pointer is NULL            */
@@ -85,9 +86,11 @@ int geogcn_spmm_csr_acc_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_
  * once and serves the hot nonzeros from there; only the cold ones are gathered from L2 / HBM.  The caller prepares the
  * structure: every row is ordered [hot | cold] (each part in ascending column order), rowsplit[r] is the boundary, and
  * colidx of a HOT entry holds its LDS slot s (0 <= s < n_hot) instead of the column.  n_hot <= geogcn_spmm_hot_capacity(F)
- * (0 = this width is not supported: use geogcn_spmm_csr_f32).  Accumulation is sequential in the stored order.     */
+ * (0 = this width is not supported: use geogcn_spmm_csr_f32).  Accumulation is sequential in the stored order.
+ * n_cols = rows of B (every cold column index is < n_cols): when n_cols * ldb * 4 < 2^31 the cold rows are gathered through
+ * one buffer descriptor with 32-bit offsets, four rows in flight per 16-lane group; 0 = unknown (64-bit addresses, two).  */
 int32_t geogcn_spmm_hot_capacity(int32_t F);
-int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+int geogcn_spmm_csr_hot_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
                             const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
                             int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream);
 
@@ -99,7 +102,7 @@ int geogcn_spmm_csr_hot_f32(int32_t n_rows, const int32_t* rowptr, const int32_t
  * mask_out (nullable when mask_in is given) receives the mask used, dense [n_rows][F].  One launch replaces the mask
  * kernel and an apply pass that re-reads C.  Needs F % 4 == 0 (GEOGCN_E_ALIGN otherwise: use the separate calls);
  * act is tanh or none.                                                                                           */
-int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
+int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
                                     const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
                                     float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act, float p_drop,
                                     const uint8_t* mask_in, uint8_t* mask_out, uint64_t seed, uint64_t offset,
