@@ -539,7 +539,13 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
             for (int ps = 0; ps < P; ++ps) {
                 const int seg = ps >= a.passes[0] ? 1 : 0;                  // wave-uniform
                 const int lps = seg ? ps - a.passes[0] : ps;
-                const int tile0 = (wid * (seg ? a.passes[1] : a.passes[0]) + lps) * WCT;
+                // column group of this wave: ROTATED with the row tile, so that the group whose last column tile is all padding
+                // (300 columns = 19 tiles of 16 over 4 waves: 5, 5, 5, 4) visits every SIMD in turn -- the two co-resident
+                // blocks of a CU then share MFMA pipes that carry 4.75 instead of 5 tiles per wave on average
+                const int cg = (wid + mt) & 3;
+                const int tile0 = (cg * (seg ? a.passes[1] : a.passes[0]) + lps) * WCT;
+                // does the LAST of this wave's column tiles hold any real column?  (wave-uniform: a scalar branch per k-step)
+                const bool last_real = __builtin_amdgcn_readfirstlane((int)((int64_t)(tile0 + WCT - 1) * 16 < (seg ? a.N[1] : a.N[0]))) != 0;
                 const int slot = seg | ks;
                 const int n_tiles = 4 * (seg ? a.passes[1] : a.passes[0]) * WCT;
                 const __amdgpu_buffer_rsrc_t brs = tile_rsrc(slot ? a.Bf[1] : a.Bf[0], (int64_t)n_tiles * NK * 1024);
@@ -567,9 +573,16 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
 #pragma unroll
                         for (int i = 0; i < MR; ++i)
 #pragma unroll
-                            for (int j = 0; j < WCT; ++j)
+                            for (int j = 0; j < WCT - 1; ++j)
                                 // operands swapped (as in gemm_kernel): a lane owns 4 consecutive columns of one row of C
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][t], af[i][t], acc[i][j], 0, 0, 0);
+                    if (last_real) {          // (an all-padding tile would only multiply zeros: its accumulators stay 0, its stores are masked)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int i = 0; i < MR; ++i)
+                                acc[i][WCT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[WCT - 1][t], af[i][t], acc[i][WCT - 1], 0, 0, 0);
+                    }
                 };
                 f32x4 ring[D1][WCT];
 #pragma unroll
