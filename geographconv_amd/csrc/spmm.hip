@@ -45,7 +45,7 @@ __device__ __forceinline__ void fma4(float4& acc, float a, const float4& b) {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // (a hub hint -- hub columns first with default loads, the rest with non-temporal loads so that they do not evict the
-//  hubs -- was built and measured in rounds 1-2: 2.0 -> 2.6-2.8 ms, removed in round 3)
+//  hubs -- was built and measured in rounds 1-2: 2.0 -> 2.6-2.8 ms, removed in round 3; DESIGN_NOTEBOOK.md section 4.1)
 __device__ __forceinline__ float4 gather4(const void* row, int q) {
     const f32x4v v = *(reinterpret_cast<const f32x4v*>(row) + q);
     return make_float4(v.x, v.y, v.z, v.w);
@@ -402,7 +402,7 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
     constexpr int kGroupsPerBlock = kRowBlock / G;
     const int long_nnz = plan ? plan->long_row_nnz : INT32_MAX;
     const int n_chunks = (plan && plan->n_long > 0) ? (int)plan->n_chunks : 0;
-    constexpr int xcd_rows = 1;      // (0 = plain block -> row-block map: the A/B of DESIGN.md section 4.1)
+    constexpr int xcd_rows = 1;      // (0 = plain block -> row-block map: the A/B of DESIGN_NOTEBOOK.md section 4.1)
     const int64_t ldp = (int64_t)((F + 3) / 4) * 4;
     const int n_row_blocks = (int)cdiv(n_rows, kGroupsPerBlock);
     XcdRows xr{};

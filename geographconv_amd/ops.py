@@ -920,7 +920,7 @@ def spmm_x(x: SparseOperand, W: DMat, out: DMat = None, bias: torch.Tensor = Non
     """out = act(x . W + bias) for a sparse input x (S.structured_dot(X, W0), reference gcnmodel.py:39-42): the hot rows
     of W from LDS (geogcn_spmm_csr_hot_f32) from tuning.HOT_MIN_NNZ stored entries on, the plain row gather below.
     (Measured and removed: the dense head panel on the MFMA pipe + CSR tail continuing the rows -- 1.69 ms against
-    1.32 -- and its column-slab variant)"""
+    1.32 -- and its column-slab variant; DESIGN_NOTEBOOK.md section 4.2.)"""
     if isinstance(x.fwd, CSR) and x.fwd.nnz >= tuning.HOT_MIN_NNZ and not x.symmetric:
         # a layer wider than the LDS kernel takes (384 columns) runs as two column slabs of it when they are float4-aligned
         # (600 wide: 2 x 1.33 ms against 3.93 ms for the plain row gather)

@@ -11,7 +11,7 @@ Environment variables read by product code -- four, all about WHICH configuratio
 documented constant with the measurement that set it.  Tests that need an A/B flip the attribute (monkeypatch), nothing
 reads the environment behind the caller's back.  Kernel-side constants that used to be getenv() switches are now
 `constexpr` next to the kernel they belong to (spmm.hip kRowBlock, xt.hip kDocBlock / kUnitCap, elementwise.hip hw_parts,
-gemm.hip wide_bn); the experiments they guarded are recorded in DESIGN.md sections 4.1-4.3 and were removed from the
+gemm.hip wide_bn); the experiments they guarded are recorded in DESIGN_NOTEBOOK.md sections 4.1-4.3 (summaries: DESIGN.md section 4) and were removed from the
 code in round 3: the SpMM hub hint (non-temporal tail loads), the split X.W0 forward (dense head GEMM + CSR tail, and its
 column-slab variant), the side-stream overlap of the graph product with the gate GEMMs, the X^T sweep's L2 prefetch and
 per-XCD rendezvous."""
