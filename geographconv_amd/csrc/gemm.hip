@@ -457,6 +457,102 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_ker
     }
 }
 
+// ---- A^T . B for the weight gradients WITHOUT LDS and without barriers (round 4) ------------------------------------------------
+// dW = H^T . dZ reduces over the node dimension; both operands are k-STRIDED in memory ([K][M], [K][N]) -- and that is exactly the
+// operand layout of v_mfma_f32_16x16x4_f32: lane l of an A (B) fragment holds H[k0 + l / 16][m0 + l % 16] (dZ[k0 + l / 16][n0 + l % 16]).
+// So a fragment is ONE buffer_load_dword (four 64-byte row segments per wave), every wave streams its own MR + NR fragments per 4 k
+// straight into registers, TN_DEPTH steps ahead, and multiplies MR x NR MFMAs -- no LDS image, no stage barrier (gemm_kernel<.., AT> spends
+// a barrier, 61 KB of LDS stores and 40 ds_read_b32 per wave on every 32 k).  The 8 waves of a block (2 x 4: 160 x 320 / 128 x 256 ...)
+// share lines through the CU's L1 only; the blocks of one K slab share an XCD (L2).  Split-K slabs go to the workspace in the layout
+// splitk_reduce_kernel combines in slab order: deterministic.  tools/micro/tn_direct.hip: H^T . [dZ | dU] at the TwitterUS shape
+// 1.36 ms = 116 TF against 1.67 ms = 94.5 TF for the staged kernel.  (k grouping per MFMA differs from the staged kernel's: results
+// agree to fp32 rounding, not bit for bit.)
+struct TnDirectArgs {
+    int64_t M, K;
+    const float* A; int64_t lda;
+    const float* B[2]; int64_t ldb[2]; int64_t N[2];
+    float* W; int64_t ldw, seg_w;       // slabs [nsplit][M][ldw]; N segment q starts at column q * seg_w
+    int n_mt, n_nt, nt_per_seg, nsplit;
+    int64_t kchunk;
+};
+constexpr int TN_DEPTH = 5;
+
+template <int MR, int NR>
+__global__ __launch_bounds__(512, 1) void gemm_tn_direct_kernel(const TnDirectArgs a) {
+    constexpr int WM = 2, WN = 4, D = TN_DEPTH;
+    const int lane = threadIdx.x & 63;
+    const int wid = uni(threadIdx.x >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 15, lk = lane >> 4;
+    // block -> (tile, slab): the tiles of one K slab run on ONE XCD (block b runs on XCD b % 8), so that a slab's rows of A and B
+    // come from HBM once and from that XCD's L2 for the other tiles
+    const int T = a.n_mt * a.n_nt;
+    const int b = blockIdx.x;
+    const int zx = b % kNumXCD, rest = b / kNumXCD;
+    const int tile = rest % T, z = (rest / T) * kNumXCD + zx;
+    if (z >= a.nsplit) return;
+    const int mt = tile / a.n_nt, ntile = tile % a.n_nt;
+    const int seg = uni(ntile / a.nt_per_seg), nt = ntile % a.nt_per_seg;
+    const int m0 = (mt * WM + wm) * MR * 16, n0 = (nt * WN + wn) * NR * 16;
+    const int64_t M = a.M, N = seg ? a.N[1] : a.N[0];
+    const float* Bp = seg ? a.B[1] : a.B[0];
+    const int64_t ldb = seg ? a.ldb[1] : a.ldb[0];
+    const int64_t kbeg = (int64_t)z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    if (kbeg >= kend) return;
+    // descriptors start at the slab's first row and end with its last: rows past the end read as zeros in hardware
+    const __amdgpu_buffer_rsrc_t ar = tile_rsrc(a.A + kbeg * a.lda, (kend - kbeg) * a.lda * 4);
+    const __amdgpu_buffer_rsrc_t br = tile_rsrc(Bp + kbeg * ldb, (kend - kbeg) * ldb * 4);
+    // lane part of the offsets; a lane whose column lies beyond the matrix reads zeros (its pitch may have no pad columns)
+    uint32_t ao[MR], bo[NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) ao[i] = (m0 + i * 16 + li < M) ? (uint32_t)((lk * a.lda + m0 + i * 16 + li) * 4) : kOobOffset;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) bo[j] = (n0 + j * 16 + li < N) ? (uint32_t)((lk * ldb + n0 + j * 16 + li) * 4) : kOobOffset;
+    const uint32_t astep = (uint32_t)a.lda * 16u, bstep = (uint32_t)ldb * 16u;          // 4 rows per step, in bytes
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = (int)((kend - kbeg + 3) / 4);
+    float ra[D + 1][MR], rb[D + 1][NR];
+    auto fetch = [&](float (&fa)[MR], float (&fb)[NR], int s) {          // (steps past the end: beyond num_records -> zeros)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+            fa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, (int)ao[i], (int)((uint32_t)s * astep), 0));
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            fb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (int)bo[j], (int)((uint32_t)s * bstep), 0));
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(ra[d], rb[d], d);
+#pragma unroll 1
+    for (int s0 = 0; s0 < nsteps; s0 += D + 1) {
+#pragma unroll
+        for (int u = 0; u <= D; ++u) {
+            fetch(ra[(u + D) % (D + 1)], rb[(u + D) % (D + 1)], s0 + u + D);
+            if (s0 + u < nsteps) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][i], rb[u][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // D[i = 4 * (lane / 16) + r][j = lane % 16]  ->  slab z, row m, column n of segment seg
+    float* Wz = a.W + (int64_t)z * M * a.ldw + (seg ? a.seg_w : 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + i * 16 + 4 * lk + r, n = n0 + j * 16 + li;
+                if (m < M && n < N) Wz[m * a.ldw + n] = acc[i][j][r];
+            }
+}
+
 // ---- the highway block's fused products on WHOLE ROWS of A (round 3) ---------------------------------------------------
 // For N_nodes x 300 x [300 | 300] (the dual launch) and dZ.Wh^T + dU.Wt^T (the k-concatenated one) the operand that matters is
 // skinny: K = 300.  A block takes 64 whole rows of A -- one contiguous 77 KB read into LDS (64 x 308 floats: two blocks per CU) --
@@ -787,12 +883,28 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     GEOGCN_REQUIRE(ws && ws_bytes >= need, GEOGCN_E_ARG, "gemm_f32: split-K workspace too small (%zu < %zu)",
                    ws_bytes, need);
     float* W = (float*)ws;
+#ifndef GEOGCN_F32_NO_TN_DIRECT          // (A/B build only: every A^T . B on the staged kernel)
+    if constexpr (AT && !BT && WM == 2 && WN == 4) {
+        // the weight gradients: fragments straight from L1 / L2 into registers, no LDS, no barriers (gemm_tn_direct_kernel)
+        TnDirectArgs t{};
+        t.M = c.M; t.K = c.K[0]; t.A = c.A[0]; t.lda = c.lda[0];
+        for (int q = 0; q < 2; ++q) { t.B[q] = c.B[q]; t.ldb[q] = c.ldb[q]; t.N[q] = c.N[q]; }
+        t.W = W; t.ldw = ldw; t.seg_w = seg_w;
+        t.n_mt = a.n_mt; t.n_nt = n_nt; t.nt_per_seg = nt_per_seg; t.nsplit = sp.nsplit; t.kchunk = sp.kchunk;
+        const int T = t.n_mt * t.n_nt;
+        const dim3 dgrid((unsigned)(cdiv(sp.nsplit, kNumXCD) * kNumXCD * T));
+        hipLaunchKernelGGL((gemm_tn_direct_kernel<BM / 32, BN / 64>), dgrid, dim3(512), 0, st, t);
+        GEOGCN_LAUNCH_CHECK("gemm_tn_direct_kernel");
+    } else
+#endif
+    {
     a.C[0] = W;
     a.ldc[0] = ldw;
     a.slab_seg_w = seg_w;
     a.bias[0] = a.bias[1] = nullptr;
     a.accumulate = 0;
     GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1);
+    }
     for (int q = 0; q < c.n_nseg; ++q) {
         const int rc = splitk_reduce_launch(c.M, c.N[q], sp.nsplit, W + q * seg_w, ldw, c.C[q], c.ldc[q], c.bias[q],
                                             c.act[q], c.accumulate, st);
