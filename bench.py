@@ -242,7 +242,7 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     act = 4 * N * F                                # one N x F fp32 activation
     mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_rows_kernel: 64 whole rows of A per block, dual)", 'gemm_dual_nn', 2 * fl,
          3 * act + 2 * wb, 'f32')
-    mfma("H^T . [dZ | dU]  (gemm_kernel TN, dual, split-K + ordered combine)", 'gemm_dual_tn', 2 * fl, 3 * act + 2 * wb, 'f32')
+    mfma("H^T . [dZ | dU]  (gemm_tn_direct_kernel: fragments straight into registers, no LDS; split-K + ordered combine)", 'gemm_dual_tn', 2 * fl, 3 * act + 2 * wb, 'f32')
     mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl,
          4 * act + 2 * wb, 'f32', "operand bytes: dZ, dU read, the carry read and dH written")
     # single products (every GEMM of the bf16 / bf16x3 configurations, the output layer's in all): label = shape and form
@@ -252,7 +252,7 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
         if 2.0 * M_ * N_ * K_ < 1e9:
             continue
         opb = 4 * (M_ * K_ + K_ * N_) + cb * M_ * N_ * (2 if acc else 1)
-        kern = {'f32': 'gemm_kernel', 'bf16x3': 'gemm_bf16_kernel<NS=3>', 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
+        kern = {'f32': 'gemm_tn_direct_kernel' if form == 'tn' else 'gemm_kernel', 'bf16x3': 'gemm_bf16_kernel<NS=3>', 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
         mfma("%s product %d x %d x %d (%s; C %s%s)" % ({'nn': 'A . B', 'nt': 'A . B^T', 'tn': 'A^T . B'}[form], M_, N_, K_, kern,
                                                          'bf16' if cb == 2 else 'fp32', ', accumulating' if acc else ''),
              key, 2.0 * M_ * N_ * K_, opb, 'bf16' if prec == 'bf16' else 'f32',
@@ -570,7 +570,7 @@ def main():
                        "tuning_overrides": overrides or None,
                        "dropout_stream": "Philox keyed by device row: with --reorder the dropped entries differ from the "
                                          "un-reordered run of the same seed (statistically equivalent, not bitwise)" if args.reorder else "Philox",
-                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
+                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
                                 "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
                        "train_loss_last": float(last[0])},
             "roofline": roofline,
