@@ -883,6 +883,7 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     GEOGCN_REQUIRE(ws && ws_bytes >= need, GEOGCN_E_ARG, "gemm_f32: split-K workspace too small (%zu < %zu)",
                    ws_bytes, need);
     float* W = (float*)ws;
+    int nsplit_used = sp.nsplit;
 #ifndef GEOGCN_F32_NO_TN_DIRECT          // (A/B build only: every A^T . B on the staged kernel)
     if constexpr (AT && !BT && WM == 2 && WN == 4) {
         // the weight gradients: fragments straight from L1 / L2 into registers, no LDS, no barriers (gemm_tn_direct_kernel)
@@ -890,9 +891,17 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
         t.M = c.M; t.K = c.K[0]; t.A = c.A[0]; t.lda = c.lda[0];
         for (int q = 0; q < 2; ++q) { t.B[q] = c.B[q]; t.ldb[q] = c.ldb[q]; t.N[q] = c.N[q]; }
         t.W = W; t.ldw = ldw; t.seg_w = seg_w;
-        t.n_mt = a.n_mt; t.n_nt = n_nt; t.nt_per_seg = nt_per_seg; t.nsplit = sp.nsplit; t.kchunk = sp.kchunk;
+        t.n_mt = a.n_mt; t.n_nt = n_nt; t.nt_per_seg = nt_per_seg;
         const int T = t.n_mt * t.n_nt;
-        const dim3 dgrid((unsigned)(cdiv(sp.nsplit, kNumXCD) * kNumXCD * T));
+        // one 8-wave block per CU and the tiles of a slab on one XCD: an XCD (32 CUs) takes ceil(nsplit / 8) * T blocks -- keep that
+        // within 32, or the 33rd block of an XCD runs after the others (384 x 300: 3 tiles x 85 slabs took twice the time)
+        int ns = sp.nsplit;
+        const int ns_cap = kNumXCD * std::max(1, (kNumCU / kNumXCD) / T);
+        if (ns > ns_cap) ns = ns_cap;
+        t.kchunk = ns == sp.nsplit ? sp.kchunk : cdiv(cdiv(c.K[0], ns), BK) * BK;
+        t.nsplit = (int)cdiv(c.K[0], t.kchunk);
+        nsplit_used = t.nsplit;
+        const dim3 dgrid((unsigned)(cdiv(t.nsplit, kNumXCD) * kNumXCD * T));
         hipLaunchKernelGGL((gemm_tn_direct_kernel<BM / 32, BN / 64>), dgrid, dim3(512), 0, st, t);
         GEOGCN_LAUNCH_CHECK("gemm_tn_direct_kernel");
     } else
@@ -906,7 +915,7 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     GEOGCN_GEMM_LAUNCH(GEOGCN_ACT_NONE, 1);
     }
     for (int q = 0; q < c.n_nseg; ++q) {
-        const int rc = splitk_reduce_launch(c.M, c.N[q], sp.nsplit, W + q * seg_w, ldw, c.C[q], c.ldc[q], c.bias[q],
+        const int rc = splitk_reduce_launch(c.M, c.N[q], nsplit_used, W + q * seg_w, ldw, c.C[q], c.ldc[q], c.bias[q],
                                             c.act[q], c.accumulate, st);
         if (rc) return rc;
     }
