@@ -289,13 +289,14 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
 // flattened over the wave's tiles): no LDS image, no barrier, no load / multiply / store phases -- 8 independent streams per CU,
 // whose loads, MFMAs and C stores overlap because they belong to different waves.  The price: the waves that share a row tile
 // (one per 80-column group) each fetch its A fragments -- the second to eighth time from the CU's L1.
-template <int KP, int WCT, int DEPTH, int PROBE = 0>
-__global__ __launch_bounds__(512, 1) void direct_f32_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+template <int KP, int WCT, int DEPTH, int PROBE = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 1) void direct_f32_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
                                                             const float* __restrict__ Bf, int N, float* __restrict__ C, int64_t ldc,
                                                             int n_mt, int passes) {
     constexpr int MR = 4, NK = KP / 16, D = DEPTH;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wid >= 8) return;                             // (NW > 8: the extra waves only cap the register budget in this probe)
     const int li = lane & 15, lg = lane >> 4;
     const int n_groups = 4 * passes;                  // 80-column groups: 4 (N <= 320) or 8
     const int cg = wid % n_groups, sub = wid / n_groups, n_sub = 8 / n_groups;       // row tiles a block works on at a time: 2 or 1
@@ -394,23 +395,23 @@ __global__ __launch_bounds__(512, 1) void direct_f32_kernel(const float* __restr
     }
 }
 
-template <int KP, int WCT, int DEPTH, int PROBE>
+template <int KP, int WCT, int DEPTH, int PROBE, int NW = 8>
 static void run_direct(const char* name, const float* dA, int64_t lda, int64_t M, int K, const float* dB, int N, float* dC, int64_t ldc,
                        const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
     const int n_mt = (int)((M + 63) / 64);
     const int passes = N <= 4 * WCT * 16 ? 1 : 2;
-    auto kern = direct_f32_kernel<KP, WCT, DEPTH, PROBE>;
+    auto kern = direct_f32_kernel<KP, WCT, DEPTH, PROBE, NW>;
     CK(hipMemset(dC, 0, (size_t)M * ldc * 4));
     const size_t lds = (PROBE & 16) ? 8 * 5120 * 4 : 0;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int reps = 20;
     CK(hipEventRecord(e0));
-    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -496,17 +497,11 @@ int main() {
         CK(hipMemcpy(dF, hF.data(), hF.size() * 4, hipMemcpyHostToDevice));
         printf("N = %d (%.1f GFLOP)\n", N, 2.0 * M * N * K / 1e9);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
-        run_direct<304, 5, 2, 0>("no LDS: direct fragments, 2 ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run_direct<304, 5, 3, 0>("no LDS: direct fragments, 3 ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 8>("  probe: C stores into an L2-resident region", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 64 + (1 << 8)>("  staggered start, 8k cycles per wave", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 64 + (2 << 8)>("  staggered start, 16k cycles per wave", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 2, 64 + (2 << 8)>("  staggered 16k, 2 ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 64 + (3 << 8)>("  staggered start, 24k cycles per wave", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 32>("  instrumented (cycle counter)", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 16>("  probe: C tile into LDS instead of memory", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 4>("  ablation: no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
-        run_direct<304, 5, 3, 6>("  ablation: no A loads, no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run_direct<304, 5, 3, 16>("  C tile into LDS, 3 ahead (8 waves)", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run_direct<304, 5, 1, 16>("  C tile into LDS, 1 ahead (8 waves)", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run_direct<304, 5, 1, 16, 10>("  C tile into LDS, 1 ahead, 10-wave budget", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run_direct<304, 5, 1, 4, 10>("  no C stores, 1 ahead, 10-wave budget", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<304, 64, 5, 2, 0>("whole rows, B 2 steps ahead (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         CK(hipFree(dF));
     }
