@@ -884,8 +884,13 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
                    ws_bytes, need);
     float* W = (float*)ws;
     int nsplit_used = sp.nsplit;
+    bool direct_done = false;
 #ifndef GEOGCN_F32_NO_TN_DIRECT          // (A/B build only: every A^T . B on the staged kernel)
+    // (a slab's rows must lie within one 2 GB buffer descriptor for its end to be a hardware bound; wider operands than the
+    //  GCN's -- rows x pitch x 4 bytes per slab beyond 2^31 -- stay on the staged kernel)
+    const bool direct_ok = (int64_t)sp.kchunk * std::max(c.lda[0], std::max(c.ldb[0], c.n_nseg == 2 ? c.ldb[1] : 0)) * 4 < 0x7FFFFFFFll;
     if constexpr (AT && !BT && WM == 2 && WN == 4) {
+      if (direct_ok) {
         // the weight gradients: fragments straight from L1 / L2 into registers, no LDS, no barriers (gemm_tn_direct_kernel)
         TnDirectArgs t{};
         t.M = c.M; t.K = c.K[0]; t.A = c.A[0]; t.lda = c.lda[0];
@@ -904,9 +909,11 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
         const dim3 dgrid((unsigned)(cdiv(t.nsplit, kNumXCD) * kNumXCD * T));
         hipLaunchKernelGGL((gemm_tn_direct_kernel<BM / 32, BN / 64>), dgrid, dim3(512), 0, st, t);
         GEOGCN_LAUNCH_CHECK("gemm_tn_direct_kernel");
-    } else
+        direct_done = true;
+      }
+    }
 #endif
-    {
+    if (!direct_done) {
     a.C[0] = W;
     a.ldc[0] = ldw;
     a.slab_seg_w = seg_w;

@@ -451,6 +451,43 @@ def test_gemm_dual_transposed_equals_two_calls_bitwise(dev, R, M, N0, N1):
     assert torch.all(o0.t[:, N0:] == 0) and torch.all(o1.t[:, N1:] == 0)
 
 
+@pytest.mark.parametrize("R,M,N", [(9475, 300, 300), (50001, 300, 256), (4099, 256, 300), (9475, 129, 161), (20003, 257, 320),
+                                   (1037, 300, 300), (130, 300, 300), (440000 // 8 + 3, 384, 300)])
+def test_gemm_tn_without_lds_tiles_pitches_and_slab_edges(dev, R, M, N):
+    """gemm_tn_direct_kernel (A^T . B with every fragment loaded straight into registers: the four 8-wave tile shapes 160 / 128 x
+    320 / 256, reduction lengths that are not multiples of 4 or of the slab length, outputs that do not fill the last 16 x 16
+    tile, operands that are ROW RANGES of pitched matrices with garbage beyond their columns and rows -- the kernel masks by
+    column and bounds each slab's descriptor, so nothing outside may leak in), against the fp64 product; run to run bitwise."""
+    from geographconv_amd import ops
+    A = _rand((R, M), 11)
+    B = _rand((R, N), 12)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    tol = 3e-6 * (np.abs(A).T @ np.abs(B)) + 1e-5
+    # operands embedded in larger buffers: pitch beyond the width, rows before and after, everything outside = NaN-free garbage
+    bigA = ops.DMat.empty(R + 7, M, dev, ld=ops.gather_ld(M) + 8)
+    bigB = ops.DMat.empty(R + 7, N, dev, ld=ops.gather_ld(N))
+    bigA.t.fill_(1e30)
+    bigB.t.fill_(-1e30)
+    bigA.t[3:3 + R, :M] = torch.from_numpy(A).to(dev)
+    bigB.t[3:3 + R, :N] = torch.from_numpy(B).to(dev)
+    # (the library's convention: pad columns up to roundup4 are zero)
+    bigA.t[3:3 + R, M:ops.pad4(M)] = 0
+    bigB.t[3:3 + R, N:ops.pad4(N)] = 0
+    dA, dB = bigA.rows(3, 3 + R), bigB.rows(3, 3 + R)
+    g1 = ops.gemm(dA, dB, transA=True)
+    assert np.all(np.abs(g1.numpy() - ref) <= tol), np.abs(g1.numpy() - ref).max()
+    assert torch.all(g1.t[:, N:] == 0)
+    g2 = ops.gemm(dA, dB, transA=True)
+    assert torch.equal(g1.t, g2.t)
+    # accumulate + bias + activation go through the ordered combine
+    bias = torch.from_numpy(_rand((ops.pad4(N),), 13)).to(dev)
+    C0 = _rand((M, N), 14)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm(dA, dB, out=dC, transA=True, bias=bias, act=ops.ACT_TANH, accumulate=True)
+    want = np.tanh(ref + bias.cpu().numpy()[:N].astype(np.float64)) + C0
+    assert np.all(np.abs(dC.numpy() - want) <= tol + 2e-6)
+
+
 @pytest.mark.parametrize("M,K,N0,N1", [(40000, 300, 300, 300), (33001, 300, 300, 600), (32768, 256, 300, 300), (50001, 290, 620, 289)])
 def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
     """The fused highway launches on gemm_rows_kernel (64 whole rows of A per block, weights in fragment order; taken when the
