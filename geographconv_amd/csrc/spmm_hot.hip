@@ -83,7 +83,7 @@ struct HotArgs {
 template <int K4, int ACT, int DROP = 0, int BUF = 1>
 __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 hot[];         // [n_hot][K4][16]
-    const int lane = threadIdx.x % kGroup, g = threadIdx.x / kGroup;
+    const int lane = threadIdx.x % kGroup;
     const int nF4 = (a.F + 3) >> 2;
     for (int i = threadIdx.x; i < a.n_hot * K4 * kGroup; i += kThreads) {
         const int slot = i / (K4 * kGroup), r = i % (K4 * kGroup);
@@ -91,11 +91,22 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
         const int q = l + kGroup * k;
         hot[i] = (q < nF4) ? ld4g(a.B + (int64_t)a.hot_rows[slot] * a.ldb, q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // Rows are handed out DYNAMICALLY inside the workgroup: workgroup b owns the contiguous rows [r_lo, r_hi) and every wave takes
+    // the next four of them from a counter in LDS when it has finished its last four.  (A fixed stride gave every 16-lane group 27
+    // rows of a log-normal length distribution -- the slowest of the 16,384 groups set the kernel's time.)  Which wave computes a
+    // row never changes a value.
+    __shared__ unsigned next_row;
+    if (threadIdx.x == 0) next_row = 0;
     __syncthreads();
-    const int n_tiles = (a.n_rows + kGroups - 1) / kGroups;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int row = tile * kGroups + g;
-        if (row >= a.n_rows) continue;
+    const int r_lo = (int)((int64_t)a.n_rows * blockIdx.x / gridDim.x), r_hi = (int)((int64_t)a.n_rows * (blockIdx.x + 1) / gridDim.x);
+    const int gw = (threadIdx.x & 63) / kGroup;          // group inside the wave
+    while (true) {
+        unsigned base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&next_row, 64 / kGroup);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (r_lo + (int)base >= r_hi) break;
+        const int row = r_lo + (int)base + gw;
+        if (row >= r_hi) continue;
         const int s = a.rowptr[row], h = a.rowsplit[row], e = a.rowptr[row + 1];
         float4 acc[K4];
 #pragma unroll
@@ -299,7 +310,7 @@ static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act
         auto kern = hot_kernel_for<K, ACT, DROP>(buf);                                                              \
         static bool attr_done[2] = {false, false};                                                                  \
         if (!attr_done[buf]) {                                                                                      \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kHotLdsBytes)); \
             attr_done[buf] = true;                                                                                  \
         }                                                                                                           \
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);                                                 \
