@@ -32,9 +32,9 @@ SIGNATURES = {
     'geogcn_spmm_csr_acc_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                         c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_spmm_hot_capacity': (c_i32, [c_i32]),
-    'geogcn_spmm_csr_hot_f32': (c_i32, [c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_i32,
+    'geogcn_spmm_csr_hot_f32': (c_i32, [c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32,
                                         c_ptr, c_i32, c_ptr]),
-    'geogcn_spmm_csr_hot_dropout_f32': (c_i32, [c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_ptr, c_i64,
+    'geogcn_spmm_csr_hot_dropout_f32': (c_i32, [c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64,
                                                 c_i32, c_ptr, c_i32, c_f32, c_ptr, c_ptr, c_u64, c_u64, c_ptr, c_i64, c_i64, c_ptr]),
     'geogcn_xt_plan_create': (c_i32, [c_i32, c_i32, c_ptr, c_ptr, c_i32, C.POINTER(c_ptr)]),
     'geogcn_xt_plan_destroy': (None, [c_ptr]),

@@ -67,6 +67,7 @@ struct HotArgs {
     const float* val;
     const float* B; int64_t ldb;
     const int* hot_rows; int n_hot;
+    const int* row_order;       // nullable: position -> row (rows of similar length next to each other; see geogcn.h)
     float* C; int64_t ldc;
     int F;
     const float* bias;
@@ -105,8 +106,9 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
         if ((threadIdx.x & 63) == 0) base = atomicAdd(&next_row, 64 / kGroup);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (r_lo + (int)base >= r_hi) break;
-        const int row = r_lo + (int)base + gw;
-        if (row >= r_hi) continue;
+        const int pos = r_lo + (int)base + gw;
+        if (pos >= r_hi) continue;
+        const int row = a.row_order ? a.row_order[pos] : pos;
         const int s = a.rowptr[row], h = a.rowsplit[row], e = a.rowptr[row + 1];
         float4 acc[K4];
 #pragma unroll
@@ -337,17 +339,18 @@ static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act
 }
 
 int geogcn_spmm_csr_hot_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
-                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
-                            int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream) {
+                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
+                            const int32_t* row_order, float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream) {
     HotArgs a{};
-    a.n_rows = n_rows; a.n_cols = n_cols; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
+    a.n_rows = n_rows; a.n_cols = n_cols; a.row_order = row_order; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
     a.hot_rows = hot_rows; a.n_hot = n_hot; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
     return spmm_hot_launch("spmm_csr_hot_f32", a, n_hot, act, 0, (hipStream_t)stream);
 }
 
 int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
                                     const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
-                                    float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act, float p_drop,
+                                    const int32_t* row_order, float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act,
+                                    float p_drop,
                                     const uint8_t* mask_in, uint8_t* mask_out, uint64_t seed, uint64_t offset,
                                     const int64_t* calls_dev, int64_t per_call_elems, int64_t base_elems, void* stream) {
     const char* fn = "spmm_csr_hot_dropout_f32";
@@ -362,7 +365,7 @@ int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, int32_t n_cols, const int32_
                    "and 4-byte aligned masks (F=%d)", fn, F);
     HotArgs a{};
     a.n_rows = n_rows; a.n_cols = n_cols; a.rowptr = rowptr; a.rowsplit = rowsplit; a.colidx = colidx; a.val = val; a.B = B; a.ldb = ldb;
-    a.hot_rows = hot_rows; a.n_hot = n_hot; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
+    a.hot_rows = hot_rows; a.n_hot = n_hot; a.row_order = row_order; a.C = C; a.ldc = ldc; a.F = F; a.bias = bias;
     a.Cd = Cd; a.mask_in = mask_in; a.mask_out = mask_out; a.keep_prob = 1.0f - p_drop; a.scale = 1.0f / (1.0f - p_drop);
     a.seed = seed; a.offset = offset; a.calls = calls_dev; a.per_call = per_call_elems; a.base = base_elems;
     return spmm_hot_launch(fn, a, n_hot, act, 1, (hipStream_t)stream);

@@ -897,6 +897,21 @@ class HotCSR:
         self.colidx = torch.from_numpy(np.ascontiguousarray(col2)).to(dev)
         self.val = torch.from_numpy(np.ascontiguousarray(values_host[order], dtype=np.float32)).to(dev)
         self.hot_rows = torch.from_numpy(hot).to(dev)
+        # working order of the rows (speed only): the four rows a wave takes at a time run in lockstep, so rows of similar COLD
+        # length (the dependent L2 round trips) go next to each other -- sorted, longest first, then the groups of four dealt round
+        # the 256 workgroups so that each gets the same mix and starts with its longest rows
+        cold_per_row = (np.diff(indptr) - hot_per_row).astype(np.int64)
+        by_len = np.argsort(-cold_per_row, kind='stable').astype(np.int32)
+        n = len(by_len)
+        n_wg, quad = 256, 4
+        groups = -(-n // quad)
+        pad = np.full(groups * quad, -1, dtype=np.int32)
+        pad[:n] = by_len
+        pad = pad.reshape(groups, quad)
+        dealt = np.concatenate([pad[c::n_wg] for c in range(n_wg)]).ravel()
+        order_rows = dealt[dealt >= 0]
+        assert len(order_rows) == n
+        self.row_order = torch.from_numpy(np.ascontiguousarray(order_rows, dtype=np.int32)).to(dev) if tuning.HOT_ROW_ORDER else None
 
 
 def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, col0=0, F=None):
@@ -910,7 +925,7 @@ def spmm_hot(A: HotCSR, B: DMat, out: DMat = None, bias: torch.Tensor = None, ac
         raise ValueError("spmm_hot: bad column slab [%d, %d) of %d" % (col0, col0 + F, B.F))
     at = lambda t: None if t is None else C.c_void_p(t.data_ptr() + 4 * col0)
     check(_ffi.lib().geogcn_spmm_csr_hot_f32(A.shape[0], B.n, _p(A.rowptr), _p(A.rowsplit), _p(A.colidx), _p(A.val), at(B.t), B.ld,
-                                             _p(A.hot_rows), A.n_hot, at(out.t), out.ld, F, at(bias), act, _stream()),
+                                             _p(A.hot_rows), A.n_hot, _p(A.row_order), at(out.t), out.ld, F, at(bias), act, _stream()),
           'spmm_csr_hot_f32')
     return out
 
@@ -961,7 +976,7 @@ def spmm_x_dropout(x: SparseOperand, W: DMat, bias, act, p, mask_in=None, seed=0
     H0, Hd = DMat.empty(n, W.F, W.device), DMat.empty(n, W.F, W.device)
     mask = mask_in if mask_in is not None else torch.empty((n, W.F), dtype=torch.uint8, device=W.device)
     check(lib.geogcn_spmm_csr_hot_dropout_f32(n, W.n, _p(hot.rowptr), _p(hot.rowsplit), _p(hot.colidx), _p(hot.val), _p(W.t), W.ld,
-                                              _p(hot.hot_rows), hot.n_hot, _p(H0.t), _p(Hd.t), H0.ld, W.F, _p(bias), int(act),
+                                              _p(hot.hot_rows), hot.n_hot, _p(hot.row_order), _p(H0.t), _p(Hd.t), H0.ld, W.F, _p(bias), int(act),
                                               float(p), _p(mask_in), None if mask_in is not None else _p(mask), int(seed),
                                               int(offset), _p(calls_dev), int(per_call), int(base), _stream()),
           'spmm_csr_hot_dropout_f32')

@@ -63,6 +63,9 @@ XT_MIN_NNZ = 1_000_000
 # ... in column slabs of at most this width (2 x F/64 float4 accumulators per lane: up to 320 columns 1024-thread
 # workgroups fit; F = 600 in one piece 5.5 ms, as two slabs of 300 3.0 ms)
 XT_MAX_F = 320
+# X . W0: rows worked on in an order that puts rows of similar cold length into the same wave (ops.HotCSR.row_order); False = natural
+# order (the A/B)
+HOT_ROW_ORDER = True
 # X . W0 with the hot rows of W0 in LDS (geogcn_spmm_csr_hot_f32) from this many stored entries on
 HOT_MIN_NNZ = 2_000_000
 

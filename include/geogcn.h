@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: round 3 changed exported signatures incompatibly (geogcn_spmm_plan_create: chunks_with_owner instead of a rowsplit pointer;
  * geogcn_gemm_kcat_f32: ws / ws_bytes before stream; geogcn_spmm_plan_attach_timer replaced geogcn_timer_attach_spmm);
- * round 4: geogcn_spmm_csr_hot_f32 / _hot_dropout_f32 take n_cols after n_rows. */
+ * round 4: geogcn_spmm_csr_hot_f32 / _hot_dropout_f32 take n_cols after n_rows and row_order after n_hot. */
 #define GEOGCN_ABI_VERSION 2
 
 #define GEOGCN_E_NULL   (-1)   /* required pointer is NULL            */
@@ -88,11 +88,14 @@ int geogcn_spmm_csr_acc_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_
  * colidx of a HOT entry holds its LDS slot s (0 <= s < n_hot) instead of the column.  n_hot <= geogcn_spmm_hot_capacity(F)
  * (0 = this width is not supported: use geogcn_spmm_csr_f32).  Accumulation is sequential in the stored order.
  * n_cols = rows of B (every cold column index is < n_cols): when n_cols * ldb * 4 < 2^31 the cold rows are gathered through
- * one buffer descriptor with 32-bit offsets, four rows in flight per 16-lane group; 0 = unknown (64-bit addresses, two).  */
+ * one buffer descriptor with 32-bit offsets, four rows in flight per 16-lane group; 0 = unknown (64-bit addresses, two).
+ * row_order (nullable; a permutation of [0, n_rows)): the ORDER in which rows are worked on -- speed only, never a value: the four
+ * 16-lane groups of a wave run in lockstep, so a wave takes as long as the longest of its four rows; the caller can put rows of
+ * similar cold length next to each other (workgroup b of G works on positions [n_rows b / G, n_rows (b+1) / G), four per wave). */
 int32_t geogcn_spmm_hot_capacity(int32_t F);
 int geogcn_spmm_csr_hot_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
-                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot, float* C,
-                            int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream);
+                            const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
+                            const int32_t* row_order, float* C, int64_t ldc, int32_t F, const float* bias, int32_t act, void* stream);
 
 /* The same product with the dropout that FOLLOWS this layer in the reference (lasagne.layers.dropout, gcnmodel.py:357)
  * in its epilogue:  C = act(A . B + bias)  (the layer output, which the backward differentiates through),
@@ -104,7 +107,8 @@ int geogcn_spmm_csr_hot_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowpt
  * act is tanh or none.                                                                                           */
 int geogcn_spmm_csr_hot_dropout_f32(int32_t n_rows, int32_t n_cols, const int32_t* rowptr, const int32_t* rowsplit, const int32_t* colidx,
                                     const float* val, const float* B, int64_t ldb, const int32_t* hot_rows, int32_t n_hot,
-                                    float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act, float p_drop,
+                                    const int32_t* row_order, float* C, float* Cd, int64_t ldc, int32_t F, const float* bias, int32_t act,
+                                    float p_drop,
                                     const uint8_t* mask_in, uint8_t* mask_out, uint64_t seed, uint64_t offset,
                                     const int64_t* calls_dev, int64_t per_call_elems, int64_t base_elems, void* stream);
 

@@ -751,7 +751,7 @@ def test_spmm_hot_with_the_dropout_in_its_epilogue(dev, n_docs, n_words, mean, F
     lib = _ffi.lib()
     hot = next(iter(x._hot.values()))
     rc = lib.geogcn_spmm_csr_hot_dropout_f32(n_docs, n_words, ops._p(hot.rowptr), ops._p(hot.rowsplit), ops._p(hot.colidx), ops._p(hot.val),
-                                             ops._p(W7.t), W7.ld, ops._p(hot.hot_rows), 0, ops._p(H0.t), ops._p(Hd.t), H0.ld, 30,
+                                             ops._p(W7.t), W7.ld, ops._p(hot.hot_rows), 0, None, ops._p(H0.t), ops._p(Hd.t), H0.ld, 30,
                                              None, 1, 0.5, None, ops._p(mask), 1, 0, None, 0, 0, ops._stream())
     assert rc == -3                                        # GEOGCN_E_ALIGN
 
