@@ -57,8 +57,22 @@ class ClockSampler:
         self.files = {}
         cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
         cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
+        self.card = None
         if cards:
             hw = cards[min(index, len(cards) - 1)]
+            self.card = "hwmon #%d of %d (no PCI match)" % (min(index, len(cards) - 1), len(cards))
+            # A box can show the hwmon directories of GPUs this process cannot see: take the one whose PCI address is the device's.
+            try:
+                import torch
+                pr = torch.cuda.get_device_properties(index)
+                want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+                for c in cards:
+                    pci = os.path.basename(os.path.realpath(os.path.join(c, '..', '..')))
+                    if pci.startswith(want):
+                        hw, self.card = c, "PCI " + pci
+                        break
+            except (AttributeError, RuntimeError, AssertionError):
+                pass
             for key, name in (('sclk_mhz', 'freq1_input'), ('mclk_mhz', 'freq2_input'), ('power_w', 'power1_input'),
                               ('power_cap_w', 'power1_cap'), ('temp_c', 'temp2_input')):
                 f = os.path.join(hw, name)
@@ -104,7 +118,7 @@ class ClockSampler:
         wall = time.perf_counter() - t0
         keep = max(1, int(len(next(iter(self.samples.values()), [])) * min(1.0, 1.0 / wall)))
         self.samples = {k: v[-keep:] for k, v in self.samples.items()}
-        out = {"how": "amdgpu hwmon (freq1_input / freq2_input / power1_input / temp2_input) polled every ~15 ms by a thread while "
+        out = {"card": self.card, "how": "amdgpu hwmon (freq1_input / freq2_input / power1_input / temp2_input) polled every ~15 ms by a thread while "
                       "%d further f_train steps ran for %.1f s after the timed region; min / median / max over the last second (the "
                       "SMU telemetry is a moving average)" % (n, wall), "samples": keep}
         for k, v in self.samples.items():
