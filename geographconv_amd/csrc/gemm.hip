@@ -1001,15 +1001,22 @@ inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int 
 }
 
 // ---- whole-rows kernel: which calls take it, its workspace, its launch ---------------------------------------------------------
-// Only the fused launches (two N segments or two K segments): a single 300-wide product runs as fast on the staged kernel
-// (0.74 against 0.75 ms).  Every segment must fill its column passes (a pass is 320 columns: 300 -> 320 is the padding the
+// The fused launches (two N segments or two K segments) and, since round 4, single A . B^T products (rows_kp); a single 300-wide
+// A . B runs as fast on the staged kernel (0.74 against 0.75 ms).  Every segment must fill its column passes (a pass is 320 columns: 300 -> 320 is the padding the
 // staged kernel has as well; 256 would multiply 64 columns of zeros: at most an eighth may be padding) and K must pad to an instantiated depth.
 inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
-inline int rows_kp(const GemmCall& c, bool transA) {
+inline int rows_kp(const GemmCall& c, bool transA, bool transB = false) {
 #ifdef GEOGCN_F32_NO_ROWS_KERNEL          // A/B build only (GEOGCN_BUILD_DEFINES): every call on the staged kernel
     return 0;
 #endif
-    if (transA || c.panel_w || (c.n_nseg == 1 && c.n_kseg == 1) || c.M < 32768) return 0;
+    // (round 4) ... and the single A . B^T products (dH = dS . W^T of the output layer and of plain layers): the staged kernel's
+    // weakest form (96 x 160 tiles, 0.57 of the MFMA peak at 440,000 x 300 x 256); here the weights are laid out in fragment
+    // order whatever their orientation
+    bool single_ok = transB;
+#ifdef GEOGCN_F32_NO_ROWS_SINGLE          // A/B build only
+    single_ok = false;
+#endif
+    if (transA || c.panel_w || (c.n_nseg == 1 && c.n_kseg == 1 && !single_ok) || c.M < 32768) return 0;
     const int64_t kp = cdiv(c.K[0], 16) * 16;
     if (kp != 304 && kp != 256) return 0;
     if (c.n_kseg == 2 && (cdiv(c.K[1], 16) * 16 != kp || c.N[0] > 320)) return 0;      // one accumulator: one column pass
@@ -1081,7 +1088,7 @@ int run_rows(int kp, bool transB, const GemmCall& c, void* ws, hipStream_t st) {
 }
 
 int run_call(bool transA, bool transB, const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
-    if (const int kp = rows_kp(c, transA); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp))
+    if (const int kp = rows_kp(c, transA, transB); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp))
         return run_rows(kp, transB, c, ws, st);          // (too small a workspace -- an older caller: the staged kernel)
     int bm, bn;
     choose_tiles(transA, transB, c.M, c.maxN(), c.n_nseg, bm, bn);
@@ -1117,9 +1124,14 @@ extern "C" {
 
 size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
                                    int32_t precision) {
-    (void)transB;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    if (!transA) return precision == GEOGCN_GEMM_F32 ? 0 : gemm_bf16_workspace_bytes(precision, N, K);
+    if (!transA && precision == GEOGCN_GEMM_F32) {      // the whole-rows kernel's fragment-ordered weights (0: the staged kernel)
+        GemmCall c{};
+        c.M = M; c.n_nseg = 1; c.n_kseg = 1; c.N[0] = N; c.K[0] = K;
+        const int kp = rows_kp(c, false, transB != 0);
+        return kp ? rows_ws_bytes(c, kp) : 0;
+    }
+    if (!transA) return gemm_bf16_workspace_bytes(precision, N, K);
     if (precision == GEOGCN_GEMM_BF16) {
         const size_t h = gemm_bf16_tn_workspace_bytes(M, N, K);      // 0: shape left to the fp32 kernel
         if (h) return h;
