@@ -267,7 +267,8 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
             continue
         opb = 4 * (M_ * K_ + K_ * N_) + cb * M_ * N_ * (2 if acc else 1)
         kern = {'f32': 'gemm_tn_direct_kernel' if form == 'tn' else
-                       ('gemm_rows_kernel' if form == 'nt' and M_ >= 32768 and N_ <= 640 and -(-K_ // 16) * 16 in (256, 304) else 'gemm_kernel'), 'bf16x3': 'gemm_bf16_kernel<NS=3>', 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
+                       ('gemm_rows_kernel' if (form == 'nt' or N_ in range(193, 257) or N_ in range(449, 513)) and M_ >= 32768 and N_ <= 640
+                        and -(-K_ // 16) * 16 in (256, 304) else 'gemm_kernel'), 'bf16x3': 'gemm_bf16_kernel<NS=3>', 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
         mfma("%s product %d x %d x %d (%s; C %s%s)" % ({'nn': 'A . B', 'nt': 'A . B^T', 'tn': 'A^T . B'}[form], M_, N_, K_, kern,
                                                          'bf16' if cb == 2 else 'fp32', ', accumulating' if acc else ''),
              key, 2.0 * M_ * N_ * K_, opb, 'bf16' if prec == 'bf16' else 'f32',

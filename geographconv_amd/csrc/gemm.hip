@@ -583,7 +583,8 @@ struct RowsArgs {
     int n_kseg;                         // 1, or 2 A operands reduced into one accumulator (then ONE column pass)
     const float* A[2]; int64_t lda[2]; int K[2];
     const float* Bf[2];                 // fragment-ordered weights of slot q = N segment | K segment
-    int n_nseg; int passes[2];          // column passes of each N segment (4 waves x 5 tiles x 16 columns per pass)
+    int n_nseg; int passes[2];          // column passes of each N segment (4 waves x wct tiles x 16 columns per pass)
+    int wct[2];                         // column tiles a wave takes per pass: 5, or 4 where 4 x passes x 4 tiles cover the segment (N = 256, 512)
     float* C[2]; int64_t ldc[2]; const float* bias[2]; int64_t N[2]; int act_on[2];
     int accumulate;
 };
@@ -639,9 +640,10 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
                 // (300 columns = 19 tiles of 16 over 4 waves: 5, 5, 5, 4) visits every SIMD in turn -- the two co-resident
                 // blocks of a CU then share MFMA pipes that carry 4.75 instead of 5 tiles per wave on average
                 const int cg = (wid + mt) & 3;
-                const int tile0 = (cg * (seg ? a.passes[1] : a.passes[0]) + lps) * WCT;
-                // does the LAST of this wave's column tiles hold any real column?  (wave-uniform: a scalar branch per k-step)
-                const bool last_real = __builtin_amdgcn_readfirstlane((int)((int64_t)(tile0 + WCT - 1) * 16 < (seg ? a.N[1] : a.N[0]))) != 0;
+                const int w = seg ? a.wct[1] : a.wct[0];
+                const int tile0 = (cg * (seg ? a.passes[1] : a.passes[0]) + lps) * w;
+                // does the LAST of this wave's column tiles hold any real column OF ITS OWN?  (wave-uniform: a scalar branch per k-step)
+                const bool last_real = __builtin_amdgcn_readfirstlane((int)(w == WCT && (int64_t)(tile0 + WCT - 1) * 16 < (seg ? a.N[1] : a.N[0]))) != 0;
                 const int slot = seg | ks;
                 const int n_tiles = 4 * (seg ? a.passes[1] : a.passes[0]) * WCT;
                 const __amdgpu_buffer_rsrc_t brs = tile_rsrc(slot ? a.Bf[1] : a.Bf[0], (int64_t)n_tiles * NK * 1024);
@@ -697,7 +699,8 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
                 float* Cout = seg ? a.C[1] : a.C[0];
                 const int64_t ldc = seg ? a.ldc[1] : a.ldc[0];
                 const float* bias = seg ? a.bias[1] : a.bias[0];
-                const int64_t Nseg = seg ? a.N[1] : a.N[0];
+                // (columns from tile0 + w on belong to the next wave)
+                const int64_t Nseg = std::min<int64_t>(seg ? a.N[1] : a.N[0], (int64_t)(tile0 + w) * 16);
                 const bool act_on = (seg ? a.act_on[1] : a.act_on[0]) != 0;
                 const int64_t ncol0 = (int64_t)tile0 * 16;
                 float bcol[WCT][4];
@@ -1005,6 +1008,7 @@ inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int 
 // A . B runs as fast on the staged kernel (0.74 against 0.75 ms).  Every segment must fill its column passes (a pass is 320 columns: 300 -> 320 is the padding the
 // staged kernel has as well; 256 would multiply 64 columns of zeros: at most an eighth may be padding) and K must pad to an instantiated depth.
 inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
+inline int rows_wct(int64_t N) { return (int)cdiv(cdiv(N, 16), 4 * rows_passes(N)); }      // 5, or 4 (N <= 256, 321..512), or fewer
 inline int rows_kp(const GemmCall& c, bool transA, bool transB = false) {
 #ifdef GEOGCN_F32_NO_ROWS_KERNEL          // A/B build only (GEOGCN_BUILD_DEFINES): every call on the staged kernel
     return 0;
@@ -1012,7 +1016,8 @@ inline int rows_kp(const GemmCall& c, bool transA, bool transB = false) {
     // (round 4) ... and the single A . B^T products (dH = dS . W^T of the output layer and of plain layers): the staged kernel's
     // weakest form (96 x 160 tiles, 0.57 of the MFMA peak at 440,000 x 300 x 256); here the weights are laid out in fragment
     // order whatever their orientation
-    bool single_ok = transB;
+    // ... and single A . B products whose width four waves cover with FOUR column tiles each (N = 256: the output layer's logits)
+    bool single_ok = transB || (c.N[0] > 192 && rows_wct(c.N[0]) == 4);
 #ifdef GEOGCN_F32_NO_ROWS_SINGLE          // A/B build only
     single_ok = false;
 #endif
@@ -1022,7 +1027,7 @@ inline int rows_kp(const GemmCall& c, bool transA, bool transB = false) {
     if (c.n_kseg == 2 && (cdiv(c.K[1], 16) * 16 != kp || c.N[0] > 320)) return 0;      // one accumulator: one column pass
     for (int q = 0; q < c.n_nseg; ++q) {
         if (c.N[q] > 640) return 0;
-        const int64_t cols = (int64_t)rows_passes(c.N[q]) * 320;
+        const int64_t cols = (int64_t)rows_passes(c.N[q]) * 4 * std::max(rows_wct(c.N[q]), 4) * 16;
         if ((cols - c.N[q]) * 8 > cols) return 0;              // at most an eighth of a pass multiplies zero columns
     }
     return (int)kp;
@@ -1068,6 +1073,7 @@ int run_rows(int kp, bool transB, const GemmCall& c, void* ws, hipStream_t st) {
         a.C[q] = c.C[q]; a.ldc[q] = c.ldc[q]; a.bias[q] = c.bias[q]; a.N[q] = c.N[q];
         a.act_on[q] = c.act[q] != GEOGCN_ACT_NONE;
         a.passes[q] = c.N[q] > 0 ? rows_passes(c.N[q]) : 0;
+        a.wct[q] = c.N[q] > 0 ? std::max(rows_wct(c.N[q]), 4) : kRowsWCT;
     }
     // slot q = N segment | K segment: its weights in fragment order
     const int n_slots = (c.n_nseg == 2 || c.n_kseg == 2) ? 2 : 1;

@@ -488,7 +488,8 @@ def test_gemm_tn_without_lds_tiles_pitches_and_slab_edges(dev, R, M, N):
     assert np.all(np.abs(dC.numpy() - want) <= tol + 2e-6)
 
 
-@pytest.mark.parametrize("M,K,N0,N1", [(40000, 300, 300, 300), (33001, 300, 300, 600), (32768, 256, 300, 300), (50001, 290, 620, 289)])
+@pytest.mark.parametrize("M,K,N0,N1", [(40000, 300, 300, 300), (33001, 300, 300, 600), (32768, 256, 300, 300), (50001, 290, 620, 289),
+                                      (40001, 300, 256, 512), (33000, 256, 250, 500)])
 def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
     """The fused highway launches on gemm_rows_kernel (64 whole rows of A per block, weights in fragment order; taken when the
     caller supplies the workspace): the dual launch and the k-concatenated one are BIT-identical to the staged kernel -- the
@@ -534,31 +535,40 @@ def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
                 assert torch.equal(out.t, want.t), (transB, acc)
 
 
-@pytest.mark.parametrize("M,N,K", [(40000, 300, 256), (33001, 300, 300), (50001, 289, 250), (32768, 600, 300)])
-def test_single_a_bt_product_on_the_whole_rows_kernel_bitwise(dev, M, N, K):
-    """dH = dS . W^T (the output layer's and plain layers' backward) takes gemm_rows_kernel when the caller supplies the
-    workspace geogcn_gemm_workspace_bytes asks for: BIT-identical to the staged kernel (same call, NULL workspace) through bias,
-    activation and accumulate; A . B (not transposed) stays on the staged kernel (no workspace asked)."""
+@pytest.mark.parametrize("M,N,K,transB", [(40000, 300, 256, True), (33001, 300, 300, True), (50001, 289, 250, True), (32768, 600, 300, True),
+                                         (40000, 256, 300, False), (33001, 250, 256, False), (32768, 512, 300, False), (40000, 256, 300, True)])
+def test_single_products_on_the_whole_rows_kernel_bitwise(dev, M, N, K, transB):
+    """dH = dS . W^T (the output layer's and plain layers' backward) and A . B products of 256 / 512 columns (the logits: four waves
+    x four column tiles) take gemm_rows_kernel when the caller supplies the workspace geogcn_gemm_workspace_bytes asks for:
+    BIT-identical to the staged kernel (same call, NULL workspace) through bias, activation and accumulate; a 300-wide A . B
+    stays on the staged kernel (no workspace asked)."""
     import ctypes as C
     from geographconv_amd import _ffi, ops
     lib = _ffi.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert lib.geogcn_gemm_workspace_bytes(0, 1, M, N, K, _ffi.GEMM_F32) > 0
-    assert lib.geogcn_gemm_workspace_bytes(0, 0, M, N, K, _ffi.GEMM_F32) == 0
-    assert lib.geogcn_gemm_workspace_bytes(0, 1, 1000, N, K, _ffi.GEMM_F32) == 0          # too few rows: staged
+    assert lib.geogcn_gemm_workspace_bytes(0, int(transB), M, N, K, _ffi.GEMM_F32) > 0
+    assert lib.geogcn_gemm_workspace_bytes(0, 0, M, 300, K, _ffi.GEMM_F32) == 0
+    assert lib.geogcn_gemm_workspace_bytes(0, int(transB), 1000, N, K, _ffi.GEMM_F32) == 0          # too few rows: staged
     A = ops.DMat.from_numpy(_rand((M, K), 1), dev)
-    W = ops.DMat.from_numpy(_rand((N, K), 2, 0.1), dev)
+    W = ops.DMat.from_numpy(_rand((N, K) if transB else (K, N), 2, 0.1), dev)
     bias = torch.from_numpy(_rand((ops.pad4(N),), 3)).to(dev)
     for acc, b, act in ((False, None, ops.ACT_NONE), (True, None, ops.ACT_NONE), (False, bias, ops.ACT_TANH)):
         C0 = _rand((M, N), 4)
         got, want = ops.DMat.from_numpy(C0, dev), ops.DMat.from_numpy(C0, dev)
-        ops.gemm(A, W, out=got, transB=True, bias=b, act=act, accumulate=acc)
-        _ffi.check(lib.geogcn_gemm_f32(0, 1, M, N, K, ops._p(A.t), A.ld, ops._p(W.t), W.ld, ops._p(want.t), want.ld, ops._p(b), act,
-                                       int(acc), _ffi.GEMM_F32, None, 0, st), 'A . B^T, staged')
+        ops.gemm(A, W, out=got, transB=transB, bias=b, act=act, accumulate=acc)
+        _ffi.check(lib.geogcn_gemm_f32(0, int(transB), M, N, K, ops._p(A.t), A.ld, ops._p(W.t), W.ld, ops._p(want.t), want.ld, ops._p(b),
+                                       act, int(acc), _ffi.GEMM_F32, None, 0, st), 'single product, staged')
         assert torch.equal(got.t, want.t), (acc, act)
-    ref = A.numpy().astype(np.float64) @ W.numpy().astype(np.float64).T
-    got = ops.gemm(A, W, transB=True)
-    assert np.all(np.abs(got.numpy() - ref) <= 2e-6 * (np.abs(A.numpy()) @ np.abs(W.numpy()).T) + 1e-6)
+    Wn = W.numpy().astype(np.float64)
+    Wn = Wn.T if transB else Wn
+    ref = A.numpy().astype(np.float64) @ Wn
+    got = ops.gemm(A, W, transB=transB)
+    assert np.all(np.abs(got.numpy() - ref) <= 2e-6 * (np.abs(A.numpy()) @ np.abs(Wn)) + 1e-6)
+    # a gather-pitch output keeps its pad columns
+    wide = ops.DMat.empty(M, N, dev, ld=ops.gather_ld(N) + 32)
+    wide.t.fill_(7.0)
+    ops.gemm(A, W, out=wide, transB=transB)
+    assert torch.equal(wide.t[:, :N], got.t[:, :N]) and torch.all(wide.t[:, ops.pad4(N):] == 7.0)
 
 
 @pytest.mark.parametrize("M,N,K0,K1", [(1000, 300, 300, 300), (4100, 600, 600, 600), (777, 300, 129, 300), (333, 16, 40, 64),
