@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TPB) void highway_bwd_kernel(int64_t n, int ld4, co
         if constexpr (S16) ((uint2*)dSv)[es] = pack_bf16x4(s);
         else dS[es] = s;
         dU[e] = u;
-        dHc[e] = c;
+        if (dHc) dHc[e] = c;          // (NULL: the carry is formed where it is consumed -- geogcn_gemm_kcat_gated_f32)
     }
 }
 
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int 
                 dS[row * ld4_dS + q] = s;
             }
             dU[e] = u;
-            dHc[e] = c;
+            if (dHc) dHc[e] = c;
         };
         int64_t row = r0 + ri;
         for (; row + rpi < r1; row += 2 * rpi) {
@@ -210,6 +210,20 @@ __global__ __launch_bounds__(TPB) void highway_bwd_colsum_kernel(int64_t n, int 
         }
         P[(int64_t)blockIdx.x * 2 * W + q] = aS;
         P[(int64_t)blockIdx.x * 2 * W + W + q] = aU;
+    }
+}
+
+// the carry gradient of the gating mix on its own: out = G * (1 - T), the arithmetic of hw_grad's `c`
+__global__ __launch_bounds__(TPB) void gate_carry_kernel(int64_t n, int F4, const float* __restrict__ G, int64_t ldg,
+                                                         const float* __restrict__ T, int64_t ldt, float* __restrict__ out, int64_t ldo) {
+#pragma clang fp contract(off)
+    const int64_t total = n * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t row = e / F4;
+        const int c0 = (int)(e - row * F4) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(G + row * ldg + c0), t = *reinterpret_cast<const float4*>(T + row * ldt + c0);
+        *reinterpret_cast<float4*>(out + row * ldo + c0) =
+            make_float4(g.x * (1.0f - t.x), g.y * (1.0f - t.y), g.z * (1.0f - t.z), g.w * (1.0f - t.w));
     }
 }
 
@@ -601,7 +615,8 @@ static int highway_bwd_impl(bool s16, int64_t n, int32_t F, const float* G, cons
         if (dbU) { const int rc = zero_fill_async(dbU, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream); if (rc) return rc; }
         return 0;
     }
-    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dU, dHcarry);
+    CHECK_VEC("highway_bwd_f32", ld, G, T, Hc, H, dU);
+    GEOGCN_REQUIRE(aligned16(dHcarry), GEOGCN_E_ALIGN, "highway_bwd_f32: misaligned dHcarry");          // (NULL: not stored)
     GEOGCN_REQUIRE(dS && (uintptr_t)dS % 16 == 0, GEOGCN_E_NULL, "highway_bwd_f32: dS is null or not 16-byte aligned");
     GEOGCN_REQUIRE(ld_dS % (s16 ? 8 : 4) == 0 && ld_dS >= ld, GEOGCN_E_ALIGN,
                    "highway_bwd_f32: ld_dS=%lld must be a multiple of %d, >= ld", (long long)ld_dS, s16 ? 8 : 4);
@@ -788,6 +803,21 @@ int geogcn_unpack_panels_f32(int64_t n_rows, int64_t R, int32_t F, const float* 
     hipLaunchKernelGGL(unpack_panels_kernel, dim3(stream_grid(n_rows * F4)), dim3(TPB), 0, (hipStream_t)stream, n_rows, R, F, F4,
                        (const float4*)in, W, wp / 4, Y, ldy);
     GEOGCN_LAUNCH_CHECK("unpack_panels_kernel");
+    return 0;
+}
+
+int geogcn_gate_carry_f32(int64_t n, int32_t F, const float* G, int64_t ldg, const float* T, int64_t ldt, float* out,
+                          int64_t ldo, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "gate_carry_f32: negative size");
+    if (n == 0 || F == 0) return 0;
+    GEOGCN_REQUIRE(G && T && out, GEOGCN_E_NULL, "gate_carry_f32: null pointer");
+    const int64_t f4 = ((int64_t)F + 3) / 4 * 4;
+    GEOGCN_REQUIRE(aligned16(G) && aligned16(T) && aligned16(out) && ldg % 4 == 0 && ldt % 4 == 0 && ldo % 4 == 0 && ldg >= f4 &&
+                       ldt >= f4 && ldo >= f4,
+                   GEOGCN_E_ALIGN, "gate_carry_f32: needs 16-byte aligned operands and pitches that are multiples of 4, >= roundup4(F)");
+    hipLaunchKernelGGL(gate_carry_kernel, dim3(stream_grid(n * (f4 / 4))), dim3(TPB), 0, (hipStream_t)stream, n, (int)(f4 / 4), G, ldg,
+                       T, ldt, out, ldo);
+    GEOGCN_LAUNCH_CHECK("gate_carry_kernel");
     return 0;
 }
 

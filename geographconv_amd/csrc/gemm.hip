@@ -587,9 +587,20 @@ struct RowsArgs {
     int wct[2];                         // column tiles a wave takes per pass: 5, or 4 where 4 x passes x 4 tiles cover the segment (N = 256, 512)
     float* C[2]; int64_t ldc[2]; const float* bias[2]; int64_t N[2]; int act_on[2];
     int accumulate;
+    // C += G * (1 - T), each operation rounded on its own: the carry gradient of the highway block formed here instead of being
+    // written by highway_bwd and read back (NULL: none)
+    const float* gateG; int64_t ldg; const float* gateT; int64_t ldt;
 };
 
-template <int KP, int ACT>
+// x + g * (1 - t) with every operation rounded on its own (no fused multiply-add): the value highway_bwd's hw_grad stores as the
+// carry, added the way the accumulating epilogue adds it
+__device__ __forceinline__ float add_gate_carry(float x, float g, float t) {
+#pragma clang fp contract(off)
+    const float c = g * (1.0f - t);
+    return x + c;
+}
+
+template <int KP, int ACT, bool GATE = false>
 __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
     constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
     constexpr int PITCH = KP + 4;               // floats per LDS row: an odd number of float4s -> conflict-free ds_read_b128
@@ -710,20 +721,38 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bcol[j][r] = (bias && col0 + r < Nseg) ? bias[col0 + r] : 0.f;
                 }
+                // what the epilogue reads besides the accumulators -- the old C (accumulate) or G and T (gate carry) -- is requested
+                // one row tile AHEAD of its use, column tile by column tile as the registers of the current one fall free (the
+                // compiler cannot move a load above the stores before it: C may alias anything)
+                // (locals, not fields of the by-value argument struct: a lambda that touches `a` makes the compiler keep a copy of it in scratch)
+                const float* const gG = GATE ? a.gateG : nullptr; const float* const gT = GATE ? a.gateT : nullptr;      // (GATE: its own instance -- the second operand array costs 20 registers)
+                const int64_t ldg = a.ldg, ldt = a.ldt, Mrows = a.M;
+                const bool accum = a.accumulate != 0;
+                const bool extra = accum || gG != nullptr;
+                f32x4 ea[WCT], eb[WCT];
+                // (buffer loads: one descriptor per operand for the row tile, a 32-bit offset per request -- 64-bit addresses for
+                //  every (row tile, column tile) pair had the kernel at 256 registers with spills; rows past M read as zero)
+                const int64_t lda_e = gG ? ldg : ldc;
+                const int64_t rows_here = std::min<int64_t>(BM, Mrows - m0);
+                const __amdgpu_buffer_rsrc_t ersA = tile_rsrc((gG ? gG + m0 * ldg : Cout + m0 * ldc), extra ? rows_here * lda_e * 4 : 0);
+                const __amdgpu_buffer_rsrc_t ersB = tile_rsrc(gG ? gT + m0 * ldt : Cout, gG ? rows_here * ldt * 4 : 0);
+                const uint32_t lda_e4 = (uint32_t)lda_e * 4u, ldt4 = (uint32_t)ldt * 4u;
+                auto eload = [&](int i, int j) __attribute__((always_inline)) {
+                    const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                    const uint32_t r = (uint32_t)(i * 16 + li), c = (uint32_t)col0 * 4u;
+                    const bool ok = col0 < Nseg;
+                    ea[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ersA, (int)(ok ? r * lda_e4 + c : kOobOffset), 0, 0));
+                    if constexpr (GATE) eb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ersB, (int)(ok ? r * ldt4 + c : kOobOffset), 0, 0));
+                };
+                if (extra) {
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) eload(0, j);
+                }
 #pragma unroll
                 for (int i = 0; i < MR; ++i) {
                     const int64_t row = m0 + i * 16 + li;
                     float* crow = Cout + row * ldc;
-                    const bool row_ok = row < a.M;
-                    float4 oldv[WCT];
-                    if (a.accumulate) {
-#pragma unroll
-                        for (int j = 0; j < WCT; ++j) {
-                            const int64_t col0 = ncol0 + j * 16 + lg * 4;
-                            oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (row_ok && col0 < Nseg) oldv[j] = *reinterpret_cast<const float4*>(crow + col0);
-                        }
-                    }
+                    const bool row_ok = row < Mrows;
 #pragma unroll
                     for (int j = 0; j < WCT; ++j) {
                         const int64_t col0 = ncol0 + j * 16 + lg * 4;
@@ -733,11 +762,17 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
                             x[r] = acc[i][j][r] + bcol[j][r];
                             if (ACT == GEOGCN_ACT_NONE || act_on) x[r] = apply_act<ACT>(x[r]);
                         }
-                        if (a.accumulate) { x[0] += oldv[j].x; x[1] += oldv[j].y; x[2] += oldv[j].z; x[3] += oldv[j].w; }
+                        if (accum) { x[0] += ea[j][0]; x[1] += ea[j][1]; x[2] += ea[j][2]; x[3] += ea[j][3]; }
+                        if constexpr (GATE) {
+                            x[0] = add_gate_carry(x[0], ea[j][0], eb[j][0]); x[1] = add_gate_carry(x[1], ea[j][1], eb[j][1]);
+                            x[2] = add_gate_carry(x[2], ea[j][2], eb[j][2]); x[3] = add_gate_carry(x[3], ea[j][3], eb[j][3]);
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (col0 + r >= Nseg) x[r] = 0.f;
                         if (row_ok && col0 < Nseg) *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
+                        // this column tile's operands of the NEXT row tile: on their way while the remaining tiles are finished
+                        if (extra && i + 1 < MR) eload(i + 1, j);
                     }
                 }
             }
@@ -811,6 +846,7 @@ struct GemmCall {
     int accumulate;
     int panel_w = 0;
     int64_t panel_R = 0;
+    const float* gateG = nullptr; int64_t ldg = 0; const float* gateT = nullptr; int64_t ldt = 0;      // whole-rows kernel only
     int64_t maxN() const { return n_nseg == 2 ? std::max(N[0], N[1]) : N[0]; }
 };
 
@@ -1052,7 +1088,16 @@ int launch_rows(const RowsArgs& a, int act, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);                                      \
         GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");                                                                 \
     } while (0)
-    if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
+    if (a.gateG) {
+        auto kern = gemm_rows_kernel<KP, GEOGCN_ACT_NONE, true>;          // (the gated form has no activation: geogcn_gemm_kcat_gated_f32)
+        static bool attr_done = false;
+        if (!attr_done) {
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);
+        GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");
+    } else if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
     else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_R(GEOGCN_ACT_SIGMOID);
     else GEOGCN_R(GEOGCN_ACT_NONE);
 #undef GEOGCN_R
@@ -1066,6 +1111,7 @@ int run_rows(int kp, bool transB, const GemmCall& c, void* ws, hipStream_t st) {
     a.n_kseg = c.n_kseg;
     a.n_nseg = c.n_nseg;
     a.accumulate = c.accumulate;
+    a.gateG = c.gateG; a.ldg = c.ldg; a.gateT = c.gateT; a.ldt = c.ldt;
     float* w = (float*)ws;
     const int nks = kp / 16;
     for (int q = 0; q < 2; ++q) {
@@ -1303,6 +1349,39 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
     c.C[0] = C; c.ldc[0] = ldc;
     c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate;
     return run_call(false, transB != 0, c, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                               const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                               float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, void* ws,
+                               size_t ws_bytes, void* stream) {
+    const char* fn = "gemm_kcat_gated_f32";
+    GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    if (M == 0 || N == 0) return 0;
+    GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C && G && T, GEOGCN_E_NULL, "%s: null pointer", fn);
+    const int64_t b0_cols = transB ? K0 : N, b1_cols = transB ? K1 : N, n4 = (N + 3) & ~(int64_t)3;
+    GEOGCN_REQUIRE(lda0 >= K0 && lda1 >= K1 && ldb0 >= b0_cols && ldb1 >= b1_cols && ldc >= N && ldg >= n4 && ldt >= n4, GEOGCN_E_SIZE,
+                   "%s: leading dimension too small", fn);
+    GEOGCN_REQUIRE(ld_ok(A0, lda0) && ld_ok(A1, lda1) && ld_ok(B0, ldb0) && ld_ok(B1, ldb1) && ld_ok(C, ldc) && ld_ok(G, ldg) &&
+                       ld_ok(T, ldt),
+                   GEOGCN_E_ALIGN, "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
+    GEOGCN_REQUIRE(C != G && C != T, GEOGCN_E_ARG, "%s: C must not alias G or T", fn);
+    GemmCall c{};
+    c.M = M; c.n_nseg = 1; c.n_kseg = 2;
+    c.A[0] = A0; c.lda[0] = lda0; c.A[1] = A1; c.lda[1] = lda1;
+    c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
+    c.C[0] = C; c.ldc[0] = ldc;
+    c.N[0] = N; c.K[0] = K0; c.K[1] = K1;
+    hipStream_t st = (hipStream_t)stream;
+    if (const int kp = rows_kp(c, false, transB != 0); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp)) {
+        c.accumulate = 0;
+        c.gateG = G; c.ldg = ldg; c.gateT = T; c.ldt = ldt;
+        return run_rows(kp, transB != 0, c, ws, st);
+    }
+    // any other shape: the carry written first, the two products accumulated onto it (the same values in the same order)
+    if (const int rc = geogcn_gate_carry_f32(M, (int32_t)N, G, ldg, T, ldt, C, ldc, stream)) return rc;
+    c.accumulate = 1;
+    return run_call(false, transB != 0, c, ws, ws_bytes, st);
 }
 
 }  // extern "C"

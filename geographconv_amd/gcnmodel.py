@@ -287,8 +287,16 @@ class MultiplicativeGatingLayer(L.MergeLayer):
                and kwargs.get('A') is not None and isinstance(h1_l, ConvolutionDenseLayer2)
                and (fuse_b or h1_l.b is None)       # (an un-fused bias gradient would take the column sums of a bf16 matrix)
                and K.highway_bwd_bf16_ok(grad, fuse_b))
+        # the carry gradient dH * (1 - T) is not stored when the gate's backward will form it in the epilogue of
+        # dH_in = dZ.Wh^T + dU.Wt^T (the fused launch of the reverse sweep, nn/layers.py _backward_post): a GateCarry goes down instead
+        lazy = (tuning.FUSE_GATE_CARRY and not s16 and into[2] is None and kwargs.get('comm') is None
+                and tape.get(gate_l, {}).get('fused_with') is h1_l and isinstance(grad, K.DMat)
+                and K.kcat_gated_native(grad.n, grad.F))
         dS, dU, dH = K.highway_bwd(grad, t, h1, h2, dbS=h1_l.b.grad if fuse_b else None,
-                                   dbU=gate_l.b.grad if fuse_b else None, **({'dS_bf16': True} if s16 else {}))
+                                   dbU=gate_l.b.grad if fuse_b else None, **({'dS_bf16': True} if s16 else {}),
+                                   **({'carry': False} if lazy else {}))
+        if lazy:
+            dH = K.GateCarry(grad, t)
         if into[2] is not None:
             K.add_inplace(dH, into[2])
             dH = into[2]

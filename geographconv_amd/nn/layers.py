@@ -479,8 +479,11 @@ class DenseLayer(Layer):
                 dZ = K.spmm(A_bwd, dS if as_is else K.cast_bf16(dS))
         return self._backward_post(x, dZ, into, need_input_grad, kwargs, tape)
 
+    takes_gate_carry = True        # (backward sweep: `into[0]` may be an un-formed carry gradient, ops.GateCarry)
+
     def _backward_post(self, x, dZ, into, need_input_grad, kwargs, tape=None):
         K = backend.active()
+        lazy = into[0] if (hasattr(into[0], 'dense') and hasattr(into[0], 'G')) else None
         if isinstance(x, K.DMat):
             prec = kwargs.get('gemm_precision')
             gate = getattr(self, 'highway_gate', None)
@@ -498,8 +501,12 @@ class DenseLayer(Layer):
                 if not need_input_grad:
                     return [None]
                 # dH = dZ.Wh^T + dU.Wt^T [+ the carry gradient]: one accumulator, one pass over dH
+                if lazy is not None:          # ... the carry formed in the epilogue from the block's output gradient and its gate
+                    return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, transB=True, gate_carry=lazy)]
                 return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
                                     accumulate=into[0] is not None)]
+            if lazy is not None:
+                into = [lazy.dense()] + list(into[1:])
             K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ
             after_dw = kwargs.get('after_dw')
             if after_dw is not None:
@@ -735,10 +742,16 @@ def backward(layer, grad, tape, **kwargs):
     grads = {layer: grad}
     # which layers lie on a path from a parameterised/needed layer: all of them need grads except
     # pure inputs
+    def dense(g):
+        # a highway block's carry gradient that nobody formed in an epilogue (ops.GateCarry): form it now
+        return g.dense() if hasattr(g, 'dense') and hasattr(g, 'G') else g
+
     def run(l, **extra):
-        g = grads.pop(l)
+        g = dense(grads.pop(l))
         ins = l.input_layers if hasattr(l, 'input_layers') else [l.input_layer]
         into = [grads.get(i) if not isinstance(i, InputLayer) else None for i in ins]
+        if not getattr(l, 'takes_gate_carry', False):
+            into = [dense(b) for b in into]
         need = [not isinstance(i, InputLayer) for i in ins]
         outs = l.backward(g, tape, into, need_input_grad=any(need), **dict(kwargs, **extra))
         for i, o in zip(ins, outs):

@@ -448,13 +448,36 @@ def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None,
     return out0, out1
 
 
+class GateCarry:
+    """The carry gradient of a highway block, G * (1 - T), NOT yet formed: the gating layer hands it down like a gradient matrix and
+    gemm_kcat(gate_carry=...) forms it in its epilogue (geogcn_gemm_kcat_gated_f32) -- highway_bwd then does not store it and
+    nothing reads it back.  Whoever cannot take it that way calls `dense()`."""
+    __slots__ = ('G', 'T')
+
+    def __init__(self, G: DMat, T: DMat):
+        self.G, self.T = G, T
+
+    def dense(self):
+        out = self.G.like()
+        check(_ffi.lib().geogcn_gate_carry_f32(self.G.n, self.G.F, _p(self.G.t), self.G.ld, _p(self.T.t), self.T.ld, _p(out.t),
+                                               out.ld, _stream()), 'gate_carry_f32')
+        return out
+
+
+def kcat_gated_native(n, F):
+    """Does dH = dZ . Wh^T + dU . Wt^T + G * (1 - T) run with the carry in the epilogue at this size (whole-rows kernel)?"""
+    return _ffi.lib().geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F)) > 0
+
+
 @_timed('gemm_kcat')
-def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False):
+def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, gate_carry: GateCarry = None):
     """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
-    dH = dZ . Wh^T + dU . Wt^T of the highway block."""
+    dH = dZ . Wh^T + dU . Wt^T of the highway block.  `gate_carry`: ... + G * (1 - T) formed in the epilogue (then no accumulate)."""
     N = B0.n if transB else B0.F
     if (B1.n if transB else B1.F) != N or A0.n != A1.n or (B0.F if transB else B0.n) != A0.F or (B1.F if transB else B1.n) != A1.F:
         raise ValueError("gemm_kcat: shapes do not match")
+    if gate_carry is not None and accumulate:
+        raise ValueError("gemm_kcat: a gate carry and accumulate exclude each other")
     if out is None:
         if accumulate:
             raise ValueError("gemm_kcat: accumulate needs an existing output")
@@ -464,6 +487,14 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
     if ws is None:
         ws = _gemm_ws[A0.device] = Workspace(A0.device)
     w = ws.get(lib.geogcn_gemm_kcat_workspace_bytes(int(transB), A0.n, N, A0.F, A1.F))
+    if gate_carry is not None:
+        g, t = gate_carry.G, gate_carry.T
+        if g.n != A0.n or g.F != N or t.n != A0.n or t.F != N:
+            raise ValueError("gemm_kcat: the gate carry's operands do not have the output's shape")
+        check(lib.geogcn_gemm_kcat_gated_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
+                                             _p(B1.t), B1.ld, _p(out.t), out.ld, _p(g.t), g.ld, _p(t.t), t.ld, _p(w), w.numel(),
+                                             _stream()), 'gemm_kcat_gated_f32')
+        return out
     check(lib.geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
                                    _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _p(w), w.numel(), _stream()), 'gemm_kcat_f32')
     return out
@@ -483,19 +514,29 @@ def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
     return out
 
 
+class _NoMatType:
+    t = None
+
+
+_NoMat = _NoMatType()
+
+
 def highway_bwd_bf16_ok(G: DMat, with_bias: bool):
     """Can highway_bwd store dS as bfloat16 for this gradient?  (fused column sums: plain pitch, F <= 1024)"""
     return G.F <= 1024 and (not with_bias or G.ld == pad4(G.F))
 
 
 def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat = None, dHcarry: DMat = None,
-                dbS: torch.Tensor = None, dbU: torch.Tensor = None, dS_bf16=False):
+                dbS: torch.Tensor = None, dbU: torch.Tensor = None, dS_bf16=False, carry=True):
     """-> (dS, dU, dHcarry); with dbS / dbU given, also the two bias gradients (column sums) in the same pass.
     `dS_bf16`: dS comes back as an HMat (bf16, the bits cast_bf16 would produce) -- the bf16 configuration's A^T . dS gathers
     it directly, the fp32 dS and the cast pass are never written."""
     lib = _ffi.lib()
     dU = G.like() if dU is None else dU
-    dHcarry = G.like() if dHcarry is None else dHcarry
+    if carry:
+        dHcarry = G.like() if dHcarry is None else dHcarry
+    else:
+        dHcarry = _NoMat             # (`carry=False`: dHcarry is not stored -- a GateCarry hands it to gemm_kcat; None comes back)
     w = _ws_for(G.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(G.n, G.F),
                                   lib.geogcn_colsum_workspace_bytes(G.n, G.F)) if dbS is not None else 0)
     if dS_bf16:
@@ -503,11 +544,11 @@ def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat =
         check(lib.geogcn_highway_bwd_bf16s_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
                                                _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()),
               'highway_bwd_bf16s_f32')
-        return dS, dU, dHcarry
+        return dS, dU, (dHcarry if carry else None)
     dS = DMat.empty(G.n, G.F, G.device, ld=gather_ld(G.F)) if dS is None else dS      # dS feeds the A^T SpMM
     check(lib.geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
                                      _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
-    return dS, dU, dHcarry
+    return dS, dU, (dHcarry if carry else None)
 
 
 def act_bwd(G: DMat, Y: DMat, act, out: DMat = None, keep_mask=None, scale=1.0):

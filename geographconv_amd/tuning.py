@@ -37,6 +37,10 @@ FUSE_GEMMS = True
 #  of round 3, same box, two alternations: 6x600 bf16 step 69.95 -> 69.56 ms, 3x300 bf16 18.06 -> 17.98: now ahead, so 'all'.)
 FUSE_HIGHWAY = 'all'
 
+# the highway block's carry gradient G * (1 - T) formed in the epilogue of dH = dZ.Wh^T + dU.Wt^T (geogcn_gemm_kcat_gated_f32) instead
+# of written by highway_bwd and read back: 0.53 GB less written per 300-wide block at the TwitterUS size; same bits
+FUSE_GATE_CARRY = True
+
 # bf16 configuration, one GPU: highway_bwd stores the branch gradient dS as bf16 (what A^T . dS gathers) instead of fp32 + a cast
 # pass (-0.37 ms per 600-wide block; same bits)
 FUSE_BF16_DS = True

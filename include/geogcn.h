@@ -245,6 +245,17 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                          float* C, int64_t ldc, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with the block's CARRY gradient formed in the epilogue instead of being read from C:
+ *   C[M x N] = A0 . op(B0) + A1 . op(B1) + G * (1 - T)          (G = gradient at the block's output, T = its gate; both M x N,
+ * every operation rounded on its own: the value geogcn_highway_bwd_f32 would have stored as dHcarry) -- highway_bwd then
+ * takes dHcarry = NULL and neither writes nor re-reads 4 M N bytes.  Bit-identical to geogcn_highway_bwd_f32 (with dHcarry) followed
+ * by geogcn_gemm_kcat_f32(accumulate = 1).  Shapes the whole-rows kernel does not take (or ws too small) run as
+ * geogcn_gate_carry_f32 into C + the accumulating call.  C must not alias G or T.                                            */
+int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                               const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                               float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */
 int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const float* bias,
@@ -253,13 +264,17 @@ int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const
 int geogcn_highway_fwd_f32(int64_t n, int32_t F, const float* T, const float* Hc, const float* H,
                            int64_t ld, float* Hout, void* stream);
 /* its gradient + tanh'/sigmoid' of the two branches (what autodiff derives for :266,:136,:286):
- *   dS = G*T*(1-Hc^2)   dU = G*(Hc-H)*T*(1-T)   dHcarry = G*(1-T)                               */
+ *   dS = G*T*(1-Hc^2)   dU = G*(Hc-H)*T*(1-T)   dHcarry = G*(1-T)
+ * dHcarry may be NULL (not stored: geogcn_gemm_kcat_gated_f32 forms it where it is consumed).   */
 int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T, const float* Hc,
                            const float* H, int64_t ld, float* dS, int64_t ld_dS /* dS may use the line-aligned
                            pitch of an SpMM operand */, float* dU, float* dHcarry,
                            float* dbS /* nullable: column sums of dS = grad of the conv bias */,
                            float* dbU /* nullable: column sums of dU = grad of the gate bias */,
                            void* ws, size_t ws_bytes, void* stream);
+/* out = G * (1 - T): the carry gradient alone (the arithmetic of dHcarry above)                 */
+int geogcn_gate_carry_f32(int64_t n, int32_t F, const float* G, int64_t ldg, const float* T, int64_t ldt, float* out,
+                          int64_t ldo, void* stream);
 /* the same with dS stored as bfloat16 (round to nearest even; ld_dS16 in elements, a multiple of 8, the whole pitch written,
  * pads as zeros): in the bf16 configuration dS is only ever gathered by A^T . dS (geogcn_spmm_csr_bf16b), so the fp32 copy
  * and the geogcn_cast_bf16_f32 pass over it are not needed.  dbS is still the column sum of the fp32 values.  F <= 1024.     */

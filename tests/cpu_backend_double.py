@@ -113,7 +113,29 @@ def gemm_dual(A, B0, B1, out0=None, out1=None, transA=False, bias0=None, act0=AC
             gemm(A, B1, out=out1, transA=transA, bias=bias1, act=act1))
 
 
-def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False):
+class GateCarry:
+    def __init__(self, G, T):
+        self.G, self.T = G, T
+
+    def dense(self):
+        out = DMat(self.G.n, self.G.F, self.G.device)
+        _v(out)[...] = _v(self.G) * (1 - _v(self.T))
+        return out
+
+
+def kcat_gated_native(n, F):
+    return True              # (the double takes the gated form at every size: the host logic is what it exercises)
+
+
+def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, gate_carry=None):
+    if gate_carry is not None:
+        assert not accumulate
+        c = gate_carry.dense()
+        if out is None:
+            out = c
+        else:
+            out.t.copy_(c.t)
+        accumulate = True
     out = gemm(A0, B0, out=out, transB=transB, accumulate=accumulate)
     return gemm(A1, B1, out=out, transB=transB, accumulate=True)
 
@@ -142,13 +164,17 @@ def highway_fwd(T, Hc, H, out=None):
     return out
 
 
-def highway_bwd(G, T, Hc, H, dS=None, dU=None, dHcarry=None, dbS=None, dbU=None):
+def highway_bwd(G, T, Hc, H, dS=None, dU=None, dHcarry=None, dbS=None, dbU=None, carry=True):
     mk = lambda: DMat(G.n, G.F, G.device)
-    dS, dU, dHcarry = dS or mk(), dU or mk(), dHcarry or mk()
+    dS, dU = dS or mk(), dU or mk()
     g, t, hc, h = _v(G), _v(T), _v(Hc), _v(H)
     _v(dS)[...] = g * t * (1 - hc * hc)
     _v(dU)[...] = g * (hc - h) * t * (1 - t)
-    _v(dHcarry)[...] = g * (1 - t)
+    if carry:
+        dHcarry = dHcarry or mk()
+        _v(dHcarry)[...] = g * (1 - t)
+    else:
+        dHcarry = None
     if dbS is not None:
         dbS.numpy()[:G.F] = _v(dS).sum(axis=0)
         dbU.numpy()[:G.F] = _v(dU).sum(axis=0)

@@ -424,6 +424,72 @@ def test_dropout_in_the_first_layers_epilogue_equals_the_separate_kernels(cmu, m
     assert all(np.array_equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
 
 
+def _count_gate_carries(monkeypatch):
+    from geographconv_amd import ops
+    made, formed = [], []
+    init, dense = ops.GateCarry.__init__, ops.GateCarry.dense
+    monkeypatch.setattr(ops.GateCarry, '__init__', lambda self, G, T: (made.append(1), init(self, G, T))[1])
+    monkeypatch.setattr(ops.GateCarry, 'dense', lambda self: (formed.append(1), dense(self))[1])
+    return made, formed
+
+
+def test_carry_gradient_in_the_epilogue_of_the_gates_backward_product(monkeypatch):
+    """tuning.FUSE_GATE_CARRY: the highway block's carry gradient dH * (1 - T) is formed in the epilogue of
+    dH_in = dZ.Wh^T + dU.Wt^T (whole-rows kernel: from 32,768 nodes on) instead of being written by highway_bwd and read back.
+    Three training steps of a 40,000-node graph (two highway blocks) are bitwise the run with the stored carry, eager and
+    captured; one GateCarry per block and step goes down the reverse sweep and none has to be formed on its own."""
+    from geographconv_amd import tuning
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    N, C = 40000, 12
+    A, X, Y = synth.small_graph(N, 6.0, 1500, 10, C, seed=21)
+    hid = [300, 300, 300]
+    params = O.random_params(X.shape[1], hid, C, True, seed=4)
+    tr, dev_idx = np.arange(0, 30000, dtype=np.int32), np.arange(30000, 36000, dtype=np.int32)
+    made, formed = _count_gate_carries(monkeypatch)
+    runs = {}
+    for fused in (True, False):
+        for graph in (False, True):
+            monkeypatch.setattr(tuning, 'FUSE_GATE_CARRY', fused)
+            del made[:], formed[:]
+            clf = GraphConv(X.shape[1], C, hid, 0.0, 0.5, highway=True, hip_graph=graph)
+            clf.build_model(A, seed=77)
+            L.set_all_param_values(clf.l_out, params)
+            hist = []
+            for step in range(3):
+                out = clf.f_train(X, Y[tr], Y[dev_idx], A, tr, dev_idx)
+                hist.append([float(v) for v in out[:4]])
+            runs[(fused, graph)] = (hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out))
+            if fused:
+                assert len(made) >= 2 and not formed, (len(made), len(formed))         # (captured: made while capturing)
+            else:
+                assert not made
+    for graph in (False, True):
+        (hist, P, prm), ref = runs[(True, graph)], runs[(False, graph)]
+        assert hist == ref[0] and np.array_equal(P, ref[1]), graph
+        assert all(np.array_equal(a, b) for a, b in zip(prm, ref[2])), graph
+
+
+def test_carry_gradient_handed_down_at_sizes_the_whole_rows_kernel_does_not_take(cmu, monkeypatch):
+    """The same switch forced on at the CMU size (9,475 nodes: geogcn_gemm_kcat_gated_f32 writes the carry with
+    geogcn_gate_carry_f32 and accumulates onto it): losses, probabilities and gradients bitwise those of the stored carry."""
+    from geographconv_amd import ops, tuning
+    c = cmu
+    made, formed = _count_gate_carries(monkeypatch)
+    outs = {}
+    for mode in ('stored', 'handed'):
+        monkeypatch.setattr(tuning, 'FUSE_GATE_CARRY', mode != 'stored')
+        monkeypatch.setattr(ops, 'kcat_gated_native', (lambda n, F: True) if mode != 'stored' else ops.kcat_gated_native)
+        del made[:], formed[:]
+        clf = _clf(c)
+        clf.inject_dropout_mask(c['mask'])
+        out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+        outs[mode] = ([float(v) for v in out[:4]], np.asarray(out[4]).copy(), clf.get_grads())
+        assert (len(made) > 0, len(formed)) == {'stored': (False, 0), 'handed': (True, 0)}[mode], mode
+    a, b = outs['stored'], outs['handed']
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+
+
 def test_bf16_configuration_branch_gradient_stored_as_bf16(cmu, monkeypatch):
     """tuning.FUSE_BF16_DS: in the bf16 configuration highway_bwd writes the convolution branch's gradient as bf16 (what
     A^T . dS gathers) instead of fp32 + a cast pass: three training steps are bitwise the run with the separate cast."""

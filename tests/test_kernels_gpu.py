@@ -571,6 +571,44 @@ def test_single_products_on_the_whole_rows_kernel_bitwise(dev, M, N, K, transB):
     assert torch.equal(wide.t[:, :N], got.t[:, :N]) and torch.all(wide.t[:, ops.pad4(N):] == 7.0)
 
 
+@pytest.mark.parametrize("M,F,pitched", [(40000, 300, False), (33001, 256, True), (50001, 289, True), (5000, 300, False), (777, 129, True)])
+def test_gemm_kcat_with_the_carry_gradient_in_its_epilogue_bitwise(dev, M, F, pitched):
+    """geogcn_gemm_kcat_gated_f32: dH = dZ . Wh^T + dU . Wt^T + G * (1 - T) with the highway block's carry formed in the epilogue
+    of the whole-rows kernel (large M) or by geogcn_gate_carry_f32 ahead of the accumulating call (any other shape) is BIT-identical
+    to highway_bwd's stored carry + the accumulating call; highway_bwd without its carry output leaves dS, dU and the two bias
+    gradients unchanged."""
+    from geographconv_amd import ops
+    ld = ops.gather_ld(F) if pitched else None
+    G = ops.DMat.empty(M, F, dev, ld=ld)
+    G.t.zero_()
+    G.t[:, :F].copy_(torch.from_numpy(_rand((M, F), 1)))
+    T = ops.DMat.from_numpy(1.0 / (1.0 + np.exp(-3.0 * _rand((M, F), 2))), dev)
+    Hc, H = ops.DMat.from_numpy(np.tanh(_rand((M, F), 3)), dev), ops.DMat.from_numpy(_rand((M, F), 4), dev)
+    if G.ld != T.ld:                 # (highway_bwd takes ONE pitch for its four inputs)
+        Gp = ops.DMat.from_numpy(G.numpy(), dev)
+    else:
+        Gp = G
+    b = [torch.zeros(ops.pad4(F), device=dev) for _ in range(4)]
+    dS, dU, carry = ops.highway_bwd(Gp, T, Hc, H, dbS=b[0], dbU=b[1])
+    dS2, dU2, none = ops.highway_bwd(Gp, T, Hc, H, dbS=b[2], dbU=b[3], carry=False)
+    assert none is None and torch.equal(dS.t[:, :F], dS2.t[:, :F]) and torch.equal(dU.t[:, :F], dU2.t[:, :F])     # (dS has the gather pitch)
+    assert torch.equal(b[0], b[2]) and torch.equal(b[1], b[3])
+    assert torch.equal(ops.GateCarry(G, T).dense().t[:, :F], carry.t[:, :F])
+    dZ = ops.DMat.from_numpy(_rand((M, F), 5), dev)
+    for transB in (True, False):
+        Wh, Wt = ops.DMat.from_numpy(_rand((F, F), 6, 0.1), dev), ops.DMat.from_numpy(_rand((F, F), 7, 0.1), dev)
+        want = ops.DMat.from_numpy(carry.numpy(), dev)
+        ops.gemm_kcat(dZ, Wh, dU, Wt, out=want, transB=transB, accumulate=True)
+        got = ops.gemm_kcat(dZ, Wh, dU, Wt, transB=transB, gate_carry=ops.GateCarry(G, T))
+        assert torch.equal(got.t, want.t), transB
+        wide = ops.DMat.empty(M, F, dev, ld=ops.gather_ld(F) + 32)
+        wide.t.fill_(7.0)
+        ops.gemm_kcat(dZ, Wh, dU, Wt, out=wide, transB=transB, gate_carry=ops.GateCarry(G, T))
+        assert torch.equal(wide.t[:, :F], want.t[:, :F]) and torch.all(wide.t[:, ops.gather_ld(F):] == 7.0)
+    with pytest.raises(ValueError):
+        ops.gemm_kcat(dZ, Wh, dU, Wt, out=want, transB=True, accumulate=True, gate_carry=ops.GateCarry(G, T))
+
+
 @pytest.mark.parametrize("M,N,K0,K1", [(1000, 300, 300, 300), (4100, 600, 600, 600), (777, 300, 129, 300), (333, 16, 40, 64),
                                       (70000, 300, 300, 300)])
 def test_gemm_kcat_two_products_one_accumulator(dev, M, N, K0, K1):
