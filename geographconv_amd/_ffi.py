@@ -64,6 +64,8 @@ SIGNATURES = {
                                      c_ptr, c_i64, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_kcat_gated_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                            c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_sz, c_ptr]),
+    'geogcn_gemm_gated_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
+                                      c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gate_carry_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),

@@ -9,6 +9,14 @@
 
 namespace geogcn {
 
+// x + g * (1 - t) with every operation rounded on its own (no fused multiply-add): the value highway_bwd's hw_grad stores as the
+// carry, added the way an accumulating epilogue adds it (gemm.hip / gemm_bf16.hip whole-rows kernels)
+__device__ __forceinline__ float add_gate_carry(float x, float g, float t) {
+#pragma clang fp contract(off)
+    const float c = g * (1.0f - t);
+    return x + c;
+}
+
 constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kNumXCD = 8;
@@ -111,8 +119,12 @@ int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64
                           float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
                           hipStream_t st);
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K);
+// `gate` (nullable): C += G * (1 - T) -- the highway block's carry gradient formed in the epilogue (fp32 C, no bias / activation /
+// accumulate); shapes the whole-rows kernel does not take write it with geogcn_gate_carry_f32 first and accumulate onto it
+struct GateOps { const float* G; int64_t ldg; const float* T; int64_t ldt; };
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
-                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w = 0, int64_t panel_R = 0);
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w = 0, int64_t panel_R = 0,
+                       const GateOps* gate = nullptr);
 
 }  // namespace geogcn

@@ -592,14 +592,6 @@ struct RowsArgs {
     const float* gateG; int64_t ldg; const float* gateT; int64_t ldt;
 };
 
-// x + g * (1 - t) with every operation rounded on its own (no fused multiply-add): the value highway_bwd's hw_grad stores as the
-// carry, added the way the accumulating epilogue adds it
-__device__ __forceinline__ float add_gate_carry(float x, float g, float t) {
-#pragma clang fp contract(off)
-    const float c = g * (1.0f - t);
-    return x + c;
-}
-
 template <int KP, int ACT, bool GATE = false>
 __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
     constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
@@ -1349,6 +1341,38 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
     c.C[0] = C; c.ldc[0] = ldc;
     c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate;
     return run_call(false, transB != 0, c, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                          int64_t ldb, float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
+                          int32_t precision, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "gemm_gated_f32";
+    GEOGCN_REQUIRE(M >= 0 && N >= 0 && K > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    GEOGCN_REQUIRE(precision >= GEOGCN_GEMM_F32 && precision <= GEOGCN_GEMM_BF16, GEOGCN_E_ARG, "%s: unknown precision %d", fn, precision);
+    if (M == 0 || N == 0) return 0;
+    GEOGCN_REQUIRE(A && B && C && G && T, GEOGCN_E_NULL, "%s: null pointer", fn);
+    const int64_t b_cols = transB ? K : N, n4 = (N + 3) & ~(int64_t)3;
+    GEOGCN_REQUIRE(lda >= K && ldb >= b_cols && ldc >= N && ldg >= n4 && ldt >= n4, GEOGCN_E_SIZE, "%s: leading dimension too small", fn);
+    GEOGCN_REQUIRE(ld_ok(A, lda) && ld_ok(B, ldb) && ld_ok(C, ldc) && ld_ok(G, ldg) && ld_ok(T, ldt), GEOGCN_E_ALIGN,
+                   "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
+    GEOGCN_REQUIRE(C != G && C != T, GEOGCN_E_ARG, "%s: C must not alias G or T", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (precision != GEOGCN_GEMM_F32) {
+        const GateOps gate{G, ldg, T, ldt};
+        return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, nullptr, GEOGCN_ACT_NONE, 0, ws, ws_bytes, st,
+                                  0, 0, &gate);
+    }
+    GemmCall c{};
+    c.M = M; c.n_nseg = 1; c.n_kseg = 1;
+    c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = C; c.ldc[0] = ldc;
+    c.N[0] = N; c.K[0] = K; c.act[0] = c.act[1] = GEOGCN_ACT_NONE;
+    if (const int kp = rows_kp(c, false, transB != 0); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp)) {
+        c.gateG = G; c.ldg = ldg; c.gateT = T; c.ldt = ldt;
+        return run_rows(kp, transB != 0, c, ws, st);
+    }
+    if (const int rc = geogcn_gate_carry_f32(M, (int32_t)N, G, ldg, T, ldt, C, ldc, stream)) return rc;
+    c.accumulate = 1;
+    return run_call(false, transB != 0, c, ws, ws_bytes, st);
 }
 
 int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,

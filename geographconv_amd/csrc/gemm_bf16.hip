@@ -84,6 +84,7 @@ struct Bf16Args {
     int64_t n_store;                    // columns written per row (pads beyond N as zeros)
     int panel_w;                        // > 0: C is laid out as feature panels [N / panel_w][panel_R][panel_w] (gemm.hip)
     int64_t panel_R;
+    const float* gateG = nullptr; int64_t ldg = 0; const float* gateT = nullptr; int64_t ldt = 0;      // whole-rows kernel only (common.h GateOps)
 };
 
 template <int BM, int BN, int NS, int NT>
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(TPB) void prep_b_frag_kernel(const float* __restric
 
 constexpr int kRowsBM = 64, kRowsWCT = 5, kRowsDepth = 2;
 
-template <int KP, int ACT>
+template <int KP, int ACT, bool GATE = false>
 __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a, const int passes) {
     constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
     constexpr int PITCH = KP * 2 + 16;          // bytes per LDS row: an odd multiple of 16 -> conflict-free ds_read_b128
@@ -527,6 +528,17 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
                         if (row_ok && col0 < a.N) oldv[j] = *reinterpret_cast<const float4*>((const float*)a.C + row * a.ldc + col0);
                     }
                 }
+                float4 gv[GATE ? WCT : 1], tv[GATE ? WCT : 1];
+                if constexpr (GATE) {        // C += G * (1 - T): the highway block's carry gradient (fp32 C)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) {
+                        const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                        gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row_ok && col0 < a.N) gv[j] = *reinterpret_cast<const float4*>(a.gateG + row * a.ldg + col0);
+                        if (row_ok && col0 < a.N) tv[j] = *reinterpret_cast<const float4*>(a.gateT + row * a.ldt + col0);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < WCT; ++j) {
                     const int64_t col0 = ncol0 + j * 16 + lg * 4;
@@ -534,6 +546,10 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] = apply_act<ACT>(acc[i][j][r] + bcol[j][r]);
                     if (a.accumulate) { x[0] += oldv[j].x; x[1] += oldv[j].y; x[2] += oldv[j].z; x[3] += oldv[j].w; }
+                    if constexpr (GATE) {
+                        x[0] = add_gate_carry(x[0], gv[j].x, tv[j].x); x[1] = add_gate_carry(x[1], gv[j].y, tv[j].y);
+                        x[2] = add_gate_carry(x[2], gv[j].z, tv[j].z); x[3] = add_gate_carry(x[3], gv[j].w, tv[j].w);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (col0 + r >= a.N) x[r] = 0.f;
@@ -582,7 +598,16 @@ int launch_rows(const Bf16Args& a, int act, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);                             \
         GEOGCN_LAUNCH_CHECK("gemm_bf16_rows_kernel");                                                           \
     } while (0)
-    if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
+    if (a.gateG) {
+        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, true>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);
+        GEOGCN_LAUNCH_CHECK("gemm_bf16_rows_kernel");
+    } else if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
     else if (act == GEOGCN_ACT_SIGMOID) GEOGCN_R(GEOGCN_ACT_SIGMOID);
     else GEOGCN_R(GEOGCN_ACT_NONE);
 #undef GEOGCN_R
@@ -769,7 +794,7 @@ size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
 // called by geogcn_gemm_f32 for transA == 0 and precision != F32
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
-                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w, int64_t panel_R) {
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w, int64_t panel_R, const GateOps* gate) {
     const int ns = (precision == GEOGCN_GEMM_BF16X3) ? 3 : 1;
     const int Kp = (int)(cdiv(K, BKH) * BKH);
     const size_t need = gemm_bf16_workspace_bytes(precision, N, K);
@@ -783,9 +808,14 @@ int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t 
         GEOGCN_LAUNCH_CHECK("prep_b_frag_kernel");
         Bf16Args a{M, N, K, A, lda, planes, kp, C, ldc, bias, accumulate, (int)cdiv(M, kRowsBM), 1, c_bf16,
                    c_bf16 ? ((N + 7) & ~(int64_t)7) : ((N + 3) & ~(int64_t)3), 0, 0};
+        if (gate) { a.gateG = gate->G; a.ldg = gate->ldg; a.gateT = gate->T; a.ldt = gate->ldt; }
         if (kp == 608) return launch_rows<608>(a, act, st);
         if (kp == 320) return launch_rows<320>(a, act, st);
         return launch_rows<256>(a, act, st);
+    }
+    if (gate) {          // not a whole-rows shape: the carry written first, the product accumulated onto it (same values, same order)
+        if (const int rc = geogcn_gate_carry_f32(M, (int32_t)N, gate->G, gate->ldg, gate->T, gate->ldt, (float*)C, ldc, (void*)st)) return rc;
+        accumulate = 1;
     }
     const unsigned pgrid = (unsigned)std::min<int64_t>(cdiv((int64_t)N * Kp, TPB), 1024);
     if (ns == 3)

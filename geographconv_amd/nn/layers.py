@@ -505,14 +505,16 @@ class DenseLayer(Layer):
                     return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, transB=True, gate_carry=lazy)]
                 return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
                                     accumulate=into[0] is not None)]
-            if lazy is not None:
-                into = [lazy.dense()] + list(into[1:])
+            if lazy is not None and not need_input_grad:
+                lazy = None
             K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ
             after_dw = kwargs.get('after_dw')
             if after_dw is not None:
                 after_dw()            # (partitioned sweep: the sibling convolution's SpMM + return exchange start here)
             if not need_input_grad:
                 return [None]
+            if lazy is not None:          # dH = dZ . W^T + the carry gradient, formed in the epilogue
+                return [K.gemm(dZ, self.W.data, transB=True, precision=prec, gate_carry=lazy)]
             if into[0] is not None:
                 return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True, precision=prec)]
             return [K.gemm(dZ, self.W.data, transB=True, precision=prec)]  # dH = dZ . W^T

@@ -384,8 +384,10 @@ def _gemm_label(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_N
 
 @_timed(_gemm_label)
 def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=None, act=ACT_NONE,
-         accumulate=False, precision=None):
-    """out = act(op(A) . op(B) + bias) [+ out]  -- T.dot / Gemm (reference gcnmodel.py:126,149,285)."""
+         accumulate=False, precision=None, gate_carry=None):
+    """out = act(op(A) . op(B) + bias) [+ out]  -- T.dot / Gemm (reference gcnmodel.py:126,149,285).
+    `gate_carry` (a GateCarry): out = A . op(B) + G * (1 - T), the highway block's carry gradient formed in the epilogue
+    (geogcn_gemm_gated_f32; no bias / activation / accumulate / transA)."""
     lib = _ffi.lib()
     M = A.F if transA else A.n
     K = A.n if transA else A.F
@@ -419,6 +421,15 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     prec = GEMM_PRECISIONS[precision or GEMM_PRECISION]
     need = lib.geogcn_gemm_workspace_bytes(int(transA), int(transB), M, N, K, prec)
     w = ws.get(need)
+    if gate_carry is not None:
+        g, t = gate_carry.G, gate_carry.T
+        if transA or accumulate or bias is not None or act != ACT_NONE:
+            raise ValueError("gemm: a gate carry excludes transA, accumulate, bias and activation")
+        if g.n != M or g.F != N or t.n != M or t.F != N:
+            raise ValueError("gemm: the gate carry's operands do not have the output's shape")
+        check(lib.geogcn_gemm_gated_f32(int(transB), M, N, K, _p(A.t), A.ld, _p(B.t), B.ld, _p(out.t), out.ld, _p(g.t), g.ld,
+                                        _p(t.t), t.ld, prec, _p(w), w.numel(), _stream()), 'gemm_gated_f32')
+        return out
     check(lib.geogcn_gemm_f32(int(transA), int(transB), M, N, K, _p(A.t), A.ld, _p(B.t), B.ld, _p(out.t),
                               out.ld, _p(bias), act, int(accumulate), prec, _p(w), w.numel(), _stream()),
           'gemm_f32')
@@ -462,6 +473,16 @@ class GateCarry:
         check(_ffi.lib().geogcn_gate_carry_f32(self.G.n, self.G.F, _p(self.G.t), self.G.ld, _p(self.T.t), self.T.ld, _p(out.t),
                                                out.ld, _stream()), 'gate_carry_f32')
         return out
+
+
+def gemm_gated_native(n, F, precision=None):
+    """Does ONE product dH = dZ . W^T + G * (1 - T) (the separate launches of the reverse sweep: bf16 configuration, FUSE_GEMMS
+    off) form the carry in its epilogue?  bf16: the whole-rows kernel takes every GCN width (any other falls back to carry +
+    accumulate at the cost of the stored carry); fp32: from 32,768 rows on."""
+    p = precision or GEMM_PRECISION
+    if p == 'bf16':
+        return True
+    return p == 'f32' and _ffi.lib().geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_F32) > 0
 
 
 def kcat_gated_native(n, F):

@@ -251,6 +251,11 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
  * takes dHcarry = NULL and neither writes nor re-reads 4 M N bytes.  Bit-identical to geogcn_highway_bwd_f32 (with dHcarry) followed
  * by geogcn_gemm_kcat_f32(accumulate = 1).  Shapes the whole-rows kernel does not take (or ws too small) run as
  * geogcn_gate_carry_f32 into C + the accumulating call.  C must not alias G or T.                                            */
+/* ... and for ONE product: C[M x N] = A . op(B) + G * (1 - T) in any `precision` (the bf16 configuration forms dH_in with two
+ * calls: this one, then an accumulating geogcn_gemm_f32).  ws as for geogcn_gemm_f32 (geogcn_gemm_workspace_bytes).             */
+int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                          int64_t ldb, float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
+                          int32_t precision, void* ws, size_t ws_bytes, void* stream);
 int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                                const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                                float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, void* ws,

@@ -82,7 +82,15 @@ def spmm_x_dropout(x, W, bias, act, p, mask_in=None, seed=0, offset=0, calls_dev
     return None          # (the fused product + dropout launch is a property of the HIP backend: callers fall back)
 
 
-def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None):
+def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None, gate_carry=None):
+    if gate_carry is not None:
+        assert not (transA or accumulate or bias is not None or act != ACT_NONE)
+        c = gate_carry.dense()
+        if out is None:
+            out = c
+        else:
+            out.t.copy_(c.t)
+        accumulate = True
     a = _v(A).T if transA else _v(A)
     b = _v(B).T if transB else _v(B)
     r = a @ b
@@ -121,6 +129,10 @@ class GateCarry:
         out = DMat(self.G.n, self.G.F, self.G.device)
         _v(out)[...] = _v(self.G) * (1 - _v(self.T))
         return out
+
+
+def gemm_gated_native(n, F, precision=None):
+    return True
 
 
 def kcat_gated_native(n, F):

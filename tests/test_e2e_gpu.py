@@ -490,6 +490,35 @@ def test_carry_gradient_handed_down_at_sizes_the_whole_rows_kernel_does_not_take
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
 
 
+@pytest.mark.parametrize("config", ['bf16', 'f32, separate launches'])
+def test_carry_gradient_in_the_epilogue_of_the_first_of_two_products(cmu, monkeypatch, config):
+    """Where dH_in = dZ.Wh^T + dU.Wt^T is two launches -- the bf16 configuration; exact fp32 with tuning.FUSE_GEMMS off -- the
+    first of them forms the carry gradient (geogcn_gemm_gated_f32) and highway_bwd does not store it: three steps bitwise the
+    run with the stored carry."""
+    from geographconv_amd import ops, tuning
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    kw = {'gemm_precision': 'bf16'} if config == 'bf16' else {}
+    if config != 'bf16':
+        monkeypatch.setattr(tuning, 'FUSE_GEMMS', False)
+        monkeypatch.setattr(ops, 'gemm_gated_native', lambda n, F, precision=None: True)      # (9,475 rows: carry + accumulate inside the call)
+    made, formed = _count_gate_carries(monkeypatch)
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tuning, 'FUSE_GATE_CARRY', fused)
+        del made[:], formed[:]
+        clf = _clf(c, **kw)
+        clf.inject_dropout_mask(c['mask'])
+        hist = []
+        for step in range(3):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+        runs.append((hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out)))
+        assert (len(made) > 0, len(formed)) == ((True, 0) if fused else (False, 0)), (fused, len(made), len(formed))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
 def test_bf16_configuration_branch_gradient_stored_as_bf16(cmu, monkeypatch):
     """tuning.FUSE_BF16_DS: in the bf16 configuration highway_bwd writes the convolution branch's gradient as bf16 (what
     A^T . dS gathers) instead of fp32 + a cast pass: three training steps are bitwise the run with the separate cast."""

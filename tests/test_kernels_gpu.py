@@ -571,7 +571,8 @@ def test_single_products_on_the_whole_rows_kernel_bitwise(dev, M, N, K, transB):
     assert torch.equal(wide.t[:, :N], got.t[:, :N]) and torch.all(wide.t[:, ops.pad4(N):] == 7.0)
 
 
-@pytest.mark.parametrize("M,F,pitched", [(40000, 300, False), (33001, 256, True), (50001, 289, True), (5000, 300, False), (777, 129, True)])
+@pytest.mark.parametrize("M,F,pitched", [(40000, 300, False), (33001, 256, True), (50001, 289, True), (5000, 300, False), (777, 129, True),
+                                         (4100, 600, False), (3000, 620, True)])
 def test_gemm_kcat_with_the_carry_gradient_in_its_epilogue_bitwise(dev, M, F, pitched):
     """geogcn_gemm_kcat_gated_f32: dH = dZ . Wh^T + dU . Wt^T + G * (1 - T) with the highway block's carry formed in the epilogue
     of the whole-rows kernel (large M) or by geogcn_gate_carry_f32 ahead of the accumulating call (any other shape) is BIT-identical
@@ -607,6 +608,16 @@ def test_gemm_kcat_with_the_carry_gradient_in_its_epilogue_bitwise(dev, M, F, pi
         assert torch.equal(wide.t[:, :F], want.t[:, :F]) and torch.all(wide.t[:, ops.gather_ld(F):] == 7.0)
     with pytest.raises(ValueError):
         ops.gemm_kcat(dZ, Wh, dU, Wt, out=want, transB=True, accumulate=True, gate_carry=ops.GateCarry(G, T))
+    # ONE product with the carry in its epilogue (geogcn_gemm_gated_f32: the bf16 configuration's first of two launches; exact
+    # fp32 and bf16x3 as well), against the stored carry + the accumulating call of the same precision
+    for prec in ('bf16', 'f32', 'bf16x3'):
+        for transB in (True, False):
+            want = ops.DMat.from_numpy(carry.numpy(), dev)
+            ops.gemm(dZ, Wh, out=want, transB=transB, accumulate=True, precision=prec)
+            got = ops.gemm(dZ, Wh, transB=transB, precision=prec, gate_carry=ops.GateCarry(G, T))
+            assert torch.equal(got.t, want.t), (prec, transB)
+    with pytest.raises(ValueError):
+        ops.gemm(dZ, Wh, transB=True, accumulate=True, out=want, gate_carry=ops.GateCarry(G, T))
 
 
 @pytest.mark.parametrize("M,N,K0,K1", [(1000, 300, 300, 300), (4100, 600, 600, 600), (777, 300, 129, 300), (333, 16, 40, 64),
