@@ -257,8 +257,14 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_rows_kernel: 64 whole rows of A per block, dual)", 'gemm_dual_nn', 2 * fl,
          3 * act + 2 * wb, 'f32')
     mfma("H^T . [dZ | dU]  (gemm_tn_direct_kernel: fragments straight into registers, no LDS; split-K + ordered combine)", 'gemm_dual_tn', 2 * fl, 3 * act + 2 * wb, 'f32')
-    mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl,
-         4 * act + 2 * wb, 'f32', "operand bytes: dZ, dU read, the carry read and dH written")
+    from geographconv_amd import tuning as _tuning
+    if _tuning.FUSE_GATE_CARRY:
+        mfma("dH = dZ . Wh^T + dU . Wt^T + G (1 - T)  (gemm_rows_kernel, two A operands into one accumulator, the block's carry "
+             "gradient formed in the epilogue)", 'gemm_kcat', 2 * fl, 5 * act + 2 * wb, 'f32',
+             "operand bytes: dZ, dU, G, T read, dH written (highway_bwd does not store the carry)")
+    else:
+        mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl,
+             4 * act + 2 * wb, 'f32', "operand bytes: dZ, dU read, the carry read and dH written")
     # single products (every GEMM of the bf16 / bf16x3 configurations, the output layer's in all): label = shape and form
     for key in sorted(k for k in ms if k.startswith('gemm:')):
         _, form, prec, M_, N_, K_, cb, acc = key.split(':')
