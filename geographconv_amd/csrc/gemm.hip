@@ -1035,6 +1035,10 @@ inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int 
 // The fused launches (two N segments or two K segments) and, since round 4, single A . B^T products (rows_kp); a single 300-wide
 // A . B runs as fast on the staged kernel (0.74 against 0.75 ms).  Every segment must fill its column passes (a pass is 320 columns: 300 -> 320 is the padding the
 // staged kernel has as well; 256 would multiply 64 columns of zeros: at most an eighth may be padding) and K must pad to an instantiated depth.
+#ifndef GEOGCN_ROWS_MIN_M
+#define GEOGCN_ROWS_MIN_M 32768
+#endif
+constexpr int64_t kRowsMinM = GEOGCN_ROWS_MIN_M;          // rows from which the whole-rows kernel is taken (A/B builds override)
 inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
 inline int rows_wct(int64_t N) { return (int)cdiv(cdiv(N, 16), 4 * rows_passes(N)); }      // 5, or 4 (N <= 256, 321..512), or fewer
 inline int rows_kp(const GemmCall& c, bool transA, bool transB = false) {
@@ -1049,7 +1053,7 @@ inline int rows_kp(const GemmCall& c, bool transA, bool transB = false) {
 #ifdef GEOGCN_F32_NO_ROWS_SINGLE          // A/B build only
     single_ok = false;
 #endif
-    if (transA || c.panel_w || (c.n_nseg == 1 && c.n_kseg == 1 && !single_ok) || c.M < 32768) return 0;
+    if (transA || c.panel_w || (c.n_nseg == 1 && c.n_kseg == 1 && !single_ok) || c.M < kRowsMinM) return 0;
     const int64_t kp = cdiv(c.K[0], 16) * 16;
     if (kp != 304 && kp != 256) return 0;
     if (c.n_kseg == 2 && (cdiv(c.K[1], 16) * 16 != kp || c.N[0] > 320)) return 0;      // one accumulator: one column pass
