@@ -121,6 +121,10 @@ int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64
 size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K);
 // `gate` (nullable): C += G * (1 - T) -- the highway block's carry gradient formed in the epilogue (fp32 C, no bias / activation /
 // accumulate); shapes the whole-rows kernel does not take write it with geogcn_gate_carry_f32 first and accumulate onto it
+size_t gemm_bf16_dual_workspace_bytes(int64_t N0, int64_t N1, int64_t K);
+int gemm_bf16_dual_dispatch(int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda, const float* B0,
+                            int64_t ldb0, const float* B1, int64_t ldb1, void* C0, int64_t ldc0, int c0_bf16, float* C1,
+                            int64_t ldc1, const float* bias1, int act1, void* ws, size_t ws_bytes, hipStream_t st);
 struct GateOps { const float* G; int64_t ldg; const float* T; int64_t ldt; };
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,

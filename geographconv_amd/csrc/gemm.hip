@@ -1347,6 +1347,30 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
     return run_call(false, transB != 0, c, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t geogcn_gemm_dual_bf16_workspace_bytes(int64_t M, int64_t N0, int64_t N1, int64_t K) {
+    if (M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0) return 0;
+    return gemm_bf16_dual_workspace_bytes(N0, N1, K);
+}
+
+int geogcn_gemm_dual_bf16(int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda, const float* B0, int64_t ldb0,
+                          const float* B1, int64_t ldb1, void* C0, int64_t ldc0, int32_t c0_bf16, float* C1, int64_t ldc1,
+                          const float* bias1, int32_t act1, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "gemm_dual_bf16";
+    GEOGCN_REQUIRE(M >= 0 && N0 > 0 && N1 > 0 && K > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    GEOGCN_REQUIRE(act1 >= GEOGCN_ACT_NONE && act1 <= GEOGCN_ACT_SIGMOID, GEOGCN_E_ARG, "%s: unknown act %d", fn, act1);
+    if (M == 0) return 0;
+    GEOGCN_REQUIRE(A && B0 && B1 && C0 && C1, GEOGCN_E_NULL, "%s: null pointer", fn);
+    GEOGCN_REQUIRE(lda >= K && ldb0 >= N0 && ldb1 >= N1 && ldc0 >= N0 && ldc1 >= N1, GEOGCN_E_SIZE, "%s: leading dimension too small", fn);
+    GEOGCN_REQUIRE(ld_ok(A, lda) && ld_ok(B0, ldb0) && ld_ok(B1, ldb1) && ld_ok(C1, ldc1) && aligned16(C0), GEOGCN_E_ALIGN,
+                   "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
+    if (c0_bf16)
+        GEOGCN_REQUIRE(ldc0 % 8 == 0 && ldc0 >= ((N0 + 7) & ~(int64_t)7), GEOGCN_E_ALIGN, "%s: a bf16 C0 needs ldc0 %% 8 == 0 and >= roundup8(N0)", fn);
+    else
+        GEOGCN_REQUIRE(ldc0 % 4 == 0, GEOGCN_E_ALIGN, "%s: ldc0 %% 4 != 0", fn);
+    return gemm_bf16_dual_dispatch(M, N0, N1, K, A, lda, B0, ldb0, B1, ldb1, C0, ldc0, c0_bf16, C1, ldc1, bias1, act1, ws, ws_bytes,
+                                   (hipStream_t)stream);
+}
+
 int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                           int64_t ldb, float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
                           int32_t precision, void* ws, size_t ws_bytes, void* stream) {

@@ -85,6 +85,12 @@ struct Bf16Args {
     int panel_w;                        // > 0: C is laid out as feature panels [N / panel_w][panel_R][panel_w] (gemm.hip)
     int64_t panel_R;
     const float* gateG = nullptr; int64_t ldg = 0; const float* gateT = nullptr; int64_t ldt = 0;      // whole-rows kernel only (common.h GateOps)
+    // whole-rows kernel only: a SECOND column segment of the same launch (the highway block's H . [Wh | Wt]: segment 0 = the
+    // fields above, without activation; segment 1 = these, with the launch's activation) -- A is read and rounded once
+    int n_nseg = 1;
+    int passes0 = 0, passes1 = 0;
+    const unsigned short* Bp1 = nullptr; void* C1 = nullptr; int64_t ldc1 = 0; const float* bias1 = nullptr; int64_t N1 = 0;
+    int c_bf16_1 = 0; int64_t n_store1 = 0;
 };
 
 template <int BM, int BN, int NS, int NT>
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
     const int li = lane & 15, lg = lane >> 4;
     const int K4 = (int)((a.K + 3) & ~(int64_t)3);            // pad columns of A up to roundup4(K) are zero (geogcn.h); beyond: not read
     const uint32_t ld4 = (uint32_t)a.lda * 4u;
-    const __amdgpu_buffer_rsrc_t brs = tn_rsrc(reinterpret_cast<const float*>(a.Bp), (int64_t)4 * passes * WCT * NK * 1024);
+    const int P = a.n_nseg == 2 ? a.passes0 + a.passes1 : passes;
     for (int mt = blockIdx.x; mt < a.n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
         {
@@ -466,9 +472,19 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
         }
         __syncthreads();
 #pragma unroll 1
-        for (int ps = 0; ps < passes; ++ps) {
-            const int tile0 = (wid * passes + ps) * WCT;        // first of this wave's column tiles in this pass
+        for (int ps = 0; ps < P; ++ps) {
+            // (segment, pass inside it: wave-uniform)
+            const int seg = (a.n_nseg == 2 && ps >= a.passes0) ? 1 : 0;
+            const int lps = seg ? ps - a.passes0 : ps;
+            const int spasses = a.n_nseg == 2 ? (seg ? a.passes1 : a.passes0) : passes;
+            const int tile0 = (wid * spasses + lps) * WCT;        // first of this wave's column tiles in this pass
             const int64_t ncol0 = (int64_t)tile0 * 16;
+            const __amdgpu_buffer_rsrc_t brs = tn_rsrc(reinterpret_cast<const float*>(seg ? a.Bp1 : a.Bp), (int64_t)4 * spasses * WCT * NK * 1024);
+            const int64_t Nseg = seg ? a.N1 : a.N, nstore = seg ? a.n_store1 : a.n_store, ldc = seg ? a.ldc1 : a.ldc;
+            void* const Cseg = seg ? a.C1 : a.C;
+            const float* const bias = seg ? a.bias1 : a.bias;
+            const bool cb16 = (seg ? a.c_bf16_1 : a.c_bf16) != 0;
+            const bool act_on = a.n_nseg == 1 || seg == 1;
             f32x4 acc[MR][WCT];
 #pragma unroll
             for (int i = 0; i < MR; ++i)
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
             for (int j = 0; j < WCT; ++j) {
                 const int64_t col0 = ncol0 + j * 16 + lg * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && col0 + r < a.N) ? a.bias[col0 + r] : 0.f;
+                for (int r = 0; r < 4; ++r) bcol[j][r] = (bias && col0 + r < Nseg) ? bias[col0 + r] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
@@ -525,7 +541,7 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
                     for (int j = 0; j < WCT; ++j) {
                         const int64_t col0 = ncol0 + j * 16 + lg * 4;
                         oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row_ok && col0 < a.N) oldv[j] = *reinterpret_cast<const float4*>((const float*)a.C + row * a.ldc + col0);
+                        if (row_ok && col0 < Nseg) oldv[j] = *reinterpret_cast<const float4*>((const float*)Cseg + row * ldc + col0);
                     }
                 }
                 float4 gv[GATE ? WCT : 1], tv[GATE ? WCT : 1];
@@ -535,8 +551,8 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
                         const int64_t col0 = ncol0 + j * 16 + lg * 4;
                         gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                         tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row_ok && col0 < a.N) gv[j] = *reinterpret_cast<const float4*>(a.gateG + row * a.ldg + col0);
-                        if (row_ok && col0 < a.N) tv[j] = *reinterpret_cast<const float4*>(a.gateT + row * a.ldt + col0);
+                        if (row_ok && col0 < Nseg) gv[j] = *reinterpret_cast<const float4*>(a.gateG + row * a.ldg + col0);
+                        if (row_ok && col0 < Nseg) tv[j] = *reinterpret_cast<const float4*>(a.gateT + row * a.ldt + col0);
                     }
                 }
 #pragma unroll
@@ -544,7 +560,10 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
                     const int64_t col0 = ncol0 + j * 16 + lg * 4;
                     float x[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[r] = apply_act<ACT>(acc[i][j][r] + bcol[j][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        x[r] = acc[i][j][r] + bcol[j][r];
+                        if (ACT == GEOGCN_ACT_NONE || act_on) x[r] = apply_act<ACT>(x[r]);
+                    }
                     if (a.accumulate) { x[0] += oldv[j].x; x[1] += oldv[j].y; x[2] += oldv[j].z; x[3] += oldv[j].w; }
                     if constexpr (GATE) {
                         x[0] = add_gate_carry(x[0], gv[j].x, tv[j].x); x[1] = add_gate_carry(x[1], gv[j].y, tv[j].y);
@@ -552,16 +571,16 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (col0 + r >= a.N) x[r] = 0.f;
-                    if (row_ok && col0 < a.n_store) {
-                        const int64_t off = row * a.ldc + col0;
-                        if (a.c_bf16) {
+                        if (col0 + r >= Nseg) x[r] = 0.f;
+                    if (row_ok && col0 < nstore) {
+                        const int64_t off = row * ldc + col0;
+                        if (cb16) {
                             uint2 w;
                             w.x = bf16_pack(x[0], x[1]);
                             w.y = bf16_pack(x[2], x[3]);
-                            *reinterpret_cast<uint2*>((unsigned short*)a.C + off) = w;
+                            *reinterpret_cast<uint2*>((unsigned short*)Cseg + off) = w;
                         } else {
-                            *reinterpret_cast<float4*>((float*)a.C + off) = make_float4(x[0], x[1], x[2], x[3]);
+                            *reinterpret_cast<float4*>((float*)Cseg + off) = make_float4(x[0], x[1], x[2], x[3]);
                         }
                     }
                 }
@@ -789,6 +808,50 @@ size_t gemm_bf16_workspace_bytes(int precision, int64_t N, int64_t K) {
     // (the whole-rows kernel reads its weights in fragment order, padded to 4 waves x passes x 5 column tiles)
     const int64_t cols = rows_kp(N, K, 0, ns) ? std::max<int64_t>(N, (int64_t)4 * rows_passes(N) * kRowsWCT * 16) : N;
     return (size_t)ns * (size_t)cols * (size_t)Kp * sizeof(unsigned short);
+}
+
+// ---- the highway block's forward pair in ONE launch (bf16 configuration): Z = H . Wh as bf16 (the SpMM's operand) or fp32,
+// T = act1(H . Wt + bias1) as fp32 -- H read from HBM and rounded to bf16 ONCE for both (whole-rows kernel, two column
+// segments); widths the kernel does not take run as the two separate launches.  Same arithmetic either way: bit-identical.
+static size_t dual_slot_bytes(int64_t N, int kp) { return (size_t)4 * rows_passes(N) * kRowsWCT * (kp / BKH) * 1024; }
+static int dual_kp(int64_t N0, int64_t N1, int64_t K) {
+    const int k0 = rows_kp(N0, K, 0, 1), k1 = rows_kp(N1, K, 0, 1);
+    return (k0 && k0 == k1) ? k0 : 0;
+}
+size_t gemm_bf16_dual_workspace_bytes(int64_t N0, int64_t N1, int64_t K) {
+    const size_t separate = std::max(gemm_bf16_workspace_bytes(GEOGCN_GEMM_BF16, N0, K), gemm_bf16_workspace_bytes(GEOGCN_GEMM_BF16, N1, K));
+    const int kp = dual_kp(N0, N1, K);
+    return kp ? std::max(separate, dual_slot_bytes(N0, kp) + dual_slot_bytes(N1, kp)) : separate;
+}
+int gemm_bf16_dual_dispatch(int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda, const float* B0,
+                            int64_t ldb0, const float* B1, int64_t ldb1, void* C0, int64_t ldc0, int c0_bf16, float* C1,
+                            int64_t ldc1, const float* bias1, int act1, void* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = gemm_bf16_dual_workspace_bytes(N0, N1, K);
+    GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "gemm_dual_bf16: workspace too small (%zu < %zu)", ws_bytes, need);
+    const int kp = dual_kp(N0, N1, K);
+    if (!kp || lda % 4 != 0) {
+        if (const int rc = gemm_bf16_dispatch(GEOGCN_GEMM_BF16, 0, M, N0, K, A, lda, B0, ldb0, C0, ldc0, c0_bf16, nullptr, GEOGCN_ACT_NONE, 0,
+                                              ws, ws_bytes, st, 0, 0, nullptr))
+            return rc;
+        return gemm_bf16_dispatch(GEOGCN_GEMM_BF16, 0, M, N1, K, A, lda, B1, ldb1, C1, ldc1, 0, bias1, act1, 0, ws, ws_bytes, st, 0, 0, nullptr);
+    }
+    const int nks = kp / BKH;
+    unsigned short* p0 = (unsigned short*)ws;
+    unsigned short* p1 = p0 + dual_slot_bytes(N0, kp) / sizeof(unsigned short);
+    const int t0 = 4 * rows_passes(N0) * kRowsWCT, t1 = 4 * rows_passes(N1) * kRowsWCT;
+    hipLaunchKernelGGL((prep_b_frag_kernel<1>), dim3((unsigned)std::min<int64_t>(cdiv((int64_t)t0 * nks * 512, TPB), 1024)), dim3(TPB), 0, st,
+                       B0, ldb0, (int)K, (int)N0, nks, t0, 0, p0);
+    hipLaunchKernelGGL((prep_b_frag_kernel<1>), dim3((unsigned)std::min<int64_t>(cdiv((int64_t)t1 * nks * 512, TPB), 1024)), dim3(TPB), 0, st,
+                       B1, ldb1, (int)K, (int)N1, nks, t1, 0, p1);
+    GEOGCN_LAUNCH_CHECK("prep_b_frag_kernel");
+    Bf16Args a{M, N0, K, A, lda, p0, kp, C0, ldc0, nullptr, 0, (int)cdiv(M, kRowsBM), 1, c0_bf16,
+               c0_bf16 ? ((N0 + 7) & ~(int64_t)7) : ((N0 + 3) & ~(int64_t)3), 0, 0};
+    a.n_nseg = 2;
+    a.passes0 = rows_passes(N0); a.passes1 = rows_passes(N1);
+    a.Bp1 = p1; a.C1 = C1; a.ldc1 = ldc1; a.bias1 = bias1; a.N1 = N1; a.c_bf16_1 = 0; a.n_store1 = (N1 + 3) & ~(int64_t)3;
+    if (kp == 608) return launch_rows<608>(a, act1, st);
+    if (kp == 320) return launch_rows<320>(a, act1, st);
+    return launch_rows<256>(a, act1, st);
 }
 
 // called by geogcn_gemm_f32 for transA == 0 and precision != F32

@@ -293,6 +293,11 @@ class DenseLayer(Layer):
                 _, y = K.gemm_dual(input, conv.W.data, self.W.data, out0=zf, bias1=bias, act1=act)
                 tape[('fused_z', conv)] = (input, zf)
                 saved['fused_with'] = conv
+            elif self._fusable_sibling(input, tape, kwargs, bf16=True) is not None:
+                # the same pair in the bf16 configuration: Z leaves the accumulators as bf16 (the SpMM's operand), T as fp32
+                conv = self._fusable_sibling(input, tape, kwargs, bf16=True)
+                zf, y = K.gemm_dual_bf16(input, conv.W.data, self.W.data, bias1=bias, act1=act)
+                tape[('fused_z', conv)] = (input, zf)            # (no 'fused_with': the reverse sweep keeps its bf16 launches)
             elif isinstance(input, K.DMat):
                 y = K.gemm(input, self.W.data, bias=bias, act=act, precision=prec)   # bias + act fused
             else:
@@ -305,8 +310,12 @@ class DenseLayer(Layer):
                 if K.bf16_gather(prec) and isinstance(input, K.DMat) and type(self)._matmul is DenseLayer._matmul:
                     # bf16 configuration: Z goes from the MFMA accumulators to HBM as bf16 -- half the bytes per
                     # gathered row in the SpMM, no fp32 round trip
-                    zf = K.HMat(n_in, self.num_units, y_device(input))
-                    self._matmul(input, zf, prec)
+                    pre = tape.pop(('fused_z', self), None) if tape is not None else None
+                    if pre is not None and pre[0] is input and isinstance(pre[1], K.HMat):
+                        zf = pre[1]                 # the gate's launch already multiplied by this layer's W (geogcn_gemm_dual_bf16)
+                    else:
+                        zf = K.HMat(n_in, self.num_units, y_device(input))
+                        self._matmul(input, zf, prec)
                 else:
                     pre = tape.pop(('fused_z', self), None) if tape is not None else None
                     if pre is not None and pre[0] is input:
@@ -365,14 +374,18 @@ class DenseLayer(Layer):
                 return y
         return K.spmm_x(input, self.W.data, bias=bias, act=act)
 
-    def _fusable_sibling(self, input, tape, kwargs):
-        """The highway block's conv branch, when its H.W can ride in this gate's launch: one GPU, exact-fp32 products,
-        a graph convolution (whose Z stays linear) with a plain dense product, evaluated with a tape."""
+    def _fusable_sibling(self, input, tape, kwargs, bf16=False):
+        """The highway block's conv branch, when its H.W can ride in this gate's launch: one GPU, exact-fp32 products (or, `bf16`,
+        the bf16 configuration with its bf16 SpMM operand), a graph convolution (whose Z stays linear) with a plain dense product,
+        evaluated with a tape."""
         K = backend.active()
         conv = getattr(self, 'highway_conv', None)
+        prec = kwargs.get('gemm_precision') or K.GEMM_PRECISION
+        if bf16 and not (prec == 'bf16' and K.bf16_gather(prec) and tuning.FUSE_BF16_DUAL):
+            return None
         if (conv is None or tape is None or kwargs.get('comm') is not None or kwargs.get('A') is None
                 or not isinstance(input, K.DMat) or conv.input_layer is not self.input_layer
-                or (kwargs.get('gemm_precision') or K.GEMM_PRECISION) != 'f32' or not _fuse_gemms()
+                or (not bf16 and prec != 'f32') or not _fuse_gemms()
                 or not conv._uses_graph(kwargs) or type(conv)._matmul is not DenseLayer._matmul
                 or conv.W.data is None or conv.W.shape[0] != self.W.shape[0]):
             return None

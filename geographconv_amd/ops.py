@@ -490,6 +490,25 @@ def kcat_gated_native(n, F):
     return _ffi.lib().geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F)) > 0
 
 
+@_timed('gemm_dual_bf16')
+def gemm_dual_bf16(A: DMat, B0: DMat, B1: DMat, out0=None, out1: DMat = None, bias1=None, act1=ACT_NONE):
+    """(out0, out1) = (A . B0, act1(A . B1 + bias1)) with bf16 products in ONE launch (geogcn_gemm_dual_bf16): the bf16
+    configuration's highway block -- out0 an HMat (bf16: what the SpMM gathers) or a DMat, out1 fp32."""
+    lib = _ffi.lib()
+    if B0.n != A.F or B1.n != A.F:
+        raise ValueError("gemm_dual_bf16: inner dimensions differ (%d vs %d, %d)" % (A.F, B0.n, B1.n))
+    out0 = HMat(A.n, B0.F, A.device) if out0 is None else out0
+    out1 = DMat.empty(A.n, B1.F, A.device) if out1 is None else out1
+    ws = _gemm_ws.get(A.device)
+    if ws is None:
+        ws = _gemm_ws[A.device] = Workspace(A.device)
+    w = ws.get(lib.geogcn_gemm_dual_bf16_workspace_bytes(A.n, B0.F, B1.F, A.F))
+    check(lib.geogcn_gemm_dual_bf16(A.n, B0.F, B1.F, A.F, _p(A.t), A.ld, _p(B0.t), B0.ld, _p(B1.t), B1.ld, _p(out0.t), out0.ld,
+                                    int(isinstance(out0, HMat)), _p(out1.t), out1.ld, _p(bias1), int(act1), _p(w), w.numel(),
+                                    _stream()), 'gemm_dual_bf16')
+    return out0, out1
+
+
 @_timed('gemm_kcat')
 def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, gate_carry: GateCarry = None):
     """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --

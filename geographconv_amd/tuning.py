@@ -41,6 +41,10 @@ FUSE_HIGHWAY = 'all'
 # of written by highway_bwd and read back: 0.53 GB less written per 300-wide block at the TwitterUS size; same bits
 FUSE_GATE_CARRY = True
 
+# bf16 configuration, one GPU: the highway block's H . Wh (bf16 result, the SpMM's operand) and sigmoid(H . Wt + bt) in one launch of
+# the bf16 whole-rows kernel -- H read and rounded once (geogcn_gemm_dual_bf16); same bits as the two launches
+FUSE_BF16_DUAL = True
+
 # bf16 configuration, one GPU: highway_bwd stores the branch gradient dS as bf16 (what A^T . dS gathers) instead of fp32 + a cast
 # pass (-0.37 ms per 600-wide block; same bits)
 FUSE_BF16_DS = True

@@ -235,6 +235,14 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
                          const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
                          float* C1, int64_t ldc1, const float* bias0, int32_t act0, const float* bias1, int32_t act1,
                          void* ws, size_t ws_bytes, void* stream);
+/* The forward pair of the bf16 configuration (BASELINE configs[4]) in one launch: C0 = A . B0 stored as bfloat16 (c0_bf16 = 1: the
+ * operand geogcn_spmm_csr_bf16b gathers; pitch a multiple of 8, pads as zeros) or fp32, C1 = act1(A . B1 + bias1) in fp32 --
+ * bf16 products, fp32 accumulation, A read and rounded once (bf16 whole-rows kernel, widths <= 640 with K padding to 256 / 320 /
+ * 608); other shapes run as the two separate geogcn_gemm_f32 / geogcn_gemm_f32_bf16c launches.  Bit-identical to those.        */
+size_t geogcn_gemm_dual_bf16_workspace_bytes(int64_t M, int64_t N0, int64_t N1, int64_t K);
+int geogcn_gemm_dual_bf16(int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda, const float* B0, int64_t ldb0,
+                          const float* B1, int64_t ldb1, void* C0, int64_t ldc0, int32_t c0_bf16, float* C1, int64_t ldc1,
+                          const float* bias1, int32_t act1, void* ws, size_t ws_bytes, void* stream);
 /* Two products into one accumulator (what autodiff derives for the input of the highway block: dH = dZ.Wh^T + dU.Wt^T
  * [+ the carry gradient already in C]):  C[M x N] = A0 . op(B0) + A1 . op(B1) [+ C].  A0 is M x K0, A1 is M x K1;
  * transB = 1: B0 is N x K0, B1 is N x K1 (the weights as stored); transB = 0: B0 is K0 x N, B1 is K1 x N.

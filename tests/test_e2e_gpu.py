@@ -519,6 +519,34 @@ def test_carry_gradient_in_the_epilogue_of_the_first_of_two_products(cmu, monkey
     assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
 
 
+def test_bf16_configuration_forward_pair_in_one_launch(cmu, monkeypatch):
+    """tuning.FUSE_BF16_DUAL: in the bf16 configuration the highway block's H . Wh (bf16, gathered by the SpMM) and
+    sigmoid(H . Wt + bt) come from ONE launch (geogcn_gemm_dual_bf16): three training steps and a prediction are bitwise the run
+    with the two launches."""
+    from geographconv_amd import ops, tuning
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    calls = []
+    orig = ops.gemm_dual_bf16
+    monkeypatch.setattr(ops, 'gemm_dual_bf16', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tuning, 'FUSE_BF16_DUAL', fused)
+        del calls[:]
+        clf = _clf(c, gemm_precision='bf16')
+        clf.inject_dropout_mask(c['mask'])
+        hist = []
+        for step in range(3):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+        pred, probs = clf.predict(c['X'], c['A'], c['te'])
+        runs.append((hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out), pred, probs))
+        assert (len(calls) > 0) == fused
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    assert np.array_equal(runs[0][3], runs[1][3]) and np.array_equal(runs[0][4], runs[1][4])
+
+
 def test_bf16_configuration_branch_gradient_stored_as_bf16(cmu, monkeypatch):
     """tuning.FUSE_BF16_DS: in the bf16 configuration highway_bwd writes the convolution branch's gradient as bf16 (what
     A^T . dS gathers) instead of fp32 + a cast pass: three training steps are bitwise the run with the separate cast."""

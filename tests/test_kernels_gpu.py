@@ -571,6 +571,28 @@ def test_single_products_on_the_whole_rows_kernel_bitwise(dev, M, N, K, transB):
     assert torch.equal(wide.t[:, :N], got.t[:, :N]) and torch.all(wide.t[:, ops.pad4(N):] == 7.0)
 
 
+@pytest.mark.parametrize("M,K,N0,N1", [(4100, 600, 600, 600), (3001, 300, 300, 300), (2000, 256, 300, 256), (1500, 600, 289, 620), (700, 129, 300, 300),
+                                      (900, 300, 700, 300)])
+def test_gemm_dual_bf16_equals_the_two_launches_bitwise(dev, M, K, N0, N1):
+    """geogcn_gemm_dual_bf16 (the bf16 configuration's H . [Wh | Wt]: one launch of the bf16 whole-rows kernel with two column
+    segments, or the two launches where a width does not fit): Z as bf16 / fp32 and T = sigmoid(H . Wt + bt) are BIT-identical to
+    geogcn_gemm_f32_bf16c / geogcn_gemm_f32 with precision bf16."""
+    from geographconv_amd import ops
+    A = ops.DMat.from_numpy(_rand((M, K), 1), dev)
+    W0, W1 = ops.DMat.from_numpy(_rand((K, N0), 2, 0.1), dev), ops.DMat.from_numpy(_rand((K, N1), 3, 0.1), dev)
+    b1 = torch.from_numpy(_rand((ops.pad4(N1),), 4)).to(dev)
+    z_ref = ops.gemm(A, W0, out=ops.HMat(M, N0, dev), precision='bf16')
+    t_ref = ops.gemm(A, W1, bias=b1, act=ops.ACT_SIGMOID, precision='bf16')
+    z, t = ops.gemm_dual_bf16(A, W0, W1, bias1=b1, act1=ops.ACT_SIGMOID)
+    assert isinstance(z, ops.HMat) and torch.equal(z.t.view(torch.int16)[:, :N0], z_ref.t.view(torch.int16)[:, :N0])
+    assert torch.all(z.t[:, N0:(N0 + 7) // 8 * 8] == 0) and torch.equal(t.t, t_ref.t)
+    z32_ref = ops.gemm(A, W0, precision='bf16')
+    z32, t2 = ops.gemm_dual_bf16(A, W0, W1, out0=ops.DMat.empty(M, N0, dev), bias1=b1, act1=ops.ACT_SIGMOID)
+    assert torch.equal(z32.t, z32_ref.t) and torch.equal(t2.t, t_ref.t)
+    ref = A.numpy().astype(np.float64) @ W0.numpy().astype(np.float64)
+    assert np.abs(z32.numpy() - ref).max() <= 2e-2 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("M,F,pitched", [(40000, 300, False), (33001, 256, True), (50001, 289, True), (5000, 300, False), (777, 129, True),
                                          (4100, 600, False), (3000, 620, True)])
 def test_gemm_kcat_with_the_carry_gradient_in_its_epilogue_bitwise(dev, M, F, pitched):
