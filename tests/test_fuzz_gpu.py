@@ -135,6 +135,28 @@ def test_gemm_dual_and_kcat_random_shapes(dev, seed):
         ref = G0.astype(np.float64) @ W0.T + G1.astype(np.float64) @ W1.T + (C0 if acc else 0.0)
         mag = np.abs(G0) @ np.abs(W0.T) + np.abs(G1) @ np.abs(W1.T) + (np.abs(C0) if acc else 0.0)
         _close(got.numpy(), ref, mag, ('kcat', seed, case, acc))
+        # ... with the highway block's carry gradient G * (1 - T) formed in the epilogue (round 4), for two products and for one
+        # (every precision), and on its own
+        Gc, Tc = rng.randn(M, K).astype(np.float32), rng.rand(M, K).astype(np.float32)
+        gc = ops.GateCarry(_dmat(ops, dev, Gc, rng), _dmat(ops, dev, Tc, rng))
+        carry = Gc.astype(np.float64) * (1.0 - Tc.astype(np.float64))
+        _close(gc.dense().numpy(), carry, np.abs(carry), ('gate carry', seed, case))
+        got = ops.gemm_kcat(_dmat(ops, dev, G0, rng), dW0, _dmat(ops, dev, G1, rng), dW1, transB=True, gate_carry=gc)
+        ref = G0.astype(np.float64) @ W0.T + G1.astype(np.float64) @ W1.T + carry
+        mag = np.abs(G0) @ np.abs(W0.T) + np.abs(G1) @ np.abs(W1.T) + np.abs(carry)
+        _close(got.numpy(), ref, mag, ('kcat gated', seed, case))
+        for prec, tol in (('f32', None), ('bf16x3', None), ('bf16', 2e-2)):
+            got = ops.gemm(_dmat(ops, dev, G0, rng), dW0, transB=True, precision=prec, gate_carry=gc)
+            ref1 = G0.astype(np.float64) @ W0.T + carry
+            if tol is None:
+                _close(got.numpy(), ref1, np.abs(G0) @ np.abs(W0.T) + np.abs(carry), ('gemm gated', prec, seed, case))
+            else:
+                assert np.abs(got.numpy() - ref1).max() <= tol * (np.abs(G0) @ np.abs(W0.T) + np.abs(carry)).max() + 1e-6, (prec, seed, case)
+        # the bf16 configuration's forward pair in one launch (round 4)
+        z16, t32 = ops.gemm_dual_bf16(dH, dW0, dW1, bias1=bt, act1=ops.ACT_SIGMOID)
+        zr, tr_ = h64 @ W0, _act(h64 @ W1 + b1, 2)
+        assert np.abs(z16.numpy() - zr).max() <= 2e-2 * (np.abs(h64) @ np.abs(W0)).max() + 1e-6, ('dual bf16 z', seed, case)
+        assert np.abs(t32.numpy() - tr_).max() <= 2e-2 * max(1.0, (np.abs(h64) @ np.abs(W1)).max()), ('dual bf16 t', seed, case)
 
 
 @pytest.mark.parametrize("seed", _seeds(6))
