@@ -496,7 +496,7 @@ class DenseLayer(Layer):
 
     def _backward_post(self, x, dZ, into, need_input_grad, kwargs, tape=None):
         K = backend.active()
-        lazy = into[0] if (hasattr(into[0], 'dense') and hasattr(into[0], 'G')) else None
+        lazy = into[0] if isinstance(into[0], K.GateCarry) else None
         if isinstance(x, K.DMat):
             prec = kwargs.get('gemm_precision')
             gate = getattr(self, 'highway_gate', None)
@@ -759,7 +759,7 @@ def backward(layer, grad, tape, **kwargs):
     # pure inputs
     def dense(g):
         # a highway block's carry gradient that nobody formed in an epilogue (ops.GateCarry): form it now
-        return g.dense() if hasattr(g, 'dense') and hasattr(g, 'G') else g
+        return g.dense() if isinstance(g, backend.active().GateCarry) else g
 
     def run(l, **extra):
         g = dense(grads.pop(l))

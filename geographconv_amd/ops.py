@@ -554,13 +554,6 @@ def highway_fwd(T: DMat, Hc: DMat, H: DMat, out: DMat = None):
     return out
 
 
-class _NoMatType:
-    t = None
-
-
-_NoMat = _NoMatType()
-
-
 def highway_bwd_bf16_ok(G: DMat, with_bias: bool):
     """Can highway_bwd store dS as bfloat16 for this gradient?  (fused column sums: plain pitch, F <= 1024)"""
     return G.F <= 1024 and (not with_bias or G.ld == pad4(G.F))
@@ -573,22 +566,21 @@ def highway_bwd(G: DMat, T: DMat, Hc: DMat, H: DMat, dS: DMat = None, dU: DMat =
     it directly, the fp32 dS and the cast pass are never written."""
     lib = _ffi.lib()
     dU = G.like() if dU is None else dU
-    if carry:
-        dHcarry = G.like() if dHcarry is None else dHcarry
-    else:
-        dHcarry = _NoMat             # (`carry=False`: dHcarry is not stored -- a GateCarry hands it to gemm_kcat; None comes back)
+    # (`carry=False`: dHcarry is not stored -- a GateCarry hands it to gemm_kcat / gemm; None comes back)
+    dHcarry = (G.like() if dHcarry is None else dHcarry) if carry else None
+    carry_t = dHcarry.t if carry else None
     w = _ws_for(G.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(G.n, G.F),
                                   lib.geogcn_colsum_workspace_bytes(G.n, G.F)) if dbS is not None else 0)
     if dS_bf16:
         dS = HMat(G.n, G.F, G.device) if dS is None else dS
         check(lib.geogcn_highway_bwd_bf16s_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
-                                               _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()),
+                                               _p(carry_t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()),
               'highway_bwd_bf16s_f32')
-        return dS, dU, (dHcarry if carry else None)
+        return dS, dU, dHcarry
     dS = DMat.empty(G.n, G.F, G.device, ld=gather_ld(G.F)) if dS is None else dS      # dS feeds the A^T SpMM
     check(lib.geogcn_highway_bwd_f32(G.n, G.F, _p(G.t), _p(T.t), _p(Hc.t), _p(H.t), G.ld, _p(dS.t), dS.ld, _p(dU.t),
-                                     _p(dHcarry.t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
-    return dS, dU, (dHcarry if carry else None)
+                                     _p(carry_t), _p(dbS), _p(dbU), _p(w), w.numel(), _stream()), 'highway_bwd_f32')
+    return dS, dU, dHcarry
 
 
 def act_bwd(G: DMat, Y: DMat, act, out: DMat = None, keep_mask=None, scale=1.0):
