@@ -75,6 +75,8 @@ class SimComm(TorchDistComm):
         self._auto_default = self.exchange
         self.halo = self.halo_rows = None
         self._bufs = {}
+        from geographconv_amd import tuning
+        self.slabs = max(1, int(tuning.DIST_AG_SLABS))
 
 
 def main():
