@@ -69,6 +69,9 @@ SIGNATURES = {
                                       c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_gated_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                       c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_gemm_kcat_gated_tanhbwd_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
+                                                   c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_sz,
+                                                   c_ptr]),
     'geogcn_gate_carry_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
@@ -82,6 +85,7 @@ SIGNATURES = {
                                           c_ptr, c_sz, c_ptr]),
     'geogcn_add_inplace_f32': (c_i32, [c_i64, c_ptr, c_ptr, c_ptr]),
     'geogcn_colsum_workspace_bytes': (c_sz, [c_i64, c_i32]),
+    'geogcn_colsum_rowblocks_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_colsum_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_dropout_mask_philox': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_u64, c_ptr, c_ptr]),
     'geogcn_dropout_mask_philox_ctr': (c_i32, [c_i64, c_i32, c_f32, c_u64, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),

@@ -17,6 +17,17 @@ __device__ __forceinline__ float add_gate_carry(float x, float g, float t) {
     return x + c;
 }
 
+// dropout-masked tanh gradient, the arithmetic of act_bwd (elementwise.hip) spelled out so that every kernel that forms it -- the
+// elementwise ones and the whole-rows GEMM's epilogue -- produces the same bits: (g * (keep * scale)) * fma(-y, y, 1)
+__device__ __forceinline__ float tanh_bwd_val(float gg, float y) {
+#pragma clang fp contract(off)
+    return gg * __builtin_fmaf(-y, y, 1.0f);
+}
+__device__ __forceinline__ float masked_tanh_bwd(float g, float keep, float scale, float y) {
+#pragma clang fp contract(off)
+    return tanh_bwd_val(g * (keep * scale), y);
+}
+
 constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kNumXCD = 8;

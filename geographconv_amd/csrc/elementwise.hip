@@ -246,7 +246,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, 
         for (int i = 0; i < 4; ++i) {
             float gg = go[i];
             if (mask) gg = (c0 + i < F) ? gg * ((float)mask[row * F + c0 + i] * scale) : 0.f;
-            if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = gg * (1.0f - yo[i] * yo[i]);
+            if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = tanh_bwd_val(gg, yo[i]);
             else if constexpr (ACT == GEOGCN_ACT_SIGMOID) o[i] = gg * (yo[i] * (1.0f - yo[i]));
             else if constexpr (ACT == GEOGCN_ACT_SELU)      // y > 0: scale; else scale*alpha*exp(x) = y + scale*alpha
                 o[i] = gg * (yo[i] > 0.f ? 1.0507009873554805f : yo[i] + 1.0507009873554805f * 1.6732632423543772f);
@@ -259,6 +259,34 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(int64_t n, int F, int F4, 
 
 // act_bwd with the bias gradient (column sums of dS) in the same pass -- same block / thread layout and the same
 // fixed summation order as highway_bwd_colsum_kernel
+// Column sums alone, in the order the fused activation-gradient kernels (act_bwd_colsum_kernel / highway_bwd_colsum_kernel) take
+// them -- block b owns a contiguous chunk of rows, thread (ri, q) adds float4 column q of every rpi-th row, the per-thread sums are
+// combined over ri in order, one partial row per block -- so that a bias gradient formed from a matrix some other kernel produced
+// (the product's epilogue of round 4) has the bits the fused pass would have given it
+__global__ __launch_bounds__(TPB) void colsum_rowblocks_kernel(int64_t n, int F, int W, const float4* __restrict__ X, int ldx4,
+                                                               int64_t rows_per_block, float4* __restrict__ P) {
+    __shared__ float4 red[TPB];
+    const int rpi = TPB / W;
+    const int q = threadIdx.x % W, ri = threadIdx.x / W;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ri < rpi) {
+        for (int64_t row = r0 + ri; row < r1; row += rpi) {
+            const float4 s = mask_pad(X[row * ldx4 + q], q * 4, F);
+            a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (ri == 0) {
+        for (int k = 1; k < rpi; ++k) {
+            const float4 b = red[k * W + q];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        P[(int64_t)blockIdx.x * W + q] = a;
+    }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(TPB) void act_bwd_colsum_kernel(int64_t n, int F, int ld4, const float4* __restrict__ G,
                                                               const float4* __restrict__ Y,
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_colsum_kernel(int64_t n, int F, i
             for (int i = 0; i < 4; ++i) {
                 float gg = go[i];
                 if (mask) gg = (c0 + i < F) ? gg * ((float)mask[row * F + c0 + i] * scale) : 0.f;
-                if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = gg * (1.0f - yo[i] * yo[i]);
+                if constexpr (ACT == GEOGCN_ACT_TANH) o[i] = tanh_bwd_val(gg, yo[i]);
                 else if constexpr (ACT == GEOGCN_ACT_SIGMOID) o[i] = gg * (yo[i] * (1.0f - yo[i]));
                 else o[i] = gg;
             }
@@ -884,6 +912,29 @@ int geogcn_act_bwd_colsum_f32(int64_t n, int32_t F, const float* G, const float*
 #undef GEOGCN_AB
     GEOGCN_LAUNCH_CHECK("act_bwd_colsum_kernel");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, (const float*)ws, ld, db);
+    GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
+int geogcn_colsum_rowblocks_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes, void* stream) {
+    GEOGCN_REQUIRE(n >= 0 && F >= 0, GEOGCN_E_SIZE, "colsum_rowblocks_f32: negative size");
+    GEOGCN_REQUIRE(out, GEOGCN_E_NULL, "colsum_rowblocks_f32: null out");
+    if (F == 0) return 0;
+    if (n == 0) return zero_fill_async(out, (size_t)((F + 3) / 4) * 16, (hipStream_t)stream);
+    const int64_t F4 = (F + 3) / 4;
+    GEOGCN_REQUIRE(X && aligned16(X) && ldx % 4 == 0 && ldx >= F4 * 4, GEOGCN_E_ALIGN,
+                   "colsum_rowblocks_f32: X needs a 16-byte aligned base and a pitch %% 4 == 0, >= roundup4(F)");
+    if (F4 > TPB) return geogcn_colsum_f32(n, F, X, ldx, out, ws, ws_bytes, stream);       // (wider than the fused kernels handle)
+    const int64_t parts = hw_parts(n);
+    const int64_t rpb = cdiv(n, parts);
+    const int nparts = (int)cdiv(n, rpb);
+    GEOGCN_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)nparts * F4 * 4 * sizeof(float), GEOGCN_E_ARG,
+                   "colsum_rowblocks_f32: workspace too small (see geogcn_highway_bwd_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_rowblocks_kernel, dim3((unsigned)nparts), dim3(TPB), 0, st, n, F, (int)F4, (const float4*)X, (int)(ldx / 4), rpb,
+                       (float4*)ws);
+    GEOGCN_LAUNCH_CHECK("colsum_rowblocks_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(F, 16)), dim3(TPB), 0, st, nparts, F, (const float*)ws, F4 * 4, out);
     GEOGCN_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
 }

@@ -590,9 +590,12 @@ struct RowsArgs {
     // C += G * (1 - T), each operation rounded on its own: the carry gradient of the highway block formed here instead of being
     // written by highway_bwd and read back (NULL: none)
     const float* gateG; int64_t ldg; const float* gateT; int64_t ldt;
+    // ... and, on top of it, C = that * (keep * scale) * (1 - Y^2): the dropout + tanh gradient of the layer below the first highway
+    // block (what geogcn_act_bwd_f32 would do in a pass of its own); keep = bytes, pitch postF (a multiple of 4)
+    const float* postY; int64_t ldy; const uint8_t* postKeep; int64_t postF; float postScale;
 };
 
-template <int KP, int ACT, bool GATE = false>
+template <int KP, int ACT, bool GATE = false, bool POST = false>
 __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
     constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
     constexpr int PITCH = KP + 4;               // floats per LDS row: an odd number of float4s -> conflict-free ds_read_b128
@@ -729,17 +732,36 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
                 const __amdgpu_buffer_rsrc_t ersA = tile_rsrc((gG ? gG + m0 * ldg : Cout + m0 * ldc), extra ? rows_here * lda_e * 4 : 0);
                 const __amdgpu_buffer_rsrc_t ersB = tile_rsrc(gG ? gT + m0 * ldt : Cout, gG ? rows_here * ldt * 4 : 0);
                 const uint32_t lda_e4 = (uint32_t)lda_e * 4u, ldt4 = (uint32_t)ldt * 4u;
+                const __amdgpu_buffer_rsrc_t prsY = tile_rsrc(POST ? a.postY + m0 * a.ldy : Cout, POST ? rows_here * a.ldy * 4 : 0);
+                const __amdgpu_buffer_rsrc_t prsK = tile_rsrc(POST ? reinterpret_cast<const float*>(a.postKeep + m0 * a.postF) : Cout,
+                                                              POST ? rows_here * a.postF : 0);
+                const uint32_t ldy4 = POST ? (uint32_t)a.ldy * 4u : 0u, pF = POST ? (uint32_t)a.postF : 0u;
+                const float pscale = POST ? a.postScale : 0.f;
                 auto eload = [&](int i, int j) __attribute__((always_inline)) {
                     const int64_t col0 = ncol0 + j * 16 + lg * 4;
                     const uint32_t r = (uint32_t)(i * 16 + li), c = (uint32_t)col0 * 4u;
                     const bool ok = col0 < Nseg;
                     ea[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ersA, (int)(ok ? r * lda_e4 + c : kOobOffset), 0, 0));
-                    if constexpr (GATE) eb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ersB, (int)(ok ? r * ldt4 + c : kOobOffset), 0, 0));
+                    // (POST: T is requested where it is used -- twenty registers the third flavour does not have)
+                    if constexpr (GATE && !POST) eb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ersB, (int)(ok ? r * ldt4 + c : kOobOffset), 0, 0));
                 };
                 if (extra) {
 #pragma unroll
                     for (int j = 0; j < WCT; ++j) eload(0, j);
                 }
+                // (POST: T, Y and the keep bytes one column tile ahead -- nine registers; rows past M / columns past N read as zero,
+                //  their results are masked before the store anyway)
+                f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, py = pt;
+                uint32_t pk = 0;
+                auto pload = [&](int i, int j) __attribute__((always_inline)) {
+                    const int64_t col0 = ncol0 + j * 16 + lg * 4;
+                    const uint32_t pr = (uint32_t)(i * 16 + li), pc = (uint32_t)col0;
+                    const bool pok = col0 < Nseg;
+                    pt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ersB, (int)(pok ? pr * ldt4 + pc * 4u : kOobOffset), 0, 0));
+                    py = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsY, (int)(pok ? pr * ldy4 + pc * 4u : kOobOffset), 0, 0));
+                    pk = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(prsK, (int)(pok ? pr * pF + pc : kOobOffset), 0, 0);
+                };
+                if constexpr (POST) pload(0, 0);
 #pragma unroll
                 for (int i = 0; i < MR; ++i) {
                     const int64_t row = m0 + i * 16 + li;
@@ -756,8 +778,19 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
                         }
                         if (accum) { x[0] += ea[j][0]; x[1] += ea[j][1]; x[2] += ea[j][2]; x[3] += ea[j][3]; }
                         if constexpr (GATE) {
-                            x[0] = add_gate_carry(x[0], ea[j][0], eb[j][0]); x[1] = add_gate_carry(x[1], ea[j][1], eb[j][1]);
-                            x[2] = add_gate_carry(x[2], ea[j][2], eb[j][2]); x[3] = add_gate_carry(x[3], ea[j][3], eb[j][3]);
+                            f32x4 tq;
+                            if constexpr (POST) tq = pt;
+                            else tq = eb[j];
+                            x[0] = add_gate_carry(x[0], ea[j][0], tq[0]); x[1] = add_gate_carry(x[1], ea[j][1], tq[1]);
+                            x[2] = add_gate_carry(x[2], ea[j][2], tq[2]); x[3] = add_gate_carry(x[3], ea[j][3], tq[3]);
+                        }
+                        if constexpr (POST) {
+                            const f32x4 yv = py;
+                            const uint32_t kv = pk;
+                            x[0] = masked_tanh_bwd(x[0], (float)(kv & 0xffu), pscale, yv[0]);
+                            x[1] = masked_tanh_bwd(x[1], (float)((kv >> 8) & 0xffu), pscale, yv[1]);
+                            x[2] = masked_tanh_bwd(x[2], (float)((kv >> 16) & 0xffu), pscale, yv[2]);
+                            x[3] = masked_tanh_bwd(x[3], (float)(kv >> 24), pscale, yv[3]);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -765,6 +798,10 @@ __global__ __launch_bounds__(TPB, 2) void gemm_rows_kernel(const RowsArgs a) {
                         if (row_ok && col0 < Nseg) *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
                         // this column tile's operands of the NEXT row tile: on their way while the remaining tiles are finished
                         if (extra && i + 1 < MR) eload(i + 1, j);
+                        if constexpr (POST) {           // ... and the third flavour's three operands of the NEXT column tile
+                            if (j + 1 < WCT) pload(i, j + 1);
+                            else if (i + 1 < MR) pload(i + 1, 0);
+                        }
                     }
                 }
             }
@@ -839,6 +876,7 @@ struct GemmCall {
     int panel_w = 0;
     int64_t panel_R = 0;
     const float* gateG = nullptr; int64_t ldg = 0; const float* gateT = nullptr; int64_t ldt = 0;      // whole-rows kernel only
+    const float* postY = nullptr; int64_t ldy = 0; const uint8_t* postKeep = nullptr; int64_t postF = 0; float postScale = 0.f;
     int64_t maxN() const { return n_nseg == 2 ? std::max(N[0], N[1]) : N[0]; }
 };
 
@@ -1084,7 +1122,16 @@ int launch_rows(const RowsArgs& a, int act, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);                                      \
         GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");                                                                 \
     } while (0)
-    if (a.gateG) {
+    if (a.gateG && a.postY) {
+        auto kern = gemm_rows_kernel<KP, GEOGCN_ACT_NONE, true, true>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);
+        GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");
+    } else if (a.gateG) {
         auto kern = gemm_rows_kernel<KP, GEOGCN_ACT_NONE, true>;          // (the gated form has no activation: geogcn_gemm_kcat_gated_f32)
         static bool attr_done = false;
         if (!attr_done) {
@@ -1108,6 +1155,7 @@ int run_rows(int kp, bool transB, const GemmCall& c, void* ws, hipStream_t st) {
     a.n_nseg = c.n_nseg;
     a.accumulate = c.accumulate;
     a.gateG = c.gateG; a.ldg = c.ldg; a.gateT = c.gateT; a.ldt = c.ldt;
+    a.postY = c.postY; a.ldy = c.ldy; a.postKeep = c.postKeep; a.postF = c.postF; a.postScale = c.postScale;
     float* w = (float*)ws;
     const int nks = kp / 16;
     for (int q = 0; q < 2; ++q) {
@@ -1159,6 +1207,24 @@ size_t transA_ws_bytes(int64_t M, int64_t maxN, int n_nseg, int64_t K) {
     if (bm == 128 && bn == 160) return splitk_ws_bytes<128, 160>(M, maxN, n_nseg, K);
     if (bm == 160 && bn == 128) return splitk_ws_bytes<160, 128>(M, maxN, n_nseg, K);
     return splitk_ws_bytes<160, 160>(M, maxN, n_nseg, K);
+}
+
+// C = C * (keep * scale) * (1 - Y^2) in place (shapes the whole-rows kernel does not take: the post-operation on its own)
+__global__ __launch_bounds__(TPB) void tanh_bwd_post_kernel(int64_t n, int F, int F4, float* __restrict__ C, int64_t ldc,
+                                                            const float* __restrict__ Y, int64_t ldy, const uint8_t* __restrict__ keep,
+                                                            int64_t keepF, float scale) {
+    const int64_t total = n * F4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+        const int64_t row = e / F4;
+        const int c0 = (int)(e - row * F4) * 4;
+        float4 v = *reinterpret_cast<float4*>(C + row * ldc + c0);
+        const float4 y = *reinterpret_cast<const float4*>(Y + row * ldy + c0);
+        float* vv = reinterpret_cast<float*>(&v);
+        const float* yy = reinterpret_cast<const float*>(&y);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv[i] = (c0 + i < F) ? masked_tanh_bwd(vv[i], (float)keep[row * keepF + c0 + i], scale, yy[i]) : 0.f;
+        *reinterpret_cast<float4*>(C + row * ldc + c0) = v;
+    }
 }
 
 bool ld_ok(const void* p, int64_t ld) { return ld % 4 == 0 && aligned16(p); }
@@ -1403,11 +1469,40 @@ int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const
     return run_call(false, transB != 0, c, ws, ws_bytes, st);
 }
 
+static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                           const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                           float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, const float* Y, int64_t ldy,
+                           const uint8_t* keep, int64_t keepF, float scale, void* ws, size_t ws_bytes, void* stream);
+
 int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                                const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                                float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, void* ws,
                                size_t ws_bytes, void* stream) {
-    const char* fn = "gemm_kcat_gated_f32";
+    return kcat_gated_impl("gemm_kcat_gated_f32", transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, G, ldg, T, ldt,
+                           nullptr, 0, nullptr, 0, 0.f, ws, ws_bytes, stream);
+}
+
+int geogcn_gemm_kcat_gated_tanhbwd_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                                       const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                                       float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
+                                       const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    const char* fn = "gemm_kcat_gated_tanhbwd_f32";
+    GEOGCN_REQUIRE(M >= 0 && N >= 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    if (M > 0 && N > 0) {
+        GEOGCN_REQUIRE(Y && keep, GEOGCN_E_NULL, "%s: null pointer", fn);
+        GEOGCN_REQUIRE(ld_ok(Y, ldy) && ldy >= ((N + 3) & ~(int64_t)3) && keepF >= N && keepF % 4 == 0 && (uintptr_t)keep % 4 == 0,
+                       GEOGCN_E_ALIGN, "%s: Y needs a 16-byte aligned base and ld %% 4 == 0, the keep mask a pitch %% 4 == 0 >= N", fn);
+        GEOGCN_REQUIRE((const float*)C != Y, GEOGCN_E_ARG, "%s: C must not alias Y", fn);
+    }
+    return kcat_gated_impl(fn, transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, G, ldg, T, ldt, Y, ldy, keep, keepF,
+                           scale, ws, ws_bytes, stream);
+}
+
+static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                           const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                           float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, const float* Y, int64_t ldy,
+                           const uint8_t* keep, int64_t keepF, float scale, void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C && G && T, GEOGCN_E_NULL, "%s: null pointer", fn);
@@ -1428,12 +1523,20 @@ int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0,
     if (const int kp = rows_kp(c, false, transB != 0); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp)) {
         c.accumulate = 0;
         c.gateG = G; c.ldg = ldg; c.gateT = T; c.ldt = ldt;
+        c.postY = Y; c.ldy = ldy; c.postKeep = keep; c.postF = keepF; c.postScale = scale;
         return run_rows(kp, transB != 0, c, ws, st);
     }
     // any other shape: the carry written first, the two products accumulated onto it (the same values in the same order)
     if (const int rc = geogcn_gate_carry_f32(M, (int32_t)N, G, ldg, T, ldt, C, ldc, stream)) return rc;
     c.accumulate = 1;
-    return run_call(false, transB != 0, c, ws, ws_bytes, st);
+    if (const int rc = run_call(false, transB != 0, c, ws, ws_bytes, st)) return rc;
+    if (Y) {
+        const int F4 = (int)((N + 3) / 4);
+        const int64_t blocks = std::min<int64_t>(cdiv(M * F4, TPB), (int64_t)kNumCU * 16);
+        hipLaunchKernelGGL(tanh_bwd_post_kernel, dim3((unsigned)blocks), dim3(TPB), 0, st, M, (int)N, F4, C, ldc, Y, ldy, keep, keepF, scale);
+        GEOGCN_LAUNCH_CHECK("tanh_bwd_post_kernel");
+    }
+    return 0;
 }
 
 }  // extern "C"

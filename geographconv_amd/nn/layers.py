@@ -374,6 +374,25 @@ class DenseLayer(Layer):
                 return y
         return K.spmm_x(input, self.W.data, bias=bias, act=act)
 
+    def _tanh_layer_below(self, tape, kwargs):
+        """(layer, its output Y, the dropout's keep mask, 1 / (1 - p)) when this gate's input is the dropped output of a tanh layer
+        with a bias fed by the sparse input, and nothing but this highway block reads it (tuning.FUSE_ACT_BWD): the block's input
+        gradient can then leave the product's epilogue as that layer's pre-activation gradient."""
+        K = backend.active()
+        d = self.input_layer
+        if not tuning.FUSE_ACT_BWD or not isinstance(d, DropoutLayer) or tape is None:
+            return None
+        below = d.input_layer
+        keep = tape.get(d, {}).get('mask')
+        if (keep is None or not isinstance(below, DenseLayer) or below.nonlinearity is not _nl.tanh or below.b is None
+                or kwargs.get('consumers', {}).get(d) != 3 or kwargs.get('consumers', {}).get(below) != 1
+                or isinstance(tape.get(below, {}).get('x'), K.DMat)):
+            return None
+        y0 = tape[below]['y']
+        if not isinstance(y0, K.DMat) or y0.F % 4 or tuple(keep.shape) != (y0.n, y0.F) or not K.kcat_gated_native(y0.n, y0.F):
+            return None
+        return below, y0, keep, 1.0 / (1.0 - d.p)
+
     def _fusable_sibling(self, input, tape, kwargs, bf16=False):
         """The highway block's conv branch, when its H.W can ride in this gate's launch: one GPU, exact-fp32 products (or, `bf16`,
         the bf16 configuration with its bf16 SpMM operand), a graph convolution (whose Z stays linear) with a plain dense product,
@@ -515,6 +534,15 @@ class DenseLayer(Layer):
                     return [None]
                 # dH = dZ.Wh^T + dU.Wt^T [+ the carry gradient]: one accumulator, one pass over dH
                 if lazy is not None:          # ... the carry formed in the epilogue from the block's output gradient and its gate
+                    post = self._tanh_layer_below(tape, kwargs)
+                    if post is not None:
+                        # ... and, under the FIRST block, the dropout + tanh gradient of the layer below in the same epilogue: what
+                        # comes out is dS0, that layer's pre-activation gradient (its bias gradient: the column sums)
+                        below, y0, keep, scale = post
+                        dS0 = K.DMat.empty(y0.n, y0.F, y0.device, ld=K.gather_ld(y0.F))
+                        K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=dS0, transB=True, gate_carry=lazy, tanh_bwd=(y0, keep, scale))
+                        K.colsum_rowblocks(dS0, out=below.b.grad)
+                        return [PreAct(dS0, bias_done=True)]
                     return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, transB=True, gate_carry=lazy)]
                 return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
                                     accumulate=into[0] is not None)]
@@ -610,6 +638,11 @@ class DropoutLayer(Layer):
         K = backend.active()
         mask = tape[self]['mask']
         below = self.input_layer
+        if isinstance(grad, PreAct):
+            # the consumer's product already applied this layer's mask and the tanh gradient of the layer below in its epilogue
+            # (DenseLayer._tanh_layer_below): what comes through is that layer's pre-activation gradient
+            assert into[0] is None
+            return [grad]
         if (mask is not None and into[0] is None and isinstance(below, DenseLayer) and not isinstance(grad, (PreAct, Masked))
                 and below.nonlinearity.act not in (None, 0) and below.nonlinearity.fusable):
             # the layer below applies mask and 1/(1-p) inside its activation-gradient kernel
@@ -755,6 +788,14 @@ def backward(layer, grad, tape, **kwargs):
     gradient at `layer`'s output (or a PreAct token); parameter gradients land in Param.grad."""
     all_layers = get_all_layers(layer)
     grads = {layer: grad}
+    # how many inputs of other layers each layer's output is (a fusion that hands a finished gradient through a layer needs to know
+    # that nobody else will add to it)
+    consumers = {}
+    for l in all_layers:
+        for i in (l.input_layers if hasattr(l, 'input_layers') else [getattr(l, 'input_layer', None)]):
+            if i is not None:
+                consumers[i] = consumers.get(i, 0) + 1
+    kwargs = dict(kwargs, consumers=consumers)
     # which layers lie on a path from a parameterised/needed layer: all of them need grads except
     # pure inputs
     def dense(g):

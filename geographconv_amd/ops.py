@@ -510,14 +510,19 @@ def gemm_dual_bf16(A: DMat, B0: DMat, B1: DMat, out0=None, out1: DMat = None, bi
 
 
 @_timed('gemm_kcat')
-def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, gate_carry: GateCarry = None):
+def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, gate_carry: GateCarry = None,
+              tanh_bwd=None):
     """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
-    dH = dZ . Wh^T + dU . Wt^T of the highway block.  `gate_carry`: ... + G * (1 - T) formed in the epilogue (then no accumulate)."""
+    dH = dZ . Wh^T + dU . Wt^T of the highway block.  `gate_carry`: ... + G * (1 - T) formed in the epilogue (then no accumulate).
+    `tanh_bwd` = (Y, keep_mask, scale), with a gate carry only: the result times keep * scale * (1 - Y^2) -- the dropout + tanh gradient
+    of the layer below the first block in the same epilogue (geogcn_gemm_kcat_gated_tanhbwd_f32)."""
     N = B0.n if transB else B0.F
     if (B1.n if transB else B1.F) != N or A0.n != A1.n or (B0.F if transB else B0.n) != A0.F or (B1.F if transB else B1.n) != A1.F:
         raise ValueError("gemm_kcat: shapes do not match")
     if gate_carry is not None and accumulate:
         raise ValueError("gemm_kcat: a gate carry and accumulate exclude each other")
+    if tanh_bwd is not None and gate_carry is None:
+        raise ValueError("gemm_kcat: tanh_bwd comes with a gate carry")
     if out is None:
         if accumulate:
             raise ValueError("gemm_kcat: accumulate needs an existing output")
@@ -531,6 +536,15 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
         g, t = gate_carry.G, gate_carry.T
         if g.n != A0.n or g.F != N or t.n != A0.n or t.F != N:
             raise ValueError("gemm_kcat: the gate carry's operands do not have the output's shape")
+        if tanh_bwd is not None:
+            Y, keep, scale = tanh_bwd
+            if Y.n != A0.n or Y.F != N or tuple(keep.shape) != (A0.n, N) or keep.dtype != torch.uint8 or not keep.is_contiguous() or N % 4:
+                raise ValueError("gemm_kcat: tanh_bwd needs Y and a contiguous uint8 keep mask of the output's shape, width % 4 == 0")
+            check(lib.geogcn_gemm_kcat_gated_tanhbwd_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
+                                                         _p(B1.t), B1.ld, _p(out.t), out.ld, _p(g.t), g.ld, _p(t.t), t.ld, _p(Y.t), Y.ld,
+                                                         _p(keep), N, float(scale), _p(w), w.numel(), _stream()),
+                  'gemm_kcat_gated_tanhbwd_f32')
+            return out
         check(lib.geogcn_gemm_kcat_gated_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
                                              _p(B1.t), B1.ld, _p(out.t), out.ld, _p(g.t), g.ld, _p(t.t), t.ld, _p(w), w.numel(),
                                              _stream()), 'gemm_kcat_gated_f32')
@@ -621,6 +635,15 @@ def _ws_for(dev):
     if ws is None:
         ws = _misc_ws[dev] = Workspace(dev)
     return ws
+
+
+def colsum_rowblocks(X: DMat, out: torch.Tensor):
+    """Column sums in the order of the fused activation-gradient kernels (geogcn_colsum_rowblocks_f32): a bias gradient taken from
+    a dS that a product's epilogue wrote equals, bit for bit, the one act_bwd_colsum would have produced."""
+    lib = _ffi.lib()
+    w = _ws_for(X.device).get(max(lib.geogcn_highway_bwd_workspace_bytes(X.n, X.F), lib.geogcn_colsum_workspace_bytes(X.n, X.F)))
+    check(lib.geogcn_colsum_rowblocks_f32(X.n, X.F, _p(X.t), X.ld, _p(out), _p(w), w.numel(), _stream()), 'colsum_rowblocks_f32')
+    return out
 
 
 def colsum(X: DMat, out: torch.Tensor = None):

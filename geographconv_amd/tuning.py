@@ -41,6 +41,10 @@ FUSE_HIGHWAY = 'all'
 # of written by highway_bwd and read back: 0.53 GB less written per 300-wide block at the TwitterUS size; same bits
 FUSE_GATE_CARRY = True
 
+# ... and under the FIRST block the dropout + tanh gradient of the sparse-input layer in the same epilogue
+# (geogcn_gemm_kcat_gated_tanhbwd_f32): the act_bwd pass over dH disappears, its bias gradient becomes a column sum of dS0; same bits
+FUSE_ACT_BWD = True
+
 # bf16 configuration, one GPU: the highway block's H . Wh (bf16 result, the SpMM's operand) and sigmoid(H . Wt + bt) in one launch of
 # the bf16 whole-rows kernel -- H read and rounded once (geogcn_gemm_dual_bf16); same bits as the two launches
 FUSE_BF16_DUAL = True

@@ -259,6 +259,16 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
  * takes dHcarry = NULL and neither writes nor re-reads 4 M N bytes.  Bit-identical to geogcn_highway_bwd_f32 (with dHcarry) followed
  * by geogcn_gemm_kcat_f32(accumulate = 1).  Shapes the whole-rows kernel does not take (or ws too small) run as
  * geogcn_gate_carry_f32 into C + the accumulating call.  C must not alias G or T.                                            */
+/* ... and, for the FIRST highway block, with the gradient of the layer below folded in as well:
+ *   C = (A0 . op(B0) + A1 . op(B1) + G * (1 - T)) * (keep * scale) * (1 - Y^2)
+ * i.e. dS0, the gradient at the pre-activation of the tanh layer whose dropped output feeds the block (gcnmodel.py:353,357:
+ * dropout mask `keep` (bytes, pitch keepF, a multiple of 4) and 1/(1-p) = scale, Y = that layer's output) -- the pass
+ * geogcn_act_bwd_f32 would make over dH.  Same bits as that pass (tested); the bias gradient is geogcn_colsum_f32 of C.          */
+int geogcn_gemm_kcat_gated_tanhbwd_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
+                                       const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
+                                       float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
+                                       const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, void* ws,
+                                       size_t ws_bytes, void* stream);
 /* ... and for ONE product: C[M x N] = A . op(B) + G * (1 - T) in any `precision` (the bf16 configuration forms dH_in with two
  * calls: this one, then an accumulating geogcn_gemm_f32).  ws as for geogcn_gemm_f32 (geogcn_gemm_workspace_bytes).             */
 int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
@@ -285,6 +295,11 @@ int geogcn_highway_bwd_f32(int64_t n, int32_t F, const float* G, const float* T,
                            float* dbS /* nullable: column sums of dS = grad of the conv bias */,
                            float* dbU /* nullable: column sums of dU = grad of the gate bias */,
                            void* ws, size_t ws_bytes, void* stream);
+/* column sums of X (n x F) taken in the order of the fused activation-gradient kernels (row blocks of
+ * geogcn_highway_bwd_workspace_bytes' partition): the bias gradient of a dS that a product's epilogue wrote, with the bits
+ * geogcn_act_bwd_colsum_f32 would have given it.  ws: geogcn_highway_bwd_workspace_bytes(n, F).                       */
+int geogcn_colsum_rowblocks_f32(int64_t n, int32_t F, const float* X, int64_t ldx, float* out, void* ws, size_t ws_bytes,
+                                void* stream);
 /* out = G * (1 - T): the carry gradient alone (the arithmetic of dHcarry above)                 */
 int geogcn_gate_carry_f32(int64_t n, int32_t F, const float* G, int64_t ldg, const float* T, int64_t ldt, float* out,
                           int64_t ldo, void* stream);

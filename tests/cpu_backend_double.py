@@ -139,7 +139,12 @@ def kcat_gated_native(n, F):
     return True              # (the double takes the gated form at every size: the host logic is what it exercises)
 
 
-def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, gate_carry=None):
+def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, gate_carry=None, tanh_bwd=None):
+    if tanh_bwd is not None:
+        Y, keep, scale = tanh_bwd
+        tmp = gemm_kcat(A0, B0, A1, B1, transB=transB, gate_carry=gate_carry)
+        _v(out)[...] = _v(tmp) * (keep.numpy().astype(np.float32) * np.float32(scale)) * (1 - _v(Y) * _v(Y))
+        return out
     if gate_carry is not None:
         assert not accumulate
         c = gate_carry.dense()
@@ -206,6 +211,10 @@ def act_bwd(G, Y, act, out=None, keep_mask=None, scale=1.0):
 def add_inplace(X, Y):
     Y.t += X.t
     return Y
+
+
+def colsum_rowblocks(X, out):
+    return colsum(X, out=out)
 
 
 def colsum(X, out=None):

@@ -470,6 +470,51 @@ def test_carry_gradient_in_the_epilogue_of_the_gates_backward_product(monkeypatc
         assert all(np.array_equal(a, b) for a, b in zip(prm, ref[2])), graph
 
 
+def test_first_layers_gradient_in_the_epilogue_of_the_first_blocks_product(cmu, monkeypatch):
+    """tuning.FUSE_ACT_BWD: under the first highway block the product that forms dH_in also applies the dropout mask and the tanh
+    gradient of the sparse-input layer (geogcn_gemm_kcat_gated_tanhbwd_f32), so that layer's pre-activation gradient leaves the
+    epilogue and the act_bwd pass is gone: three steps of a 40,000-node model (whole-rows kernel) and of the CMU model (carry +
+    accumulate + post pass inside the call) are bitwise the runs with the separate pass, eager and captured."""
+    from geographconv_amd import ops, tuning
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    calls = []
+    orig = ops.gemm_kcat
+    monkeypatch.setattr(ops, 'gemm_kcat', lambda *a, **k: (calls.append(k.get('tanh_bwd') is not None), orig(*a, **k))[1])
+    N, C = 40000, 12
+    A, X, Y = synth.small_graph(N, 6.0, 1500, 10, C, seed=21)
+    hid = [300, 300, 300]
+    params = O.random_params(X.shape[1], hid, C, True, seed=4)
+    tr, dev_idx = np.arange(0, 30000, dtype=np.int32), np.arange(30000, 36000, dtype=np.int32)
+    c = cmu
+    for name in ('40k', 'cmu'):
+        if name == 'cmu':
+            monkeypatch.setattr(ops, 'kcat_gated_native', lambda n, F: True)
+        runs = {}
+        for fused in (True, False):
+            for graph in (False, True):
+                monkeypatch.setattr(tuning, 'FUSE_ACT_BWD', fused)
+                del calls[:]
+                if name == '40k':
+                    clf = GraphConv(X.shape[1], C, hid, 0.0, 0.5, highway=True, hip_graph=graph)
+                    clf.build_model(A, seed=77)
+                    L.set_all_param_values(clf.l_out, params)
+                    step = lambda: clf.f_train(X, Y[tr], Y[dev_idx], A, tr, dev_idx)
+                else:
+                    clf = _clf(c, hip_graph=graph)
+                    step = lambda: clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+                hist = []
+                for _ in range(3):
+                    out = step()
+                    hist.append([float(v) for v in out[:4]])
+                runs[(fused, graph)] = (hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out))
+                assert any(calls) == fused, (name, fused, graph, calls)
+        for graph in (False, True):
+            (hist, P, prm), ref = runs[(True, graph)], runs[(False, graph)]
+            assert hist == ref[0] and np.array_equal(P, ref[1]), (name, graph)
+            assert all(np.array_equal(a, b) for a, b in zip(prm, ref[2])), (name, graph)
+
+
 def test_carry_gradient_handed_down_at_sizes_the_whole_rows_kernel_does_not_take(cmu, monkeypatch):
     """The same switch forced on at the CMU size (9,475 nodes: geogcn_gemm_kcat_gated_f32 writes the carry with
     geogcn_gate_carry_f32 and accumulates onto it): losses, probabilities and gradients bitwise those of the stored carry."""

@@ -630,6 +630,21 @@ def test_gemm_kcat_with_the_carry_gradient_in_its_epilogue_bitwise(dev, M, F, pi
         assert torch.equal(wide.t[:, :F], want.t[:, :F]) and torch.all(wide.t[:, ops.gather_ld(F):] == 7.0)
     with pytest.raises(ValueError):
         ops.gemm_kcat(dZ, Wh, dU, Wt, out=want, transB=True, accumulate=True, gate_carry=ops.GateCarry(G, T))
+    # ... and with the dropout + tanh gradient of the layer below in the same epilogue (geogcn_gemm_kcat_gated_tanhbwd_f32), against
+    # the gated product followed by geogcn_act_bwd_f32 with the mask; the bias gradient: the column sums, against the fused pass
+    if F % 4 == 0:
+        Y0 = ops.DMat.from_numpy(np.tanh(_rand((M, F), 21)), dev)
+        keep = torch.from_numpy((np.random.RandomState(22).rand(M, F) < 0.5).astype(np.uint8)).to(dev)
+        for transB in (True, False):
+            Wh, Wt = ops.DMat.from_numpy(_rand((F, F), 6, 0.1), dev), ops.DMat.from_numpy(_rand((F, F), 7, 0.1), dev)
+            dH = ops.gemm_kcat(dZ, Wh, dU, Wt, transB=transB, gate_carry=ops.GateCarry(G, T))
+            db_ref = torch.zeros(ops.pad4(F), device=dev)
+            want = ops.act_bwd_colsum(dH, Y0, ops.ACT_TANH, db_ref, out=ops.DMat.empty(M, F, dev, ld=ops.gather_ld(F)), keep_mask=keep, scale=2.0)
+            got = ops.DMat.empty(M, F, dev, ld=ops.gather_ld(F))
+            got.t.fill_(7.0)
+            ops.gemm_kcat(dZ, Wh, dU, Wt, out=got, transB=transB, gate_carry=ops.GateCarry(G, T), tanh_bwd=(Y0, keep, 2.0))
+            assert torch.equal(got.t[:, :ops.pad4(F)], want.t[:, :ops.pad4(F)]), transB
+            assert torch.equal(ops.colsum_rowblocks(got, torch.zeros(ops.pad4(F), device=dev)), db_ref)
     # ONE product with the carry in its epilogue (geogcn_gemm_gated_f32: the bf16 configuration's first of two launches; exact
     # fp32 and bf16x3 as well), against the stored carry + the accumulating call of the same precision
     for prec in ('bf16', 'f32', 'bf16x3'):
