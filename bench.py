@@ -261,7 +261,9 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     if _tuning.FUSE_GATE_CARRY:
         mfma("dH = dZ . Wh^T + dU . Wt^T + G (1 - T)  (gemm_rows_kernel, two A operands into one accumulator, the block's carry "
              "gradient formed in the epilogue)", 'gemm_kcat', 2 * fl, 5 * act + 2 * wb, 'f32',
-             "operand bytes: dZ, dU, G, T read, dH written (highway_bwd does not store the carry)")
+             "operand bytes: dZ, dU, G, T read, dH written (highway_bwd does not store the carry); the median is over both blocks' calls"
+             + ("; the first block's also applies the dropout mask and the tanh gradient of the sparse-input layer (reads H0 and the mask)"
+                if _tuning.FUSE_ACT_BWD else ""))
     else:
         mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl,
              4 * act + 2 * wb, 'f32', "operand bytes: dZ, dU read, the carry read and dH written")
