@@ -30,7 +30,10 @@ extern "C" {
 
 /* 2: round 3 changed exported signatures incompatibly (geogcn_spmm_plan_create: chunks_with_owner instead of a rowsplit pointer;
  * geogcn_gemm_kcat_f32: ws / ws_bytes before stream; geogcn_spmm_plan_attach_timer replaced geogcn_timer_attach_spmm);
- * round 4: geogcn_spmm_csr_hot_f32 / _hot_dropout_f32 take n_cols after n_rows and row_order after n_hot. */
+ * round 4: geogcn_spmm_csr_hot_f32 / _hot_dropout_f32 take n_cols after n_rows and row_order after n_hot.
+ * Added since without a version change (nothing existing changed meaning): geogcn_gemm_kcat_gated_f32, geogcn_gemm_gated_f32,
+ * geogcn_gemm_kcat_gated_tanhbwd_f32, geogcn_gemm_dual_bf16 (+ _workspace_bytes), geogcn_gate_carry_f32, geogcn_colsum_rowblocks_f32;
+ * geogcn_highway_bwd_f32 / _bf16s_f32 accept dHcarry = NULL. */
 #define GEOGCN_ABI_VERSION 2
 
 #define GEOGCN_E_NULL   (-1)   /* required pointer is NULL            */
