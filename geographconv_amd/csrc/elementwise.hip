@@ -271,7 +271,18 @@ __global__ __launch_bounds__(TPB) void colsum_rowblocks_kernel(int64_t n, int F,
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ri < rpi) {
-        for (int64_t row = r0 + ri; row < r1; row += rpi) {
+        // four rows per trip: four loads in flight per thread, added in row order (the order of the fused kernels)
+        int64_t row = r0 + ri;
+        for (; row + 3 * (int64_t)rpi < r1; row += 4 * (int64_t)rpi) {
+            const float4 x0 = X[row * ldx4 + q], x1 = X[(row + rpi) * ldx4 + q];
+            const float4 x2 = X[(row + 2 * (int64_t)rpi) * ldx4 + q], x3 = X[(row + 3 * (int64_t)rpi) * ldx4 + q];
+            const float4 s0 = mask_pad(x0, q * 4, F), s1 = mask_pad(x1, q * 4, F), s2 = mask_pad(x2, q * 4, F), s3 = mask_pad(x3, q * 4, F);
+            a.x += s0.x; a.y += s0.y; a.z += s0.z; a.w += s0.w;
+            a.x += s1.x; a.y += s1.y; a.z += s1.z; a.w += s1.w;
+            a.x += s2.x; a.y += s2.y; a.z += s2.z; a.w += s2.w;
+            a.x += s3.x; a.y += s3.y; a.z += s3.z; a.w += s3.w;
+        }
+        for (; row < r1; row += rpi) {
             const float4 s = mask_pad(X[row * ldx4 + q], q * 4, F);
             a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
         }
