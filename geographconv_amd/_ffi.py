@@ -29,6 +29,8 @@ SIGNATURES = {
     'geogcn_spmm_workspace_bytes': (c_sz, [c_ptr, c_i32]),
     'geogcn_spmm_csr_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                     c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_spmm_csr_softmax_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                            c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
     'geogcn_spmm_csr_acc_f32': (c_i32, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                         c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_spmm_hot_capacity': (c_i32, [c_i32]),

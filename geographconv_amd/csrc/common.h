@@ -120,6 +120,9 @@ int zero_rows_async(float* ptr, int64_t rows, int64_t cols, int64_t ld, hipStrea
 // elementwise.hip: out[col] = sum over parts of P[part * stride + col], fixed tree (deterministic)
 int colsum_final_launch(int nparts, int F, const float* P, int64_t stride, float* out, hipStream_t st);
 
+// softmax_adam.hip: softmax of the listed rows of P, IN PLACE (P holds their logits), + the first index of each row's maximum
+int softmax_rows_indexed_launch(const int* rows_dev, int n_list, int C, float* P, int64_t ldp, int* amax, hipStream_t st);
+
 // gemm.hip: C = act(sum_z W[z] + bias) [+ C], slabs added in index order
 int splitk_reduce_launch(int64_t M, int64_t N, int nsplit, const float* W, int64_t ldw, float* C, int64_t ldc,
                          const float* bias, int act, int accumulate, hipStream_t st);

@@ -55,12 +55,14 @@ __global__ __launch_bounds__(TPB) void softmax_rows_kernel(int64_t n, int C, con
 
 // C <= 64 * KREG: the row lives in registers -- one read of the logits, one exp per element, one write.
 template <int KREG>
-__global__ __launch_bounds__(TPB) void softmax_rows_reg_kernel(int64_t n, int C, const float* __restrict__ L, int64_t ldl,
-                                                               float* __restrict__ P, int64_t ldp, int ldp_pad,
-                                                               int* __restrict__ amax) {
-    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+__global__ __launch_bounds__(TPB) void softmax_rows_reg_kernel(int64_t n, int C, const float* L, int64_t ldl,
+                                                               float* P, int64_t ldp, int ldp_pad,
+                                                               int* __restrict__ amax, const int* __restrict__ rowlist = nullptr) {
+    // (rowlist: the n listed rows instead of rows 0 .. n-1 -- then L may be P: a row is read completely before it is written)
+    const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
     const int lane = threadIdx.x % kWave;
-    if (row >= n) return;
+    if (slot >= n) return;
+    const int64_t row = rowlist ? rowlist[slot] : slot;
     const float* x = L + row * ldl;
     float v[KREG];
     float m = -INFINITY;
@@ -344,6 +346,19 @@ __global__ void scalar_final_kernel(int nparts, const float* __restrict__ part, 
 constexpr int kRegParts = 256;
 
 }  // namespace
+
+int softmax_rows_indexed_launch(const int* rows_dev, int n_list, int C, float* P, int64_t ldp, int* amax, hipStream_t st) {
+    if (n_list <= 0 || C <= 0) return 0;
+    const int ldp_pad = (int)std::min<int64_t>(ldp, (int64_t)((C + 3) / 4) * 4);
+    GEOGCN_REQUIRE(ldp_pad <= 64 * 16, GEOGCN_E_ARG, "softmax of listed rows: C=%d > 1024", C);
+    const dim3 grid((unsigned)cdiv(n_list, kWavesPerBlock));
+    if (ldp_pad <= 64 * 4)
+        hipLaunchKernelGGL((softmax_rows_reg_kernel<4>), grid, dim3(TPB), 0, st, (int64_t)n_list, C, (const float*)P, ldp, P, ldp, ldp_pad, amax, rows_dev);
+    else
+        hipLaunchKernelGGL((softmax_rows_reg_kernel<16>), grid, dim3(TPB), 0, st, (int64_t)n_list, C, (const float*)P, ldp, P, ldp, ldp_pad, amax, rows_dev);
+    GEOGCN_LAUNCH_CHECK("softmax_rows_reg_kernel (listed rows)");
+    return 0;
+}
 }  // namespace geogcn
 
 using namespace geogcn;

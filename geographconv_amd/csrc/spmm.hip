@@ -200,6 +200,8 @@ struct HwArgs {
     int64_t ld;          // common pitch of T, H, Hout
     const float* init;   // nullable: the accumulators start from init[row][:] (pitch ld_init) instead of zero --
     int64_t ld_init;     // C = act(C0 + A.B + bias): a product that continues one already in C (X.W0: dense head + tail)
+    int* amax = nullptr; // softmax epilogue (HW = 2, geogcn_spmm_csr_softmax_f32): C receives softmax(A.B + bias) row by row, amax
+    int softmax = 0;     // (nullable) the first index of each row's maximum
 };
 __device__ __forceinline__ float4 highway_mix(const float4 t, const float4 hc, const float4 h) {
     return make_float4(t.x * hc.x + (1.0f - t.x) * h.x, t.y * hc.y + (1.0f - t.y) * h.y,
@@ -278,13 +280,60 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     }
     group_accumulate<K4, G, BF>(s, e, lane16, nF4, colidx, val, B, ldb, acc);
     float4* out = reinterpret_cast<float4*>(C + (int64_t)row * ldc);
+    if constexpr (HW == 2) {
+        // softmax of the row in the epilogue (the output layer: gcnmodel.py:149 + nonlinearity softmax): the row lives in the
+        // G lanes of its group, 4 K4 values each -- maximum and first index attaining it, exp(x - max), sum, quotient: the
+        // arithmetic of softmax_rows_reg_kernel (softmax_adam.hip) with the sum taken over this layout's partial sums
+        float v[K4][4];
+        float m = -INFINITY;
+        int mi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int q = f4_index<G, BF>(lane16, k);
+            const float a4[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = q * 4 + i;
+                float x = -INFINITY;
+                if (q < nF4 && col < F) {
+                    x = a4[i];
+                    if (bias) x += bias[col];
+                }
+                v[k][i] = x;
+                if (x > m) { m = x; mi = col; }          // ascending columns within a lane: strict > keeps the first index
+            }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, G);
+            const int oi = __shfl_xor(mi, o, G);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        float ssum = 0.f;
+#pragma unroll
+        for (int k = 0; k < K4; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[k][i] = (v[k][i] == -INFINITY) ? 0.f : expf(v[k][i] - m);
+                ssum += v[k][i];
+            }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, G);
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int q = f4_index<G, BF>(lane16, k);
+            if (q < nF4) out[q] = make_float4(v[k][0] / ssum, v[k][1] / ssum, v[k][2] / ssum, v[k][3] / ssum);
+        }
+        if (hw.amax && lane16 == 0) hw.amax[row] = mi;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K4; ++k) {
         const int q = f4_index<G, BF>(lane16, k);
         if (q < nF4) {
             const float4 hc = epilogue4<ACT>(acc[k], q * 4, F, bias);
             out[q] = hc;
-            if constexpr (HW) {
+            if constexpr (HW == 1) {
                 const float4 t = reinterpret_cast<const float4*>(hw.T + (int64_t)row * hw.ld)[q];
                 const float4 h = reinterpret_cast<const float4*>(hw.H + (int64_t)row * hw.ld)[q];
                 reinterpret_cast<float4*>(hw.Hout + (int64_t)row * hw.ld)[q] = highway_mix(t, hc, h);
@@ -431,7 +480,10 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
                        colidx, val, B, ldb, C, ldc, F, bias, long_nnz, sched, n_chunks,          \
                        n_chunks ? plan->d_chunk_start : nullptr, n_chunks ? plan->d_chunk_end : nullptr, ws, ldp, hw, per_xcd, xr)
     if (n_rows > 0) {
-        if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 1); }        // highway epilogue: tanh branch only (checked by the caller)
+        if (hw.softmax) {
+            if constexpr (BF == 0 && G == kGroup && K4 <= 8) { GEOGCN_ROWS__(GEOGCN_ACT_NONE, 2); }      // (checked by the caller)
+        }
+        else if (hw.T) { GEOGCN_ROWS__(GEOGCN_ACT_TANH, 1); }        // highway epilogue: tanh branch only (checked by the caller)
         else if (act == GEOGCN_ACT_TANH) { GEOGCN_ROWS(GEOGCN_ACT_TANH); }
         else if (act == GEOGCN_ACT_SIGMOID) { GEOGCN_ROWS(GEOGCN_ACT_SIGMOID); }
         else { GEOGCN_ROWS(GEOGCN_ACT_NONE); }
@@ -453,6 +505,9 @@ int launch_k4(const geogcn_spmm_plan* plan, int n_rows, const int* rowptr, const
 #undef GEOGCN_RED
 #undef GEOGCN_RED_
         GEOGCN_LAUNCH_CHECK("spmm_long_reduce_kernel");
+        // softmax epilogue: the long rows' logits (bias added by the combine) sit in C; their softmax in place, row by row
+        if (hw.softmax)
+            if (const int rc = softmax_rows_indexed_launch(plan->d_long_rows, plan->n_long, F, C, ldc, hw.amax, st)) return rc;
     }
     if (timed) {        // the pair brackets the WHOLE product: row kernel + the long rows' ordered combine
         GEOGCN_HIP(hipEventRecord(tm->end[tm->used], st));
@@ -785,6 +840,25 @@ int geogcn_spmm_csr_highway_f32(const geogcn_spmm_plan* plan, int32_t n_rows, in
                                 bias, GEOGCN_ACT_TANH, ws, ws_bytes, stream, hw);
     return spmm_csr_impl<0>("spmm_csr_highway_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, Hc, ld, F,
                             bias, GEOGCN_ACT_TANH, ws, ws_bytes, stream, hw);
+}
+
+// P = softmax(A.B + bias) row by row [+ the first index of each row's maximum]: the output layer's product and its
+// nonlinearity in one launch -- the logits are never written
+int geogcn_spmm_csr_softmax_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                                const int32_t* rowptr, const int32_t* colidx, const float* val, const float* B, int64_t ldb,
+                                float* P, int64_t ldp, int32_t F, const float* bias, int32_t* argmax_out, void* ws,
+                                size_t ws_bytes, void* stream) {
+    const int F4 = (F + 3) / 4;
+    GEOGCN_REQUIRE(F >= 0 && (F == 0 || (F4 > 8 && F4 <= 8 * kGroup)), GEOGCN_E_ARG,
+                   "spmm_csr_softmax_f32: F=%d outside (32, %d] (narrower / wider outputs: geogcn_spmm_csr_f32 + geogcn_softmax_rows_f32)", F,
+                   32 * kGroup);
+    GEOGCN_REQUIRE(ldb % 4 == 0 && ldp % 4 == 0 && aligned16(B) && aligned16(P) && ldb >= (int64_t)F4 * 4 && ldp >= (int64_t)F4 * 4,
+                   GEOGCN_E_ALIGN, "spmm_csr_softmax_f32: needs 16-byte aligned B and P and pitches %% 4 == 0, >= roundup4(F)");
+    HwArgs hw{nullptr, nullptr, nullptr, 0, nullptr, 0};
+    hw.amax = argmax_out;
+    hw.softmax = 1;
+    return spmm_csr_impl<0>("spmm_csr_softmax_f32", plan, n_rows, n_cols, nnz, rowptr, colidx, val, B, ldb, P, ldp, F, bias,
+                            GEOGCN_ACT_NONE, ws, ws_bytes, stream, hw);
 }
 
 // C = act(C + A.B + bias): the accumulators start from the row already in C

@@ -334,6 +334,14 @@ class DenseLayer(Layer):
                     # highway block: the gating mix T*Hc + (1-T)*H rides in the SpMM's epilogue (the gate was
                     # evaluated just before this layer); MultiplicativeGatingLayer picks the result up
                     y, saved['highway_out'] = K.spmm_highway(A.fwd, zf, bias, T, input)
+                elif (self.nonlinearity is _nl.softmax and tuning.FUSE_SOFTMAX and not kwargs.get('keep_logits')
+                      and K.spmm_softmax_ok(zf, self.num_units)):
+                    # the output layer: softmax in the epilogue of its graph product; the logits are never written
+                    # (get_output(..., keep_logits=True) keeps the two passes and leaves them on the tape)
+                    import torch
+                    amax = torch.empty(A.fwd.shape[0], dtype=torch.int32, device=zf.device)
+                    y = K.spmm_softmax(A.fwd, zf, bias=bias, F=self.num_units, argmax=amax)
+                    saved['logits'], saved['argmax'], saved['softmax_done'] = None, amax, True
                 else:
                     y = K.spmm(A.fwd, zf, bias=bias, act=act, F=self.num_units)   # A_hat.(H.W) + b, act fused
             else:
@@ -341,7 +349,7 @@ class DenseLayer(Layer):
                 y = comm.graph_spmm_end(h)
         if self.nonlinearity.act is not None and not self.nonlinearity.fusable:
             y = K.bias_act(y, None, self.nonlinearity.act)       # relu / selu: bias was added in the epilogue
-        if self.nonlinearity is _nl.softmax:
+        if self.nonlinearity is _nl.softmax and not saved.get('softmax_done'):
             import torch
             amax = torch.empty(y.n, dtype=torch.int32, device=y.device)
             saved['logits'] = y

@@ -346,6 +346,27 @@ def spmm(A: CSR, B, out: DMat = None, bias: torch.Tensor = None, act=ACT_NONE, F
     return out
 
 
+def spmm_softmax_ok(B, F):
+    """Can softmax(A . B + bias) come out of the graph product's epilogue (geogcn_spmm_csr_softmax_f32)?  fp32 gathered operand,
+    32 < F <= 512."""
+    return isinstance(B, DMat) and 32 < int(F) <= 512
+
+
+@_timed('spmm_softmax')
+def spmm_softmax(A: CSR, B: DMat, bias: torch.Tensor = None, F=None, out: DMat = None, argmax: torch.Tensor = None):
+    """out = softmax(A . B + bias) row by row, `argmax` (int32, optional) = the first index of each row's maximum -- the output
+    layer's graph product with its nonlinearity in the epilogue; the logits are never written."""
+    lib = _ffi.lib()
+    F = B.F if F is None else F
+    if B.n != A.shape[1]:
+        raise ValueError("spmm_softmax: A is %s but B has %d rows" % (A.shape, B.n))
+    out = DMat.empty(A.shape[0], F, B.device) if out is None else out
+    ws = A._ws.get(lib.geogcn_spmm_workspace_bytes(A._plan, F))
+    check(lib.geogcn_spmm_csr_softmax_f32(A._plan, A.shape[0], A.shape[1], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.val), _p(B.t), B.ld,
+                                          _p(out.t), out.ld, F, _p(bias), _p(argmax), _p(ws), ws.numel(), _stream()), 'spmm_csr_softmax_f32')
+    return out
+
+
 @_timed('spmm_highway')
 def spmm_highway(A: CSR, B, bias: torch.Tensor, T: DMat, H: DMat, Hc: DMat = None, Hout: DMat = None):
     """(Hc, Hout) = (tanh(A . B + bias), T*Hc + (1-T)*H) in one launch -- the highway block's convolution with

@@ -45,6 +45,10 @@ FUSE_GATE_CARRY = True
 # (geogcn_gemm_kcat_gated_tanhbwd_f32): the act_bwd pass over dH disappears, its bias gradient becomes a column sum of dS0; same bits
 FUSE_ACT_BWD = True
 
+# the output layer's softmax in the epilogue of its graph product (geogcn_spmm_csr_softmax_f32): the logits are never written and
+# the softmax pass is gone; probabilities agree with the separate pass to rounding (the row sum is taken over another layout)
+FUSE_SOFTMAX = True
+
 # bf16 configuration, one GPU: the highway block's H . Wh (bf16 result, the SpMM's operand) and sigmoid(H . Wt + bt) in one launch of
 # the bf16 whole-rows kernel -- H read and rounded once (geogcn_gemm_dual_bf16); same bits as the two launches
 FUSE_BF16_DUAL = True

@@ -32,7 +32,8 @@ extern "C" {
  * geogcn_gemm_kcat_f32: ws / ws_bytes before stream; geogcn_spmm_plan_attach_timer replaced geogcn_timer_attach_spmm);
  * round 4: geogcn_spmm_csr_hot_f32 / _hot_dropout_f32 take n_cols after n_rows and row_order after n_hot.
  * Added since without a version change (nothing existing changed meaning): geogcn_gemm_kcat_gated_f32, geogcn_gemm_gated_f32,
- * geogcn_gemm_kcat_gated_tanhbwd_f32, geogcn_gemm_dual_bf16 (+ _workspace_bytes), geogcn_gate_carry_f32, geogcn_colsum_rowblocks_f32;
+ * geogcn_gemm_kcat_gated_tanhbwd_f32, geogcn_gemm_dual_bf16 (+ _workspace_bytes), geogcn_gate_carry_f32, geogcn_colsum_rowblocks_f32,
+ * geogcn_spmm_csr_softmax_f32;
  * geogcn_highway_bwd_f32 / _bf16s_f32 accept dHcarry = NULL. */
 #define GEOGCN_ABI_VERSION 2
 
@@ -75,6 +76,14 @@ int geogcn_spmm_csr_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_
                         const float* B, int64_t ldb, float* C, int64_t ldc, int32_t F,
                         const float* bias, int32_t act, void* ws, size_t ws_bytes, void* stream);
 
+/* P = softmax(A . B + bias) row by row, argmax_out (nullable) = the first index of each row's maximum: the output layer's graph
+ * product (gcnmodel.py:149) and its softmax nonlinearity in one launch -- the logits are never written.  32 < F <= 512; other widths:
+ * geogcn_spmm_csr_f32 + geogcn_softmax_rows_f32.  Same maximum, index and exponentials as that pair; the row sum is taken over this
+ * kernel's layout (the probabilities agree to rounding, not bit for bit).                                                    */
+int geogcn_spmm_csr_softmax_f32(const geogcn_spmm_plan* plan, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                                const int32_t* rowptr, const int32_t* colidx, const float* val, const float* B, int64_t ldb,
+                                float* P, int64_t ldp, int32_t F, const float* bias, int32_t* argmax_out, void* ws,
+                                size_t ws_bytes, void* stream);
 /* C = act(C + A_csr . B + bias): the accumulators start from the row already in C (a product that continues one begun
  * by another kernel -- X.W0 as dense head panel on the MFMA pipe + CSR tail, gcnmodel.py:39).  Same kernel, same order
  * (C's value first, then the stored nonzeros in index order).  Needs float4-addressable operands (GEOGCN_E_ALIGN).  */

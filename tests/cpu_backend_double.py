@@ -157,6 +157,10 @@ def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, gate_car
     return gemm(A1, B1, out=out, transB=transB, accumulate=True)
 
 
+def spmm_softmax_ok(B, F):
+    return False          # (the double keeps the two passes)
+
+
 def spmm_highway(A, B, bias, T, H, Hc=None, Hout=None):
     Hc = spmm(A, B, out=Hc, bias=bias, act=ACT_TANH, F=H.F)
     return Hc, highway_fwd(T, Hc, H, out=Hout)

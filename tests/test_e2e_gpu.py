@@ -51,7 +51,7 @@ def test_cmu_forward_logits_and_labels(cmu):
     from geographconv_amd.nn import layers as L
     g = clf._device_graph(c['X'], c['A'])
     tape = {}
-    L.get_output(clf.l_out, {clf.l_in: g['X']}, tape=tape, A=g['A'], deterministic=True)
+    L.get_output(clf.l_out, {clf.l_in: g['X']}, tape=tape, A=g['A'], deterministic=True, keep_logits=True)
     logits = tape[clf.l_out]['logits'].numpy()
     assert np.abs(logits - ref32['logits']).max() <= LOGIT_ATOL
     assert np.abs(logits - ref64['logits']).max() <= LOGIT_ATOL
@@ -562,6 +562,49 @@ def test_carry_gradient_in_the_epilogue_of_the_first_of_two_products(cmu, monkey
         assert (len(made) > 0, len(formed)) == ((True, 0) if fused else (False, 0)), (fused, len(made), len(formed))
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
     assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
+def test_output_layers_softmax_in_the_epilogue_of_its_graph_product(cmu, monkeypatch):
+    """tuning.FUSE_SOFTMAX: the output layer's probabilities come out of its graph product's epilogue.  A training step
+    against the oracle (losses, hit counts, probabilities, labels, gradients) exactly as the un-fused step is held to it,
+    three steps against the run with the separate softmax pass to rounding, and predictions."""
+    from geographconv_amd import ops, tuning
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    calls = []
+    orig = ops.spmm_softmax
+    monkeypatch.setattr(ops, 'spmm_softmax', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tuning, 'FUSE_SOFTMAX', fused)
+        del calls[:]
+        clf = _clf(c)
+        clf.inject_dropout_mask(c['mask'])
+        hist = []
+        for step in range(3):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+            if step == 0:
+                first = (out[:4], np.asarray(out[4]).copy(), clf.get_grads())
+        pred, probs = clf.predict(c['X'], c['A'], c['te'])
+        runs.append((hist, np.asarray(out[4]).copy(), L.get_all_param_values(clf.l_out), pred, probs, first))
+        assert (len(calls) > 0) == fused
+    a, b = runs
+    for ha, hb in zip(a[0], b[0]):
+        assert abs(ha[0] - hb[0]) <= 2e-6 * abs(hb[0]) and abs(ha[2] - hb[2]) <= 2e-6 * abs(hb[2]) and ha[1] == hb[1] and ha[3] == hb[3]
+    assert np.abs(a[1] - b[1]).max() <= 1e-6 and np.array_equal(a[3], b[3]) and np.abs(a[4] - b[4]).max() <= 1e-6
+    for p, q in zip(a[2], b[2]):
+        assert np.abs(p - q).max() <= 2e-3 * 0.02 + 1e-7
+    # the fused step against the oracle
+    st = O.AdamState(c['params'])
+    cur, ref, grads = O.f_train([p.copy() for p in c['params']], st, c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'],
+                                c['hid'], True, 0.5, c['mask'].astype(np.float32))
+    out, P, g = a[5]
+    assert abs(out[0] - ref[0]) <= 2e-6 * abs(ref[0]) + 1e-6 and abs(out[2] - ref[2]) <= 2e-6 * abs(ref[2]) + 1e-6
+    assert out[1] == ref[1] and out[3] == ref[3]
+    assert np.abs(P - ref[4]).max() <= PROB_ATOL and np.array_equal(P.argmax(-1), ref[4].argmax(-1))
+    for i, (gg, r) in enumerate(zip(g, grads)):
+        assert np.abs(gg - r).max() <= 1e-4 * np.abs(r).max() + 1e-9, i
 
 
 def test_bf16_configuration_forward_pair_in_one_launch(cmu, monkeypatch):

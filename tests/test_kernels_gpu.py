@@ -173,6 +173,30 @@ def test_spmm_long_row_chunks_on_the_owning_xcd_or_dealt_round(dev):
     assert ops.CSR(band, dev, long_row_nnz=256).chunks_with_owner is True
 
 
+@pytest.mark.parametrize("C", [256, 129, 40, 300, 512])
+def test_spmm_with_the_softmax_in_its_epilogue(dev, C):
+    """geogcn_spmm_csr_softmax_f32 (the output layer: softmax(A_hat . Z + b) without ever writing the logits) against
+    geogcn_spmm_csr_f32 + geogcn_softmax_rows_f32: the same first index of every row's maximum, probabilities to rounding (the row
+    sum is taken over another layout), rows summing to one, pad columns zero -- short rows (epilogue of the row kernel) and
+    long rows (combined, then softmaxed in place) alike; two runs bitwise equal."""
+    from geographconv_amd import ops
+    A = synth.powerlaw_ahat(20000, 260000)
+    dA = ops.CSR(A, dev)
+    assert dA.n_chunks > 0                                   # there are long rows
+    Z = ops.DMat.from_numpy(_rand((20000, C), 3, 4.0), dev)
+    b = torch.from_numpy(np.pad(_rand((C,), 2), (0, ops.pad4(C) - C))).to(dev)
+    am_ref = torch.empty(20000, dtype=torch.int32, device=dev)
+    ref = ops.softmax_rows(ops.spmm(dA, Z, bias=b), argmax=am_ref)
+    am = torch.full((20000,), -1, dtype=torch.int32, device=dev)
+    got = ops.spmm_softmax(dA, Z, bias=b, argmax=am)
+    assert torch.equal(am, am_ref)
+    assert torch.allclose(got.t[:, :C], ref.t[:, :C], rtol=2e-6, atol=1e-12)
+    assert torch.all(got.t[:, C:] == 0) and torch.all((got.t[:, :C].sum(1) - 1).abs() < 1e-5)
+    again = ops.spmm_softmax(dA, Z, bias=b)
+    assert torch.equal(again.t, got.t)
+    assert np.abs(got.numpy() - O.softmax_rows(O.spmm(A, Z.numpy()) + b.cpu().numpy()[:C])).max() < 2e-6
+
+
 def test_spmm_timer_rides_on_the_plan_handle(dev):
     """The profiling timer is a caller-held handle attached to ONE plan (no library-global state): products on another
     plan, of another width, or fused highway launches are not sampled; detaching stops the sampling."""
