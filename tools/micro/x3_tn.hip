@@ -1,0 +1,261 @@
+// Micro-benchmark (NOT part of the product): A^T . B (the weight gradients dW = H^T . dZ, reduction over the 440,000 nodes) with the
+// fp32-class split-bf16 ("bf16x3") contraction on v_mfma_f32_16x16x32_bf16.
+// Both operands are k-STRIDED fp32 in memory ([K][M], [K][N]).  A thread loads an 8 (k) x 4 (columns) patch as eight float4s, splits
+// every value EXACTLY into three bf16 terms and writes, per column, three 16-byte k-contiguous pieces (one per plane): the transpose
+// happens in registers and the LDS images are [plane][row][32 k] -- the fragment layout of the MFMA.  One 8-wave block per CU, tile
+// 160 x 320 (2 x 4 waves, wave tile 80 x 80), ONE LDS image of three planes (115 KB: no room for a second), split-K slabs in fp32.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/x3_tn.hip -o tools/micro/bin/x3_tn && tools/micro/bin/x3_tn
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) {                                                \
+            printf("%s: %s\n", #x, hipGetErrorString(e_));                     \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+constexpr int kNumXCD = 8;
+constexpr int BKH = 32, ROWB = 80;
+
+__device__ __forceinline__ uint32_t bf16_pack(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t (&p)[3]) {
+    p[0] = bf16_pack(x0, x1);
+    const float r0 = x0 - __uint_as_float(p[0] << 16), r1 = x1 - __uint_as_float(p[0] & 0xffff0000u);
+    p[1] = bf16_pack(r0, r1);
+    const float s0 = r0 - __uint_as_float(p[1] << 16), s1 = r1 - __uint_as_float(p[1] & 0xffff0000u);
+    p[2] = bf16_pack(s0, s1);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+
+// PF = stages of global loads in flight per thread.  PROBE: 1 = no global loads, 2 = no LDS stores (and no split), 4 = no MFMAs
+template <int BM, int BN, int PF, int PROBE = 0>
+__global__ __launch_bounds__(512, 1) void x3_tn_kernel(const float* __restrict__ A, int64_t lda, int64_t M, const float* __restrict__ B,
+                                                       int64_t ldb, int64_t N, int64_t K, float* __restrict__ W, int64_t ldw, int n_mt,
+                                                       int n_nt, int nsplit, int64_t kchunk) {
+    constexpr int NTH = 512, kASplit = 192;
+    constexpr int MR = BM / 32, NR = BN / 64;
+    constexpr int kAItems = 4 * (BM / 4), kBItems = 4 * (BN / 4);
+    static_assert(kAItems <= kASplit && kBItems <= NTH - kASplit, "patch lists must fit the thread ranges");
+    constexpr int kImgA = BM * ROWB, kPlane = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3, li = lane & 15, lg = lane >> 4;
+
+    const int b = blockIdx.x;
+    const int xcd = b % kNumXCD, s = b / kNumXCD;
+    const int tiles = n_nt * n_mt;
+    const int tile = s % tiles;
+    const int nt = __builtin_amdgcn_readfirstlane(tile % n_nt);
+    const int mt = __builtin_amdgcn_readfirstlane(tile / n_nt);
+    const int z = __builtin_amdgcn_readfirstlane(xcd + kNumXCD * (s / tiles));
+    if (z >= nsplit) return;
+    const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+    const int64_t kbeg = (int64_t)z * kchunk, kend = K < kbeg + kchunk ? K : kbeg + kchunk;
+    const int nk = (int)((kend - kbeg + BKH - 1) / BKH);
+
+    const bool isA = tid < kASplit;
+    const int it = isA ? tid : tid - kASplit;
+    const int cols4 = isA ? BM / 4 : BN / 4;
+    const bool active = it < 4 * cols4;
+    const int k8 = it / cols4, c4 = it % cols4;
+    const float* P = isA ? A : B;
+    const int64_t ld = isA ? lda : ldb;
+    const int64_t c0 = isA ? m0 : n0;
+    const int64_t ctot = isA ? M : N;
+    const bool col_ok = active && (c4 * 4 < ((ctot + 3) & ~(int64_t)3) - c0);
+    f32x4 ring[PF][8];
+    auto gload = [&](f32x4 (&r)[8], int kt) {
+        const int64_t k0 = kbeg + (int64_t)kt * BKH;
+        const __amdgpu_buffer_rsrc_t rs = mk_rsrc(P + k0 * ld + c0, ((kend - k0) * ld - c0) * 4);
+        const uint32_t ld4 = (uint32_t)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t off = (uint32_t)(k8 * 8 + i) * ld4 + (uint32_t)c4 * 16u;
+            r[i] = (PROBE & 1) ? f32x4{1.f, 2.f, 3.f, 4.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(col_ok ? off : 0x80000000u), 0, 0));
+        }
+    };
+    // registers -> the three planes of the LDS image: column e of the patch = component e of every row
+    auto sstore = [&](const f32x4 (&r)[8]) {
+        if (!active || (PROBE & 2)) return;
+        unsigned char* img = smem_raw + (isA ? 0 : kImgA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t p[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split3_pair(r[2 * q][e], r[2 * q + 1][e], p[q]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint4*>(img + pl * kPlane + (c4 * 4 + e) * ROWB + k8 * 16) = make_uint4(p[0][pl], p[1][pl], p[2][pl], p[3][pl]);
+        }
+    };
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int d = 0; d < PF; ++d) gload(ring[d], d);
+#pragma unroll 1
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kt = kt0 + u;
+            const bool live = kt < nk;          // (no `break`: the ring's slots must stay compile-time constants)
+            __syncthreads();                    // everybody done reading the stage before
+            if (live) sstore(ring[u]);
+            gload(ring[u], kt + PF);            // (past the end of the slab: beyond num_records -> zeros, never multiplied)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (live && !(PROBE & 4)) {
+                const unsigned char* As = smem_raw;
+                const unsigned char* Bs = smem_raw + kImgA;
+                bf16x8 af[MR][3];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * kPlane + (wm * (BM / 2) + i * 16 + li) * ROWB + lg * 16);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    bf16x8 bf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bf[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * kPlane + (wn * (BN / 4) + j * 16 + li) * ROWB + lg * 16);
+#define X3_TERM(PB, PA)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MR; ++i) acc[i][j] =                                                  \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[PB], af[i][PA], acc[i][j], 0, 0, 0);
+                    X3_TERM(0, 2) X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 1) X3_TERM(1, 0) X3_TERM(0, 0)
+#undef X3_TERM
+                }
+            }
+        }
+    }
+    float* Wz = W + (int64_t)z * M * ldw;
+    const int64_t n_store = (N + 3) & ~(int64_t)3;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int64_t row = m0 + wm * (BM / 2) + i * 16 + li;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int64_t col0 = n0 + wn * (BN / 4) + j * 16 + lg * 4;
+            f32x4 x = acc[i][j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col0 + q >= N) x[q] = 0.f;
+            if (row < M && col0 < n_store) *reinterpret_cast<f32x4*>(Wz + row * ldw + col0) = x;
+        }
+    }
+}
+
+__global__ void reduce_kernel(int M, int N, int nsplit, const float* W, int64_t ldw, float* C) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * N) return;
+    const int m = e / N, n = e % N;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += W[((int64_t)z * M + m) * ldw + n];
+    C[e] = s;
+}
+
+template <int BM, int BN, int PF, int PROBE>
+static void run(const char* name, const float* dH, int M, const float* dG, int N, int64_t K, float* dW, float* dC, const std::vector<float>& hH,
+                const std::vector<float>& hG) {
+    const int n_mt = (M + BM - 1) / BM, n_nt = (N + BN - 1) / BN;
+    const int tiles = n_mt * n_nt;
+    int ns = 256 / tiles;
+    if (ns >= kNumXCD) ns = ns / kNumXCD * kNumXCD;
+    const int64_t kchunk = ((K + ns - 1) / ns + BKH - 1) / BKH * BKH;
+    const int nsplit = (int)((K + kchunk - 1) / kchunk);
+    const int grid = tiles * ((nsplit + kNumXCD - 1) / kNumXCD) * kNumXCD;
+    const int64_t ldw = (N + 3) & ~3;
+    const int lds = 3 * (BM + BN) * ROWB;
+    auto kern = x3_tn_kernel<BM, BN, PF, PROBE>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dH, (int64_t)M, (int64_t)M, dG, (int64_t)N, (int64_t)N, K, dW, ldw, n_mt, n_nt, nsplit, kchunk);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dH, (int64_t)M, (int64_t)M, dG, (int64_t)N, (int64_t)N, K, dW, ldw, n_mt, n_nt, nsplit, kchunk);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    hipLaunchKernelGGL(reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, 0, M, N, nsplit, dW, ldw, dC);
+    std::vector<float> hc((size_t)M * N);
+    CK(hipMemcpy(hc.data(), dC, hc.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    const int ms_[] = {0, 1, 15, 16, 79, 80, 159, 160, 299}, ns_[] = {0, 17, 299, 300, 319, 320, 599};
+    for (int m : ms_)
+        for (int n : ns_) {
+            if (m >= M || n >= N) continue;
+            double s = 0, sa = 0;
+            for (int64_t k = 0; k < K; ++k) {
+                const double t = (double)hH[k * M + m] * (double)hG[k * N + n];
+                s += t;
+                sa += fabs(t);
+            }
+            worst = fmax(worst, fabs(s - hc[(size_t)m * N + n]) / sa);
+        }
+    printf("%-44s grid %4d (%d x %d tiles x %d slabs) lds %6d  %.3f ms  %.1f TF(fp32-equiv)   max err / sum|terms| %.2e\n", name, grid, n_mt, n_nt,
+           nsplit, lds, ms, 2.0 * M * N * K / ms / 1e9, worst);
+}
+
+int main() {
+    const int64_t K = 440000;
+    const int M = 300;
+    for (int N : {600, 300, 256}) {
+        std::vector<float> hH((size_t)K * M), hG((size_t)K * N);
+        uint32_t s = 12345;
+        auto rnd = [&]() {
+            s = s * 1664525u + 1013904223u;
+            return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f;
+        };
+        for (auto& x : hH) x = rnd() * (1.f + 1e-3f * rnd());
+        for (auto& x : hG) x = rnd() * 0.1f * (1.f + 1e-3f * rnd());
+        float *dH, *dG, *dW, *dC;
+        CK(hipMalloc(&dH, hH.size() * 4));
+        CK(hipMalloc(&dG, hG.size() * 4));
+        CK(hipMalloc(&dW, (size_t)256 * M * 640 * 4));
+        CK(hipMalloc(&dC, (size_t)M * N * 4));
+        CK(hipMemcpy(dH, hH.data(), hH.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
+        printf("M = %d, N = %d, K = %lld (%.1f GFLOP)\n", M, N, (long long)K, 2.0 * M * N * K / 1e9);
+        run<160, 320, 1, 0>("x3 A^T.B, 160 x 320, 1 stage ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 0>("x3 A^T.B, 160 x 320, 2 stages ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 1>("  ablation: no global loads", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 3>("  ablation: MFMAs + fragment reads only", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 4>("  ablation: no MFMAs", dH, M, dG, N, K, dW, dC, hH, hG);
+        if (N <= 256) run<160, 256, 2, 0>("x3 A^T.B, 160 x 256, 2 stages ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<128, 320, 2, 0>("x3 A^T.B, 128 x 320, 2 stages ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        CK(hipFree(dH)); CK(hipFree(dG)); CK(hipFree(dW)); CK(hipFree(dC));
+    }
+    return 0;
+}
