@@ -58,22 +58,23 @@ SIGNATURES = {
                                       c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_panels_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32,
                                        c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
-    'geogcn_gemm_dual_workspace_bytes': (c_sz, [c_i32, c_i64, c_i64, c_i64, c_i64]),
+    'geogcn_gemm_dual_workspace_bytes': (c_sz, [c_i32, c_i64, c_i64, c_i64, c_i64, c_i32]),
     'geogcn_gemm_dual_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
-                                     c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
-    'geogcn_gemm_kcat_workspace_bytes': (c_sz, [c_i32, c_i64, c_i64, c_i64, c_i64]),
+                                     c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_gemm_kcat_workspace_bytes': (c_sz, [c_i32, c_i64, c_i64, c_i64, c_i64, c_i32]),
     'geogcn_gemm_kcat_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
-                                     c_ptr, c_i64, c_i32, c_ptr, c_sz, c_ptr]),
+                                     c_ptr, c_i64, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_kcat_gated_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
-                                           c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_sz, c_ptr]),
+                                           c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_sz, c_ptr]),
+    'geogcn_debug_set_tn_slab_limit': (None, [c_i64]),
     'geogcn_gemm_dual_bf16_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'geogcn_gemm_dual_bf16': (c_i32, [c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32,
                                       c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_gated_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                       c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_kcat_gated_tanhbwd_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
-                                                   c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_sz,
-                                                   c_ptr]),
+                                                   c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_i32, c_ptr,
+                                                   c_sz, c_ptr]),
     'geogcn_gate_carry_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'geogcn_bias_act_f32': (c_i32, [c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     'geogcn_highway_fwd_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
@@ -128,7 +129,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 2          # == GEOGCN_ABI_VERSION of include/geogcn.h (tests/test_abi.py holds the two together)
+ABI_VERSION = 3          # == GEOGCN_ABI_VERSION of include/geogcn.h (tests/test_abi.py holds the two together)
 
 
 def header_symbols():

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libgeogcn.so')
-SOURCES = ['core.hip', 'spmm.hip', 'spmm_hot.hip', 'xt.hip', 'gemm.hip', 'gemm_bf16.hip', 'elementwise.hip', 'softmax_adam.hip', 'comm.hip']
+SOURCES = ['core.hip', 'spmm.hip', 'spmm_hot.hip', 'xt.hip', 'gemm.hip', 'gemm_x3.hip', 'gemm_bf16.hip', 'elementwise.hip', 'softmax_adam.hip', 'comm.hip']
 # (no -munsafe-fp-atomics: the two float atomics of the library -- softmax_adam.hip, exact by construction -- ask for the
 #  hardware add themselves with unsafeAtomicAdd; any future atomicAdd gets the safe default)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

@@ -12,6 +12,7 @@
 // transA (reduction over the long dimension N_nodes) runs split-K into a workspace and a second
 // kernel adds the slabs in slab order: deterministic, no atomics.
 #include "common.h"
+#include "gemm_call.h"
 
 #include <stdlib.h>
 
@@ -476,6 +477,7 @@ struct TnDirectArgs {
     int64_t kchunk;
 };
 constexpr int TN_DEPTH = 5;
+int64_t kTnSlabByteLimit = 0x7FFFFFFFll;      // bytes one buffer descriptor bounds; geogcn_debug_set_tn_slab_limit lowers it (the fallback's test)
 
 template <int MR, int NR>
 __global__ __launch_bounds__(512, 1) void gemm_tn_direct_kernel(const TnDirectArgs a) {
@@ -862,24 +864,6 @@ struct SplitPlan {
     int grid;
 };
 
-// host-side description of one launch (segments as in GemmArgs)
-struct GemmCall {
-    int64_t M;
-    int n_nseg, n_kseg;
-    const float* A[2]; int64_t lda[2];
-    const float* B[2]; int64_t ldb[2];
-    float* C[2]; int64_t ldc[2];
-    const float* bias[2];
-    int64_t N[2], K[2];
-    int act[2];
-    int accumulate;
-    int panel_w = 0;
-    int64_t panel_R = 0;
-    const float* gateG = nullptr; int64_t ldg = 0; const float* gateT = nullptr; int64_t ldt = 0;      // whole-rows kernel only
-    const float* postY = nullptr; int64_t ldy = 0; const uint8_t* postKeep = nullptr; int64_t postF = 0; float postScale = 0.f;
-    int64_t maxN() const { return n_nseg == 2 ? std::max(N[0], N[1]) : N[0]; }
-};
-
 // grid = resident persistent blocks; transA additionally slices K so that (tiles x slices) fills the grid
 template <int BM, int BN, bool AT, bool BT, int WM = 2, int WN = 2>
 SplitPlan plan_grid(int64_t M, int64_t n_nt, int64_t K) {
@@ -954,34 +938,48 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
     float* W = (float*)ws;
     int nsplit_used = sp.nsplit;
     bool direct_done = false;
-#ifndef GEOGCN_F32_NO_TN_DIRECT          // (A/B build only: every A^T . B on the staged kernel)
-    // (a slab's rows must lie within one 2 GB buffer descriptor for its end to be a hardware bound; wider operands than the
-    //  GCN's -- rows x pitch x 4 bytes per slab beyond 2^31 -- stay on the staged kernel)
-    const bool direct_ok = (int64_t)sp.kchunk * std::max(c.lda[0], std::max(c.ldb[0], c.n_nseg == 2 ? c.ldb[1] : 0)) * 4 < 0x7FFFFFFFll;
     if constexpr (AT && !BT && WM == 2 && WN == 4) {
-      if (direct_ok) {
-        // the weight gradients: fragments straight from L1 / L2 into registers, no LDS, no barriers (gemm_tn_direct_kernel)
-        TnDirectArgs t{};
-        t.M = c.M; t.K = c.K[0]; t.A = c.A[0]; t.lda = c.lda[0];
-        for (int q = 0; q < 2; ++q) { t.B[q] = c.B[q]; t.ldb[q] = c.ldb[q]; t.N[q] = c.N[q]; }
-        t.W = W; t.ldw = ldw; t.seg_w = seg_w;
-        t.n_mt = a.n_mt; t.n_nt = n_nt; t.nt_per_seg = nt_per_seg;
-        const int T = t.n_mt * t.n_nt;
         // one 8-wave block per CU and the tiles of a slab on one XCD: an XCD (32 CUs) takes ceil(nsplit / 8) * T blocks -- keep that
         // within 32, or the 33rd block of an XCD runs after the others (384 x 300: 3 tiles x 85 slabs took twice the time)
+        const int T = a.n_mt * n_nt;
         int ns = sp.nsplit;
         const int ns_cap = kNumXCD * std::max(1, (kNumCU / kNumXCD) / T);
         if (ns > ns_cap) ns = ns_cap;
-        t.kchunk = ns == sp.nsplit ? sp.kchunk : cdiv(cdiv(c.K[0], ns), BK) * BK;
-        t.nsplit = (int)cdiv(c.K[0], t.kchunk);
-        nsplit_used = t.nsplit;
-        const dim3 dgrid((unsigned)(cdiv(t.nsplit, kNumXCD) * kNumXCD * T));
-        hipLaunchKernelGGL((gemm_tn_direct_kernel<BM / 32, BN / 64>), dgrid, dim3(512), 0, st, t);
-        GEOGCN_LAUNCH_CHECK("gemm_tn_direct_kernel");
-        direct_done = true;
-      }
-    }
+        const int64_t kchunk = ns == sp.nsplit ? sp.kchunk : cdiv(cdiv(c.K[0], ns), BK) * BK;
+        const int nsplit = (int)cdiv(c.K[0], kchunk);
+        // (a slab's rows must lie within one 2 GB buffer descriptor for its end to be a hardware bound -- checked on the slab these kernels
+        //  actually take, after the cap above may have enlarged it; wider operands than the GCN's stay on the staged kernel)
+        const int64_t max_ld = std::max(c.lda[0], std::max(c.ldb[0], c.n_nseg == 2 ? c.ldb[1] : 0));
+        const bool slab_ok = kchunk * max_ld * 4 < kTnSlabByteLimit;
+        if (slab_ok && c.precision == GEOGCN_GEMM_BF16X3 && x3_tn_takes(BM, BN)) {
+            // fp32-class split-bf16 products, operands transposed + split on their way into LDS (gemm_x3.hip)
+            X3TnCall t{};
+            t.M = c.M; t.K = c.K[0]; t.A = c.A[0]; t.lda = c.lda[0];
+            for (int q = 0; q < 2; ++q) { t.B[q] = c.B[q]; t.ldb[q] = c.ldb[q]; t.N[q] = c.N[q]; }
+            t.W = W; t.ldw = ldw; t.seg_w = seg_w;
+            t.n_mt = a.n_mt; t.n_nt = n_nt; t.nt_per_seg = nt_per_seg;
+            t.kchunk = kchunk; t.nsplit = nsplit;
+            if (const int rc = x3_tn_launch(BM, BN, t, st)) return rc;
+            nsplit_used = nsplit;
+            direct_done = true;
+        }
+#ifndef GEOGCN_F32_NO_TN_DIRECT          // (A/B build only: every exact A^T . B on the staged kernel)
+        if (slab_ok && !direct_done) {
+            // the weight gradients: fragments straight from L1 / L2 into registers, no LDS, no barriers (gemm_tn_direct_kernel)
+            TnDirectArgs t{};
+            t.M = c.M; t.K = c.K[0]; t.A = c.A[0]; t.lda = c.lda[0];
+            for (int q = 0; q < 2; ++q) { t.B[q] = c.B[q]; t.ldb[q] = c.ldb[q]; t.N[q] = c.N[q]; }
+            t.W = W; t.ldw = ldw; t.seg_w = seg_w;
+            t.n_mt = a.n_mt; t.n_nt = n_nt; t.nt_per_seg = nt_per_seg;
+            t.kchunk = kchunk; t.nsplit = nsplit;
+            nsplit_used = nsplit;
+            const dim3 dgrid((unsigned)(cdiv(t.nsplit, kNumXCD) * kNumXCD * T));
+            hipLaunchKernelGGL((gemm_tn_direct_kernel<BM / 32, BN / 64>), dgrid, dim3(512), 0, st, t);
+            GEOGCN_LAUNCH_CHECK("gemm_tn_direct_kernel");
+            direct_done = true;
+        }
 #endif
+    }
     if (!direct_done) {
     a.C[0] = W;
     a.ldc[0] = ldw;
@@ -1184,6 +1182,9 @@ int run_rows(int kp, bool transB, const GemmCall& c, void* ws, hipStream_t st) {
 }
 
 int run_call(bool transA, bool transB, const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
+    // fp32-class split-bf16 products where the caller allows them and a kernel takes the shape (gemm_x3.hip); anything else: exact fp32
+    if (const int kc = x3_rows_kc(c, transA, transB); kc && ws && aligned16(ws) && ws_bytes >= x3_rows_ws_bytes(c, kc))
+        return x3_run_rows(kc, transB, c, ws, st);
     if (const int kp = rows_kp(c, transA, transB); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp))
         return run_rows(kp, transB, c, ws, st);          // (too small a workspace -- an older caller: the staged kernel)
     int bm, bn;
@@ -1245,6 +1246,12 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
         const int kp = rows_kp(c, false, transB != 0);
         return kp ? rows_ws_bytes(c, kp) : 0;
     }
+    if (!transA && precision == GEOGCN_GEMM_BF16X3) {   // the split-bf16 whole-rows kernel's weights, or the staged kernel's planes
+        GemmCall c{};
+        c.M = M; c.n_nseg = 1; c.n_kseg = 1; c.N[0] = N; c.K[0] = K; c.precision = precision;
+        const int kc = x3_rows_kc(c, false, transB != 0);
+        return std::max(kc ? x3_rows_ws_bytes(c, kc) : (size_t)0, gemm_bf16_workspace_bytes(precision, N, K));
+    }
     if (!transA) return gemm_bf16_workspace_bytes(precision, N, K);
     if (precision == GEOGCN_GEMM_BF16) {
         const size_t h = gemm_bf16_tn_workspace_bytes(M, N, K);      // 0: shape left to the fp32 kernel
@@ -1253,22 +1260,23 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
     return transA_ws_bytes(M, N, 1, K);
 }
 
-size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K) {
+size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, int32_t precision) {
     if (M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0) return 0;
-    if (!transA) {          // the whole-rows kernel's fragment-ordered weights (0: the call runs on the staged kernel)
+    if (!transA) {          // the whole-rows kernels' fragment-ordered weights (0: the call runs on the staged kernel)
         GemmCall c{};
-        c.M = M; c.n_nseg = 2; c.n_kseg = 1; c.N[0] = N0; c.N[1] = N1; c.K[0] = K;
+        c.M = M; c.n_nseg = 2; c.n_kseg = 1; c.N[0] = N0; c.N[1] = N1; c.K[0] = K; c.precision = precision;
+        if (const int kc = x3_rows_kc(c, false, false)) return x3_rows_ws_bytes(c, kc);
         const int kp = rows_kp(c, false);
         return kp ? rows_ws_bytes(c, kp) : 0;
     }
     return transA_ws_bytes(M, std::max(N0, N1), 2, K);
 }
 
-size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1) {
-    (void)transB;
+size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, int32_t precision) {
     if (M <= 0 || N <= 0 || K0 <= 0 || K1 <= 0) return 0;
     GemmCall c{};
-    c.M = M; c.n_nseg = 1; c.n_kseg = 2; c.N[0] = N; c.K[0] = K0; c.K[1] = K1;
+    c.M = M; c.n_nseg = 1; c.n_kseg = 2; c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.precision = precision;
+    if (const int kc = x3_rows_kc(c, false, transB != 0)) return x3_rows_ws_bytes(c, kc);
     const int kp = rows_kp(c, false);
     return kp ? rows_ws_bytes(c, kp) : 0;
 }
@@ -1310,6 +1318,15 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
         GEOGCN_REQUIRE(!bias && act == GEOGCN_ACT_NONE, GEOGCN_E_ARG, "%s: K = 0 with a bias / activation", fn);
         return zero_rows_async((float*)Cv, M, (N + 3) & ~(int64_t)3, ldc, st);
     }
+    if (!transA && precision == GEOGCN_GEMM_BF16X3 && !c_bf16 && !panel_w) {
+        // the split-bf16 whole-rows kernel where it takes the shape (TwitterUS-size operands); else the staged split-bf16 kernel below
+        GemmCall c{};
+        c.M = M; c.n_nseg = 1; c.n_kseg = 1;
+        c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = (float*)Cv; c.ldc[0] = ldc; c.bias[0] = bias;
+        c.N[0] = N; c.K[0] = K; c.act[0] = act; c.act[1] = GEOGCN_ACT_NONE; c.accumulate = accumulate; c.precision = precision;
+        if (const int kc = x3_rows_kc(c, false, transB != 0); kc && ws && aligned16(ws) && ws_bytes >= x3_rows_ws_bytes(c, kc))
+            return x3_run_rows(kc, transB != 0, c, ws, st);
+    }
     if (!transA && precision != GEOGCN_GEMM_F32)
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
                                   ws_bytes, st, panel_w, panel_R);
@@ -1323,6 +1340,7 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
     c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = C; c.ldc[0] = ldc; c.bias[0] = bias;
     c.N[0] = N; c.K[0] = K; c.act[0] = act; c.act[1] = GEOGCN_ACT_NONE; c.accumulate = accumulate;
     c.panel_w = panel_w; c.panel_R = panel_R;
+    c.precision = precision == GEOGCN_GEMM_BF16X3 ? precision : GEOGCN_GEMM_F32;      // (transA: split-bf16 slabs where a kernel takes the tile)
     return run_call(transA != 0, transB != 0, c, ws, ws_bytes, st);
 }
 
@@ -1358,8 +1376,9 @@ int geogcn_gemm_panels_f32(int32_t transB, int64_t M, int64_t N, int64_t K, cons
 int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda,
                          const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
                          float* C1, int64_t ldc1, const float* bias0, int32_t act0, const float* bias1, int32_t act1,
-                         void* ws, size_t ws_bytes, void* stream) {
+                         int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "gemm_dual_f32";
+    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3, GEOGCN_E_ARG, "%s: precision must be F32 or BF16X3 (%d)", fn, precision);
     GEOGCN_REQUIRE(M >= 0 && N0 >= 0 && N1 >= 0 && K >= 0, GEOGCN_E_SIZE, "%s: negative size", fn);
     if (M == 0 || (N0 == 0 && N1 == 0)) return 0;
     GEOGCN_REQUIRE(N0 > 0 && N1 > 0, GEOGCN_E_SIZE, "%s: both products need columns (N0=%lld N1=%lld)", fn, (long long)N0,
@@ -1387,15 +1406,16 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
     c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
     c.C[0] = C0; c.ldc[0] = ldc0; c.C[1] = C1; c.ldc[1] = ldc1;
     c.bias[0] = bias0; c.bias[1] = bias1;
-    c.N[0] = N0; c.N[1] = N1; c.K[0] = K; c.act[0] = act0; c.act[1] = act1;
+    c.N[0] = N0; c.N[1] = N1; c.K[0] = K; c.act[0] = act0; c.act[1] = act1; c.precision = precision;
     return run_call(transA != 0, false, c, ws, ws_bytes, st);
 }
 
 // C = A0.op(B0) + A1.op(B1) [+ C]: one accumulator over both reductions, exact fp32
 int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                         float* C, int64_t ldc, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+                         float* C, int64_t ldc, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "gemm_kcat_f32";
+    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3, GEOGCN_E_ARG, "%s: precision must be F32 or BF16X3 (%d)", fn, precision);
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C, GEOGCN_E_NULL, "%s: null pointer", fn);
@@ -1409,7 +1429,7 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
     c.A[0] = A0; c.lda[0] = lda0; c.A[1] = A1; c.lda[1] = lda1;
     c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
     c.C[0] = C; c.ldc[0] = ldc;
-    c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate;
+    c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.accumulate = accumulate; c.precision = precision;
     return run_call(false, transB != 0, c, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1437,6 +1457,8 @@ int geogcn_gemm_dual_bf16(int64_t M, int64_t N0, int64_t N1, int64_t K, const fl
                                    (hipStream_t)stream);
 }
 
+void geogcn_debug_set_tn_slab_limit(int64_t bytes) { kTnSlabByteLimit = bytes > 0 ? bytes : 0x7FFFFFFFll; }
+
 int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                           int64_t ldb, float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
                           int32_t precision, void* ws, size_t ws_bytes, void* stream) {
@@ -1451,6 +1473,16 @@ int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const
                    "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
     GEOGCN_REQUIRE(C != G && C != T, GEOGCN_E_ARG, "%s: C must not alias G or T", fn);
     hipStream_t st = (hipStream_t)stream;
+    if (precision == GEOGCN_GEMM_BF16X3) {
+        GemmCall c{};
+        c.M = M; c.n_nseg = 1; c.n_kseg = 1;
+        c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = C; c.ldc[0] = ldc;
+        c.N[0] = N; c.K[0] = K; c.act[0] = c.act[1] = GEOGCN_ACT_NONE; c.precision = precision;
+        if (const int kc = x3_rows_kc(c, false, transB != 0); kc && ws && aligned16(ws) && ws_bytes >= x3_rows_ws_bytes(c, kc)) {
+            c.gateG = G; c.ldg = ldg; c.gateT = T; c.ldt = ldt;
+            return x3_run_rows(kc, transB != 0, c, ws, st);
+        }
+    }
     if (precision != GEOGCN_GEMM_F32) {
         const GateOps gate{G, ldg, T, ldt};
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, nullptr, GEOGCN_ACT_NONE, 0, ws, ws_bytes, st,
@@ -1472,21 +1504,21 @@ int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const
 static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                            const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                            float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, const float* Y, int64_t ldy,
-                           const uint8_t* keep, int64_t keepF, float scale, void* ws, size_t ws_bytes, void* stream);
+                           const uint8_t* keep, int64_t keepF, float scale, int32_t precision, void* ws, size_t ws_bytes, void* stream);
 
 int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                                const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                               float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, void* ws,
-                               size_t ws_bytes, void* stream) {
+                               float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, int32_t precision,
+                               void* ws, size_t ws_bytes, void* stream) {
     return kcat_gated_impl("gemm_kcat_gated_f32", transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, G, ldg, T, ldt,
-                           nullptr, 0, nullptr, 0, 0.f, ws, ws_bytes, stream);
+                           nullptr, 0, nullptr, 0, 0.f, precision, ws, ws_bytes, stream);
 }
 
 int geogcn_gemm_kcat_gated_tanhbwd_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                                        const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                                        float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
-                                       const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, void* ws,
-                                       size_t ws_bytes, void* stream) {
+                                       const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, int32_t precision,
+                                       void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "gemm_kcat_gated_tanhbwd_f32";
     GEOGCN_REQUIRE(M >= 0 && N >= 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (M > 0 && N > 0) {
@@ -1496,14 +1528,15 @@ int geogcn_gemm_kcat_gated_tanhbwd_f32(int32_t transB, int64_t M, int64_t N, int
         GEOGCN_REQUIRE((const float*)C != Y, GEOGCN_E_ARG, "%s: C must not alias Y", fn);
     }
     return kcat_gated_impl(fn, transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, G, ldg, T, ldt, Y, ldy, keep, keepF,
-                           scale, ws, ws_bytes, stream);
+                           scale, precision, ws, ws_bytes, stream);
 }
 
 static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                            const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                            float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, const float* Y, int64_t ldy,
-                           const uint8_t* keep, int64_t keepF, float scale, void* ws, size_t ws_bytes, void* stream) {
+                           const uint8_t* keep, int64_t keepF, float scale, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
+    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3, GEOGCN_E_ARG, "%s: precision must be F32 or BF16X3 (%d)", fn, precision);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C && G && T, GEOGCN_E_NULL, "%s: null pointer", fn);
     const int64_t b0_cols = transB ? K0 : N, b1_cols = transB ? K1 : N, n4 = (N + 3) & ~(int64_t)3;
@@ -1518,8 +1551,14 @@ static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N,
     c.A[0] = A0; c.lda[0] = lda0; c.A[1] = A1; c.lda[1] = lda1;
     c.B[0] = B0; c.ldb[0] = ldb0; c.B[1] = B1; c.ldb[1] = ldb1;
     c.C[0] = C; c.ldc[0] = ldc;
-    c.N[0] = N; c.K[0] = K0; c.K[1] = K1;
+    c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.precision = precision;
     hipStream_t st = (hipStream_t)stream;
+    if (const int kc = x3_rows_kc(c, false, transB != 0); kc && ws && aligned16(ws) && ws_bytes >= x3_rows_ws_bytes(c, kc)) {
+        c.accumulate = 0;
+        c.gateG = G; c.ldg = ldg; c.gateT = T; c.ldt = ldt;
+        c.postY = Y; c.ldy = ldy; c.postKeep = keep; c.postF = keepF; c.postScale = scale;
+        return x3_run_rows(kc, transB != 0, c, ws, st);
+    }
     if (const int kp = rows_kp(c, false, transB != 0); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp)) {
         c.accumulate = 0;
         c.gateG = G; c.ldg = ldg; c.gateT = T; c.ldt = ldt;

@@ -291,7 +291,7 @@ class MultiplicativeGatingLayer(L.MergeLayer):
         # dH_in = dZ.Wh^T + dU.Wt^T (the fused launch of the reverse sweep, nn/layers.py _backward_post): a GateCarry goes down instead
         # (... or, where the two products are separate launches -- the bf16 configuration -- of the first of them)
         lazy = (tuning.FUSE_GATE_CARRY and into[2] is None and kwargs.get('comm') is None and isinstance(grad, K.DMat)
-                and (K.kcat_gated_native(grad.n, grad.F) if tape.get(gate_l, {}).get('fused_with') is h1_l
+                and (K.kcat_gated_native(grad.n, grad.F, kwargs.get('gemm_precision')) if tape.get(gate_l, {}).get('fused_with') is h1_l
                      else K.gemm_gated_native(grad.n, grad.F, kwargs.get('gemm_precision'))))
         dS, dU, dH = K.highway_bwd(grad, t, h1, h2, dbS=h1_l.b.grad if fuse_b else None,
                                    dbU=gate_l.b.grad if fuse_b else None, **({'dS_bf16': True} if s16 else {}),

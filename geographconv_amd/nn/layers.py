@@ -290,7 +290,7 @@ class DenseLayer(Layer):
                 # highway block (gcnmodel.py:281-286): this gate and the conv branch read the same input -- one launch
                 # multiplies it by [Wh | Wt]: Z = H.Wh raw into the SpMM operand's pitch, T = sigmoid(H.Wt + bt) here
                 zf = K.DMat.empty(input.n, conv.num_units, input.device, ld=K.gather_ld(conv.num_units))
-                _, y = K.gemm_dual(input, conv.W.data, self.W.data, out0=zf, bias1=bias, act1=act)
+                _, y = K.gemm_dual(input, conv.W.data, self.W.data, out0=zf, bias1=bias, act1=act, precision=prec)
                 tape[('fused_z', conv)] = (input, zf)
                 saved['fused_with'] = conv
             elif self._fusable_sibling(input, tape, kwargs, bf16=True) is not None:
@@ -397,7 +397,7 @@ class DenseLayer(Layer):
                 or isinstance(tape.get(below, {}).get('x'), K.DMat)):
             return None
         y0 = tape[below]['y']
-        if not isinstance(y0, K.DMat) or y0.F % 4 or tuple(keep.shape) != (y0.n, y0.F) or not K.kcat_gated_native(y0.n, y0.F):
+        if not isinstance(y0, K.DMat) or y0.F % 4 or tuple(keep.shape) != (y0.n, y0.F) or not K.kcat_gated_native(y0.n, y0.F, kwargs.get('gemm_precision')):
             return None
         return below, y0, keep, 1.0 / (1.0 - d.p)
 
@@ -412,7 +412,7 @@ class DenseLayer(Layer):
             return None
         if (conv is None or tape is None or kwargs.get('comm') is not None or kwargs.get('A') is None
                 or not isinstance(input, K.DMat) or conv.input_layer is not self.input_layer
-                or (not bf16 and prec != 'f32') or not _fuse_gemms()
+                or (not bf16 and prec not in ('f32', 'bf16x3')) or not _fuse_gemms()
                 or not conv._uses_graph(kwargs) or type(conv)._matmul is not DenseLayer._matmul
                 or conv.W.data is None or conv.W.shape[0] != self.W.shape[0]):
             return None
@@ -513,7 +513,7 @@ class DenseLayer(Layer):
         else:
             A_bwd = self._transpose_operand(A, grad, kwargs)
             if A_bwd is A.bwd and getattr(A, 'head_dense', None) is not None:
-                dZ = K.spmm_t(A, dS)          # an operand whose transpose is split (dense head panel + CSR tail)
+                dZ = K.spmm_t(A, dS, precision=kwargs.get('gemm_precision'))          # an operand whose transpose is split (dense head panel + CSR tail)
             else:
                 as_is = not K.bf16_gather(kwargs.get('gemm_precision')) or not isinstance(dS, K.DMat)   # (HMat: already bf16)
                 dZ = K.spmm(A_bwd, dS if as_is else K.cast_bf16(dS))
@@ -536,7 +536,7 @@ class DenseLayer(Layer):
             fused = tape.pop(('fused_dz', self), None) if tape is not None else None
             if fused is not None:
                 conv = tape[self]['fused_with']
-                K.gemm_dual(x, fused, dZ, out0=conv.W.grad, out1=self.W.grad, transA=True)     # dWh, dWt = H^T.[dZ | dU]
+                K.gemm_dual(x, fused, dZ, out0=conv.W.grad, out1=self.W.grad, transA=True, precision=prec)     # dWh, dWt = H^T.[dZ | dU]
                 tape[self]['bwd_done'] = True
                 if not need_input_grad:
                     return [None]
@@ -548,12 +548,12 @@ class DenseLayer(Layer):
                         # comes out is dS0, that layer's pre-activation gradient (its bias gradient: the column sums)
                         below, y0, keep, scale = post
                         dS0 = K.DMat.empty(y0.n, y0.F, y0.device, ld=K.gather_ld(y0.F))
-                        K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=dS0, transB=True, gate_carry=lazy, tanh_bwd=(y0, keep, scale))
+                        K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=dS0, transB=True, gate_carry=lazy, tanh_bwd=(y0, keep, scale), precision=prec)
                         K.colsum_rowblocks(dS0, out=below.b.grad)
                         return [PreAct(dS0, bias_done=True)]
-                    return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, transB=True, gate_carry=lazy)]
+                    return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, transB=True, gate_carry=lazy, precision=prec)]
                 return [K.gemm_kcat(fused, conv.W.data, dZ, self.W.data, out=into[0], transB=True,
-                                    accumulate=into[0] is not None)]
+                                    accumulate=into[0] is not None, precision=prec)]
             if lazy is not None and not need_input_grad:
                 lazy = None
             K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)    # dW = H^T . dZ
@@ -567,7 +567,7 @@ class DenseLayer(Layer):
             if into[0] is not None:
                 return [K.gemm(dZ, self.W.data, out=into[0], transB=True, accumulate=True, precision=prec)]
             return [K.gemm(dZ, self.W.data, transB=True, precision=prec)]  # dH = dZ . W^T
-        K.spmm_t(x, dZ, out=self.W.grad)                                   # dW0 = X^T . dS0
+        K.spmm_t(x, dZ, out=self.W.grad, precision=kwargs.get('gemm_precision'))      # dW0 = X^T . dS0
         return [None]
 
 

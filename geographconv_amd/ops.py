@@ -457,11 +457,20 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     return out
 
 
+def _fused_precision(precision):
+    """The fused highway launches exist in two precisions: 'f32' and 'bf16x3' (the bf16 configuration keeps its own launches)."""
+    p = precision or GEMM_PRECISION
+    if p not in ('f32', 'bf16x3'):
+        raise ValueError("fused highway GEMM launches take precision 'f32' or 'bf16x3', not %r" % (p,))
+    return GEMM_PRECISIONS[p]
+
+
 @_timed(lambda A, B0, B1, **kw: 'gemm_dual_tn' if kw.get('transA') else 'gemm_dual_nn')
 def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None, transA=False, bias0=None, act0=ACT_NONE,
-              bias1=None, act1=ACT_NONE):
-    """(out0, out1) = (act0(op(A) . B0 + bias0), act1(op(A) . B1 + bias1)) in ONE launch (exact fp32): the highway block's
-    conv branch and gate read the same input (reference gcnmodel.py:281-286)."""
+              bias1=None, act1=ACT_NONE, precision=None):
+    """(out0, out1) = (act0(op(A) . B0 + bias0), act1(op(A) . B1 + bias1)) in ONE launch: the highway block's conv branch and
+    gate read the same input (reference gcnmodel.py:281-286).  `precision`: 'f32' (exact) or 'bf16x3' (fp32-class split-bf16
+    products where a kernel takes the shape, exact otherwise)."""
     lib = _ffi.lib()
     M = A.F if transA else A.n
     K = A.n if transA else A.F
@@ -473,10 +482,11 @@ def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None,
     ws = _gemm_ws.get(dev)
     if ws is None:
         ws = _gemm_ws[dev] = Workspace(dev)
-    w = ws.get(lib.geogcn_gemm_dual_workspace_bytes(int(transA), M, B0.F, B1.F, K))
+    prec = _fused_precision(precision)
+    w = ws.get(lib.geogcn_gemm_dual_workspace_bytes(int(transA), M, B0.F, B1.F, K, prec))
     check(lib.geogcn_gemm_dual_f32(int(transA), M, B0.F, B1.F, K, _p(A.t), A.ld, _p(B0.t), B0.ld, _p(B1.t), B1.ld,
                                    _p(out0.t), out0.ld, _p(out1.t), out1.ld, _p(bias0), int(act0), _p(bias1), int(act1),
-                                   _p(w), w.numel(), _stream()), 'gemm_dual_f32')
+                                   prec, _p(w), w.numel(), _stream()), 'gemm_dual_f32')
     return out0, out1
 
 
@@ -501,14 +511,14 @@ def gemm_gated_native(n, F, precision=None):
     off) form the carry in its epilogue?  bf16: the whole-rows kernel takes every GCN width (any other falls back to carry +
     accumulate at the cost of the stored carry); fp32: from 32,768 rows on."""
     p = precision or GEMM_PRECISION
-    if p == 'bf16':
+    if p in ('bf16', 'bf16x3'):         # (bf16x3: the split-bf16 whole-rows kernel, or the staged one behind the same entry point)
         return True
     return p == 'f32' and _ffi.lib().geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_F32) > 0
 
 
-def kcat_gated_native(n, F):
-    """Does dH = dZ . Wh^T + dU . Wt^T + G * (1 - T) run with the carry in the epilogue at this size (whole-rows kernel)?"""
-    return _ffi.lib().geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F)) > 0
+def kcat_gated_native(n, F, precision=None):
+    """Does dH = dZ . Wh^T + dU . Wt^T + G * (1 - T) run with the carry in the epilogue at this size (a whole-rows kernel)?"""
+    return _ffi.lib().geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F), _fused_precision(precision)) > 0
 
 
 @_timed('gemm_dual_bf16')
@@ -532,8 +542,8 @@ def gemm_dual_bf16(A: DMat, B0: DMat, B1: DMat, out0=None, out1: DMat = None, bi
 
 @_timed('gemm_kcat')
 def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, gate_carry: GateCarry = None,
-              tanh_bwd=None):
-    """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (exact fp32) --
+              tanh_bwd=None, precision=None):
+    """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (`precision` 'f32' or 'bf16x3') --
     dH = dZ . Wh^T + dU . Wt^T of the highway block.  `gate_carry`: ... + G * (1 - T) formed in the epilogue (then no accumulate).
     `tanh_bwd` = (Y, keep_mask, scale), with a gate carry only: the result times keep * scale * (1 - Y^2) -- the dropout + tanh gradient
     of the layer below the first block in the same epilogue (geogcn_gemm_kcat_gated_tanhbwd_f32)."""
@@ -552,7 +562,8 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
     ws = _gemm_ws.get(A0.device)
     if ws is None:
         ws = _gemm_ws[A0.device] = Workspace(A0.device)
-    w = ws.get(lib.geogcn_gemm_kcat_workspace_bytes(int(transB), A0.n, N, A0.F, A1.F))
+    prec = _fused_precision(precision)
+    w = ws.get(lib.geogcn_gemm_kcat_workspace_bytes(int(transB), A0.n, N, A0.F, A1.F, prec))
     if gate_carry is not None:
         g, t = gate_carry.G, gate_carry.T
         if g.n != A0.n or g.F != N or t.n != A0.n or t.F != N:
@@ -563,15 +574,15 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
                 raise ValueError("gemm_kcat: tanh_bwd needs Y and a contiguous uint8 keep mask of the output's shape, width % 4 == 0")
             check(lib.geogcn_gemm_kcat_gated_tanhbwd_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
                                                          _p(B1.t), B1.ld, _p(out.t), out.ld, _p(g.t), g.ld, _p(t.t), t.ld, _p(Y.t), Y.ld,
-                                                         _p(keep), N, float(scale), _p(w), w.numel(), _stream()),
+                                                         _p(keep), N, float(scale), prec, _p(w), w.numel(), _stream()),
                   'gemm_kcat_gated_tanhbwd_f32')
             return out
         check(lib.geogcn_gemm_kcat_gated_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
-                                             _p(B1.t), B1.ld, _p(out.t), out.ld, _p(g.t), g.ld, _p(t.t), t.ld, _p(w), w.numel(),
+                                             _p(B1.t), B1.ld, _p(out.t), out.ld, _p(g.t), g.ld, _p(t.t), t.ld, prec, _p(w), w.numel(),
                                              _stream()), 'gemm_kcat_gated_f32')
         return out
     check(lib.geogcn_gemm_kcat_f32(int(transB), A0.n, N, A0.F, A1.F, _p(A0.t), A0.ld, _p(B0.t), B0.ld, _p(A1.t), A1.ld,
-                                   _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), _p(w), w.numel(), _stream()), 'gemm_kcat_f32')
+                                   _p(B1.t), B1.ld, _p(out.t), out.ld, int(accumulate), prec, _p(w), w.numel(), _stream()), 'gemm_kcat_f32')
     return out
 
 
@@ -964,8 +975,9 @@ def sparse_dropout(x: SparseOperand, p, seed, call):
 
 
 @_timed('spmm_t')
-def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
-    """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff)."""
+def spmm_t(x: SparseOperand, G: DMat, out: DMat = None, precision=None):
+    """out = x^T . G  (gradient of structured_dot(x, W) w.r.t. W; reference gcnmodel.py:39 autodiff).  `precision`: of the dense
+    head panel's product."""
     # column slabs of <= XT_MAX_F: the kernel keeps 2 x F/64 float4 accumulators per lane in registers; up to 320 columns
     # that leaves room for 1024-thread workgroups, beyond it halves the threads and doubles the batches (F = 600 in one
     # piece: 5.5 ms, slower than the row gather's 4.0; as two slabs of 300: see DESIGN.md 4.2)
@@ -984,7 +996,7 @@ def spmm_t(x: SparseOperand, G: DMat, out: DMat = None):
     else:
         out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)
     if x.head_dense is not None:
-        head = gemm(x.head_dense, G, transA=True)  # K x F on the MFMA pipe, deterministic split-K
+        head = gemm(x.head_dense, G, transA=True, precision=precision)  # K x F on the MFMA pipe, deterministic split-K
         scatter_rows(head, x.head_idx, out)
     return out
 

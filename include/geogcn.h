@@ -34,8 +34,11 @@ extern "C" {
  * Added since without a version change (nothing existing changed meaning): geogcn_gemm_kcat_gated_f32, geogcn_gemm_gated_f32,
  * geogcn_gemm_kcat_gated_tanhbwd_f32, geogcn_gemm_dual_bf16 (+ _workspace_bytes), geogcn_gate_carry_f32, geogcn_colsum_rowblocks_f32,
  * geogcn_spmm_csr_softmax_f32;
- * geogcn_highway_bwd_f32 / _bf16s_f32 accept dHcarry = NULL. */
-#define GEOGCN_ABI_VERSION 2
+ * geogcn_highway_bwd_f32 / _bf16s_f32 accept dHcarry = NULL.
+ * 3: round 5: the fused highway launches take `precision` (GEOGCN_GEMM_F32 or GEOGCN_GEMM_BF16X3) before their workspace --
+ * geogcn_gemm_dual_f32, geogcn_gemm_kcat_f32, geogcn_gemm_kcat_gated_f32, geogcn_gemm_kcat_gated_tanhbwd_f32 and the two
+ * _workspace_bytes functions that size it (as their last argument); GEOGCN_GEMM_BF16X3 now also applies to transA = 1. */
+#define GEOGCN_ABI_VERSION 3
 
 #define GEOGCN_E_NULL   (-1)   /* required pointer is NULL            */
 #define GEOGCN_E_SIZE   (-2)   /* negative / inconsistent size        */
@@ -198,10 +201,13 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  * `precision` selects how the products are formed (inputs, outputs and accumulation are fp32 in all):
  *   GEOGCN_GEMM_F32    v_mfma_f32_16x16x4_f32: an exact fp32 fma chain (the reference's sgemm class);
  *   GEOGCN_GEMM_BF16X3 each fp32 operand split exactly into three bf16 terms, six bf16 MFMA cross terms
- *                      per product: fp32-class accuracy (dropped terms O(2^-24 |a||b|)), 2.7x fewer MFMA
- *                      cycles -- the contraction becomes HBM-bound;
+ *                      per product: fp32-class accuracy (dropped terms O(2^-24 |a||b|); measured against fp64
+ *                      1.0-1.4e-7 sum|a.b| at K = 300, the exact kernel 1.4-1.5e-7), 2.7x fewer MFMA cycles.  It is a
+ *                      PERMISSION, not a promise: shapes no split-bf16 kernel takes run exact fp32 (csrc/gemm_x3.hip: whole
+ *                      rows of A for M >= 32,768, K <= 640, N <= 640; transA = 1 for 128 / 160 x 256 / 320 tiles; the
+ *                      staged kernel of csrc/gemm_bf16.hip for any other transA = 0 shape);
  *   GEOGCN_GEMM_BF16   one bf16 term per operand (BASELINE config 5: "bf16 H.W on MFMA, fp32 accumulate").
- * BF16X3 applies to transA = 0 only (transA = 1 then runs F32).  BF16 applies to both: transA = 1 (dW, the
+ * BF16 applies to both orientations: transA = 1 (dW, the
  * reduction over the node dimension) rounds both operands to bf16 on their way into LDS for outputs wider than
  * 160 columns (narrower ones run F32); split-K slabs and their ordered combination stay fp32.            */
 #define GEOGCN_GEMM_F32    0
@@ -242,11 +248,13 @@ int geogcn_gemm_panels_f32(int32_t transB, int64_t M, int64_t N, int64_t K, cons
  * transA = 0 with a workspace of geogcn_gemm_dual_workspace_bytes: shapes like the GCN's (M >= 32,768 rows, K padding to 256 or
  * 304, N0 and N1 filling 320-column passes) run on the whole-rows kernel -- 64 rows of A per block read once, the weights
  * re-laid in fragment order into `ws` -- with bit-identical results; without it (ws too small / NULL) on the staged kernel.  */
-size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K);
+/* `precision`: GEOGCN_GEMM_F32 (the exact kernels above) or GEOGCN_GEMM_BF16X3 (the same launches with fp32-class split-bf16
+ * products where csrc/gemm_x3.hip takes the shape -- see geogcn_gemm_f32 -- exact fp32 otherwise); the workspace is sized for it.  */
+size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, int32_t precision);
 int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda,
                          const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
                          float* C1, int64_t ldc1, const float* bias0, int32_t act0, const float* bias1, int32_t act1,
-                         void* ws, size_t ws_bytes, void* stream);
+                         int32_t precision, void* ws, size_t ws_bytes, void* stream);
 /* The forward pair of the bf16 configuration (BASELINE configs[4]) in one launch: C0 = A . B0 stored as bfloat16 (c0_bf16 = 1: the
  * operand geogcn_spmm_csr_bf16b gathers; pitch a multiple of 8, pads as zeros) or fp32, C1 = act1(A . B1 + bias1) in fp32 --
  * bf16 products, fp32 accumulation, A read and rounded once (bf16 whole-rows kernel, widths <= 640 with K padding to 256 / 320 /
@@ -260,10 +268,10 @@ int geogcn_gemm_dual_bf16(int64_t M, int64_t N0, int64_t N1, int64_t K, const fl
  * transB = 1: B0 is N x K0, B1 is N x K1 (the weights as stored); transB = 0: B0 is K0 x N, B1 is K1 x N.
  * One pass over C instead of two accumulating calls.  `ws` (geogcn_gemm_kcat_workspace_bytes; may be NULL / 0): as for the
  * dual launch -- with it, eligible shapes run on the whole-rows kernel (same accumulation order, bit-identical).      */
-size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1);
+size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, int32_t precision);
 int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                         float* C, int64_t ldc, int32_t accumulate, void* ws, size_t ws_bytes, void* stream);
+                         float* C, int64_t ldc, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream);
 
 /* The same with the block's CARRY gradient formed in the epilogue instead of being read from C:
  *   C[M x N] = A0 . op(B0) + A1 . op(B1) + G * (1 - T)          (G = gradient at the block's output, T = its gate; both M x N,
@@ -275,12 +283,13 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
  *   C = (A0 . op(B0) + A1 . op(B1) + G * (1 - T)) * (keep * scale) * (1 - Y^2)
  * i.e. dS0, the gradient at the pre-activation of the tanh layer whose dropped output feeds the block (gcnmodel.py:353,357:
  * dropout mask `keep` (bytes, pitch keepF, a multiple of 4) and 1/(1-p) = scale, Y = that layer's output) -- the pass
- * geogcn_act_bwd_f32 would make over dH.  Same bits as that pass (tested); the bias gradient is geogcn_colsum_f32 of C.          */
+ * geogcn_act_bwd_f32 would make over dH.  Same bits as that pass (tested); the bias gradient with the bits of
+ * geogcn_act_bwd_colsum_f32 is geogcn_colsum_rowblocks_f32 of C (its summation order), not geogcn_colsum_f32.                    */
 int geogcn_gemm_kcat_gated_tanhbwd_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                                        const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                                        float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
-                                       const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, void* ws,
-                                       size_t ws_bytes, void* stream);
+                                       const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, int32_t precision,
+                                       void* ws, size_t ws_bytes, void* stream);
 /* ... and for ONE product: C[M x N] = A . op(B) + G * (1 - T) in any `precision` (the bf16 configuration forms dH_in with two
  * calls: this one, then an accumulating geogcn_gemm_f32).  ws as for geogcn_gemm_f32 (geogcn_gemm_workspace_bytes).             */
 int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
@@ -288,8 +297,12 @@ int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const
                           int32_t precision, void* ws, size_t ws_bytes, void* stream);
 int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                                const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
-                               float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, void* ws,
-                               size_t ws_bytes, void* stream);
+                               float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, int32_t precision,
+                               void* ws, size_t ws_bytes, void* stream);
+/* Test hook (not part of the reference boundary): bytes one buffer descriptor is taken to bound in the A^T . B kernels that end a
+ * split-K slab with the descriptor (<= 0 restores 2^31 - 1); a slab beyond it runs on the staged kernel.  tests/ lower it to reach
+ * that fallback with small operands.                                                                                              */
+void geogcn_debug_set_tn_slab_limit(int64_t bytes);
 
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */

@@ -70,7 +70,7 @@ def spmm(A, B, out=None, bias=None, act=ACT_NONE, F=None, out_col0=0):
     return out
 
 
-def spmm_t(x, G, out=None):
+def spmm_t(x, G, out=None, precision=None):
     return spmm(x.bwd, G, out=out)
 
 
@@ -116,7 +116,7 @@ def gemm(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, ac
 GEMM_PRECISION = 'f32'
 
 
-def gemm_dual(A, B0, B1, out0=None, out1=None, transA=False, bias0=None, act0=ACT_NONE, bias1=None, act1=ACT_NONE):
+def gemm_dual(A, B0, B1, out0=None, out1=None, transA=False, bias0=None, act0=ACT_NONE, bias1=None, act1=ACT_NONE, precision=None):
     return (gemm(A, B0, out=out0, transA=transA, bias=bias0, act=act0),
             gemm(A, B1, out=out1, transA=transA, bias=bias1, act=act1))
 
@@ -135,11 +135,11 @@ def gemm_gated_native(n, F, precision=None):
     return True
 
 
-def kcat_gated_native(n, F):
+def kcat_gated_native(n, F, precision=None):
     return True              # (the double takes the gated form at every size: the host logic is what it exercises)
 
 
-def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, gate_carry=None, tanh_bwd=None):
+def gemm_kcat(A0, B0, A1, B1, out=None, transB=False, accumulate=False, gate_carry=None, tanh_bwd=None, precision=None):
     if tanh_bwd is not None:
         Y, keep, scale = tanh_bwd
         tmp = gemm_kcat(A0, B0, A1, B1, transB=transB, gate_carry=gate_carry)

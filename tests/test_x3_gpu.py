@@ -1,0 +1,201 @@
+"""The split-bf16 ("bf16x3") whole-rows and A^T.B kernels (csrc/gemm_x3.hip) through the C ABI against fp64 on the same seeded inputs,
+held to the SAME envelope as the exact fp32 MFMA kernels (2e-6 sum|a.b|, tests/test_kernels_gpu.py), and against the exact kernels'
+outputs.  Sizes sit just above the 32,768-row threshold from which the whole-rows kernels are taken (run on the MI355X: pytest -m gpu)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from geographconv_amd import ops
+    ops.require_gpu()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.RandomState(seed).randn(*shape) * scale).astype(np.float32)
+
+
+def _wide_range(shape, seed):
+    """Values whose magnitudes span 12 decades (gradients next to activations): the split must be exact at every exponent."""
+    r = np.random.RandomState(seed)
+    return (r.randn(*shape) * 10.0 ** r.uniform(-9, 3, size=shape)).astype(np.float32)
+
+
+ENV = 2e-6        # the fp32 kernels' envelope: |C - C64| <= ENV * (|A| . |B|) + tiny
+
+
+def _check(got, ref, mag, what, extra=0.0):
+    err = np.abs(got.astype(np.float64) - ref)
+    bound = ENV * mag + 1e-30 + extra
+    bad = err > bound
+    assert not bad.any(), "%s: %d entries beyond the fp32 envelope, worst %.3g x" % (what, bad.sum(), (err / bound).max())
+
+
+def _takes_x3(M, N, K, transB=False):
+    """Is this single product one the split-bf16 whole-rows kernel takes?  (its workspace differs from the staged kernel's)"""
+    from geographconv_amd import _ffi
+    lib = _ffi.lib()
+    return lib.geogcn_gemm_workspace_bytes(0, int(transB), M, N, K, _ffi.GEMM_BF16X3) > 3 * ((K + 31) // 32 * 32) * N * 2
+
+
+M0 = 33000          # >= 32,768 rows: the whole-rows kernels; not a multiple of 64 (a ragged last tile)
+
+
+@pytest.mark.parametrize("N,K", [(300, 300), (256, 300), (300, 256), (600, 300), (129, 300), (300, 129), (640, 608), (100, 300)])
+def test_x3_rows_single_products(dev, N, K):
+    from geographconv_amd import ops
+    A = _wide_range((M0, K), 1)
+    B = _rand((K, N), 2, 0.1)
+    bias = _rand((N,), 3)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+    dBt = ops.DMat.from_numpy(np.ascontiguousarray(B.T), dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(N) - N))).to(dev)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    for kw in (dict(), dict(transB=True)):
+        Bop = dBt if kw else dB
+        got = ops.gemm(dA, Bop, precision='bf16x3', **kw)
+        _check(got.numpy(), ref, mag, 'A.B%s %dx%d' % ('^T' if kw else '', N, K))
+        assert np.array_equal(got.numpy(), ops.gemm(dA, Bop, precision='bf16x3', **kw).numpy())          # run to run
+        # pad columns [N, ld) written as zeros (geogcn.h convention)
+        full = got.t.cpu().numpy().reshape(M0, got.ld)
+        assert not full[:, N:ops.pad4(N)].any()
+    got = ops.gemm(dA, dB, bias=db, act=ops.ACT_TANH, precision='bf16x3').numpy()
+    want = np.tanh(ref + bias)
+    assert np.all(np.abs(got - want) <= ENV * mag + 2e-6)
+    got = ops.gemm(dA, dB, bias=db, act=ops.ACT_SIGMOID, precision='bf16x3').numpy()
+    assert np.all(np.abs(got - 1 / (1 + np.exp(-(ref + bias)))) <= ENV * mag + 2e-6)
+    C0 = _rand((M0, N), 4)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm(dA, dB, out=dC, accumulate=True, precision='bf16x3')
+    _check(dC.numpy(), ref + C0, mag, 'accumulate', extra=2e-7 * np.abs(ref + C0))
+
+
+def test_x3_rows_shapes_really_take_the_kernel(dev):
+    """(the tests above would pass on the staged kernel too: make sure the TwitterUS shapes are routed to the whole-rows kernel)"""
+    for (N, K, tb) in [(300, 300, 0), (256, 300, 0), (300, 256, 1), (300, 300, 1)]:
+        assert _takes_x3(440000, N, K, bool(tb)), (N, K, tb)
+    assert not _takes_x3(9475, 300, 300)            # CMU size: the staged split-bf16 kernel
+
+
+@pytest.mark.parametrize("N0,N1,K", [(300, 300, 300), (256, 300, 300), (300, 129, 256), (600, 300, 300)])
+def test_x3_rows_dual(dev, N0, N1, K):
+    """The highway block's forward pair in one launch: (Z, T) = (H . Wh, sigmoid(H . Wt + bt))."""
+    from geographconv_amd import ops
+    A = _rand((M0, K), 5)
+    B0, B1 = _rand((K, N0), 6, 0.1), _rand((K, N1), 7, 0.1)
+    b1 = _rand((N1,), 8)
+    dA, d0, d1 = (ops.DMat.from_numpy(x, dev) for x in (A, B0, B1))
+    db1 = torch.from_numpy(np.pad(b1, (0, ops.pad4(N1) - N1))).to(dev)
+    z = ops.DMat.empty(M0, N0, dev, ld=ops.gather_ld(N0))
+    Z, T = ops.gemm_dual(dA, d0, d1, out0=z, bias1=db1, act1=ops.ACT_SIGMOID, precision='bf16x3')
+    A64 = A.astype(np.float64)
+    r0, r1 = A64 @ B0, A64 @ B1
+    _check(Z.numpy(), r0, np.abs(A64) @ np.abs(B0), 'dual Z')
+    assert np.all(np.abs(T.numpy() - 1 / (1 + np.exp(-(r1 + b1)))) <= ENV * (np.abs(A64) @ np.abs(B1)) + 2e-6)
+    # each half is the single product of the same precision, bit for bit (same k order, same epilogue) -- where the pair runs on the
+    # split-bf16 kernel at all (a segment it does not take sends the whole launch to the exact kernels)
+    if _takes_x3(M0, N0, K) and _takes_x3(M0, N1, K):
+        assert np.array_equal(Z.numpy(), ops.gemm(dA, d0, precision='bf16x3').numpy())
+    # ... and within the envelope of the exact launch
+    Ze, Te = ops.gemm_dual(dA, d0, d1, bias1=db1, act1=ops.ACT_SIGMOID, precision='f32')
+    assert np.all(np.abs(Z.numpy() - Ze.numpy()) <= 2 * ENV * (np.abs(A64) @ np.abs(B0)) + 1e-30)
+    assert np.abs(T.numpy() - Te.numpy()).max() <= 1e-5
+
+
+@pytest.mark.parametrize("N,K0,K1", [(300, 300, 300), (300, 256, 300), (256, 300, 300), (129, 300, 129)])
+def test_x3_rows_kcat_and_epilogues(dev, N, K0, K1):
+    """dH = dZ . Wh^T + dU . Wt^T: plain, accumulating, with the carry gradient, with the dropout + tanh gradient on top."""
+    from geographconv_amd import ops
+    A0, A1 = _wide_range((M0, K0), 9), _rand((M0, K1), 10)
+    W0, W1 = _rand((N, K0), 11, 0.1), _rand((N, K1), 12, 0.1)           # weights as stored: transB
+    d = {k: ops.DMat.from_numpy(v, dev) for k, v in dict(A0=A0, A1=A1, W0=W0, W1=W1).items()}
+    ref = A0.astype(np.float64) @ W0.T.astype(np.float64) + A1.astype(np.float64) @ W1.T.astype(np.float64)
+    mag = np.abs(A0).astype(np.float64) @ np.abs(W0.T) + np.abs(A1).astype(np.float64) @ np.abs(W1.T)
+    got = ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], transB=True, precision='bf16x3')
+    _check(got.numpy(), ref, mag, 'kcat')
+    C0 = _rand((M0, N), 13)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], out=dC, transB=True, accumulate=True, precision='bf16x3')
+    _check(dC.numpy(), ref + C0, mag, 'kcat accumulate', extra=2e-7 * np.abs(ref + C0))
+    # carry gradient G * (1 - T) in the epilogue: the stored carry + the accumulating launch, bit for bit
+    G, T = _rand((M0, N), 14), np.random.RandomState(15).rand(M0, N).astype(np.float32)
+    dG, dT = ops.DMat.from_numpy(G, dev), ops.DMat.from_numpy(T, dev)
+    carry = ops.GateCarry(dG, dT)
+    fused = ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], transB=True, gate_carry=carry, precision='bf16x3')
+    two = carry.dense()
+    ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], out=two, transB=True, accumulate=True, precision='bf16x3')
+    assert np.array_equal(fused.numpy(), two.numpy())
+    _check(fused.numpy(), ref + G.astype(np.float64) * (1 - T), mag, 'kcat + carry', extra=3e-7 * (np.abs(ref) + np.abs(G)))
+    if N % 4 == 0:
+        # ... times keep * scale * (1 - Y^2): act_bwd over the gated result, bit for bit
+        Y = np.tanh(_rand((M0, N), 16))
+        keep = (np.random.RandomState(17).rand(M0, N) < 0.7).astype(np.uint8)
+        dY, dk = ops.DMat.from_numpy(Y, dev), torch.from_numpy(keep).to(dev)
+        out = ops.DMat.empty(M0, N, dev, ld=ops.gather_ld(N))
+        ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], out=out, transB=True, gate_carry=carry, tanh_bwd=(dY, dk, 1 / 0.7), precision='bf16x3')
+        want = ops.act_bwd(fused, dY, ops.ACT_TANH, keep_mask=dk, scale=1 / 0.7)
+        assert np.array_equal(out.numpy(), want.numpy())
+    # one product with the carry (the separate launches of the reverse sweep)
+    one = ops.gemm(d['A0'], d['W0'], transB=True, precision='bf16x3', gate_carry=carry)
+    r1 = A0.astype(np.float64) @ W0.T.astype(np.float64)
+    _check(one.numpy(), r1 + G.astype(np.float64) * (1 - T), np.abs(A0).astype(np.float64) @ np.abs(W0.T), 'gated single',
+           extra=3e-7 * (np.abs(r1) + np.abs(G)))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 300, 70000), (300, 256, 50001), (256, 300, 40000), (129, 300, 33333), (300, 600, 36000)])
+def test_x3_tn(dev, M, N, K):
+    """dW = H^T . dZ over the node dimension (split-K slabs combined in slab order)."""
+    from geographconv_amd import ops
+    A, B = _rand((K, M), 18), _wide_range((K, N), 19)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+    ref = A.T.astype(np.float64) @ B.astype(np.float64)
+    mag = np.abs(A.T).astype(np.float64) @ np.abs(B).astype(np.float64)
+    got = ops.gemm(dA, dB, transA=True, precision='bf16x3')
+    _check(got.numpy(), ref, mag, 'A^T.B')
+    assert np.array_equal(got.numpy(), ops.gemm(dA, dB, transA=True, precision='bf16x3').numpy())
+    C0 = _rand((M, N), 20)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm(dA, dB, out=dC, transA=True, accumulate=True, precision='bf16x3')
+    _check(dC.numpy(), ref + C0, mag, 'A^T.B accumulate', extra=2e-7 * np.abs(ref + C0))
+
+
+def test_x3_tn_dual(dev):
+    """(dWh, dWt) = H^T . [dZ | dU] in one launch."""
+    from geographconv_amd import ops
+    K, M, N0, N1 = 70000, 300, 300, 300
+    A, B0, B1 = _rand((K, M), 21), _rand((K, N0), 22, 1e-3), _wide_range((K, N1), 23)
+    dA, d0, d1 = (ops.DMat.from_numpy(x, dev) for x in (A, B0, B1))
+    g0, g1 = ops.gemm_dual(dA, d0, d1, transA=True, precision='bf16x3')
+    A64 = A.T.astype(np.float64)
+    _check(g0.numpy(), A64 @ B0, np.abs(A64) @ np.abs(B0), 'dual dW0')
+    _check(g1.numpy(), A64 @ B1, np.abs(A64) @ np.abs(B1).astype(np.float64), 'dual dW1')
+    # (the single launch cuts the node dimension into other slabs: equal to rounding, not bit for bit)
+    one = ops.gemm(dA, d0, transA=True, precision='bf16x3').numpy()
+    assert np.all(np.abs(g0.numpy() - one) <= 2 * ENV * (np.abs(A64) @ np.abs(B0)))
+    assert np.array_equal(g0.numpy(), ops.gemm_dual(dA, d0, d1, transA=True, precision='bf16x3')[0].numpy())          # run to run
+
+
+def test_tn_slab_limit_falls_back_to_the_staged_kernel(dev):
+    """A split-K slab that does not fit one buffer descriptor must not run on the kernels that end the slab with the descriptor
+    (the guard was taken on the slab before the slab-count cap enlarged it).  The limit is lowered through the test hook
+    so that small operands reach the fallback; results must not change beyond rounding."""
+    from geographconv_amd import _ffi, ops
+    K, M, N = 70000, 300, 300
+    A, B = _rand((K, M), 24), _rand((K, N), 25)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+    ref = A.T.astype(np.float64) @ B.astype(np.float64)
+    mag = np.abs(A.T).astype(np.float64) @ np.abs(B).astype(np.float64)
+    lib = _ffi.lib()
+    try:
+        lib.geogcn_debug_set_tn_slab_limit(64 * 1024)
+        for prec in ('f32', 'bf16x3'):
+            _check(ops.gemm(dA, dB, transA=True, precision=prec).numpy(), ref, mag, 'staged fallback ' + prec)
+    finally:
+        lib.geogcn_debug_set_tn_slab_limit(0)
+    _check(ops.gemm(dA, dB, transA=True, precision='f32').numpy(), ref, mag, 'direct')
