@@ -235,12 +235,22 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
 
     def mfma(name, key, flops, operand_bytes, prec, note=''):
         if key in ms:
-            peak = MFMA_BF16_PEAK_TFLOPS if prec == 'bf16' else MFMA_F32_PEAK_TFLOPS
-            out.append({"kernel": name, "bound": "mfma", "precision": prec, "ms": ms[key], "flops": flops, "achieved": flops / ms[key] / 1e9,
-                        "peak": peak, "unit": "TFLOP/s", "frac": flops / ms[key] / 1e9 / peak,
-                        "operand_bytes": operand_bytes, "achieved_hbm": operand_bytes / ms[key] / 1e6, "peak_hbm": HBM_PEAK_GBPS,
-                        "unit_hbm": "GB/s", "frac_hbm": operand_bytes / ms[key] / 1e6 / HBM_PEAK_GBPS,
-                        "calls_per_step": calls[key], "how": how % (calls[key] * n_steps, n_steps), "note": note})
+            # split-bf16 products issue SIX bf16 MFMA terms per product: priced with that work against the bf16 peak; the useful
+            # (fp32-equivalent) rate stands beside it
+            work = 6.0 * flops if prec == 'bf16x3' else flops
+            peak = MFMA_F32_PEAK_TFLOPS if prec == 'f32' else MFMA_BF16_PEAK_TFLOPS
+            e = {"kernel": name, "bound": "mfma", "precision": prec, "ms": ms[key], "flops": flops, "achieved": work / ms[key] / 1e9,
+                 "peak": peak, "unit": "TFLOP/s", "frac": work / ms[key] / 1e9 / peak,
+                 "operand_bytes": operand_bytes, "achieved_hbm": operand_bytes / ms[key] / 1e6, "peak_hbm": HBM_PEAK_GBPS,
+                 "unit_hbm": "GB/s", "frac_hbm": operand_bytes / ms[key] / 1e6 / HBM_PEAK_GBPS,
+                 "calls_per_step": calls[key], "how": how % (calls[key] * n_steps, n_steps), "note": note}
+            if prec == 'bf16x3':
+                e["mfma_flops_issued"] = work
+                e["achieved_fp32_equivalent"] = flops / ms[key] / 1e9
+                e["note"] = (note + "; " if note else "") + ("achieved / frac = six bf16 MFMA terms per product against the dense bf16 peak (the socket runs "
+                                                             "these kernels at its 1.4 kW power cap, ~1.97 GHz: profiles/r05_x3_rows_clocks.txt); "
+                                                             "achieved_fp32_equivalent = useful flops / time")
+            out.append(e)
     X, A = g['X'], g['A']
     nnzX, V, nnz = X.fwd.nnz, X.shape[1], A.fwd.nnz
     xw = 8 * nnzX + 4 * (N + 1) + 4 * V * F + 4 * N * F
@@ -254,19 +264,22 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     fl = 2.0 * N * F * F
     wb = 4 * F * F                                 # one weight matrix
     act = 4 * N * F                                # one N x F fp32 activation
-    mfma("H . [Wh | Wt], sigmoid on the gate half  (gemm_rows_kernel: 64 whole rows of A per block, dual)", 'gemm_dual_nn', 2 * fl,
-         3 * act + 2 * wb, 'f32')
-    mfma("H^T . [dZ | dU]  (gemm_tn_direct_kernel: fragments straight into registers, no LDS; split-K + ordered combine)", 'gemm_dual_tn', 2 * fl, 3 * act + 2 * wb, 'f32')
     from geographconv_amd import tuning as _tuning
+    fp = 'bf16x3' if precision == 'bf16x3' else 'f32'        # precision of the fused highway launches
+    rows = "x3_rows_kernel: 64 rows of A per block in K chunks, three bf16 planes in LDS" if fp == 'bf16x3' else "gemm_rows_kernel: 64 whole rows of A per block"
+    mfma("H . [Wh | Wt], sigmoid on the gate half  (%s, dual)" % rows, 'gemm_dual_nn', 2 * fl, 3 * act + 2 * wb, fp)
+    mfma("H^T . [dZ | dU]  (%s; split-K + ordered combine)" % (
+        "x3_tn_kernel: operands transposed + split into three bf16 planes on their way into LDS" if fp == 'bf16x3'
+        else "gemm_tn_direct_kernel: fragments straight into registers, no LDS"), 'gemm_dual_tn', 2 * fl, 3 * act + 2 * wb, fp)
     if _tuning.FUSE_GATE_CARRY:
-        mfma("dH = dZ . Wh^T + dU . Wt^T + G (1 - T)  (gemm_rows_kernel, two A operands into one accumulator, the block's carry "
-             "gradient formed in the epilogue)", 'gemm_kcat', 2 * fl, 5 * act + 2 * wb, 'f32',
+        mfma("dH = dZ . Wh^T + dU . Wt^T + G (1 - T)  (%s, two A operands into one accumulator, the block's carry "
+             "gradient formed in the epilogue)" % rows.split(':')[0], 'gemm_kcat', 2 * fl, 5 * act + 2 * wb, fp,
              "operand bytes: dZ, dU, G, T read, dH written (highway_bwd does not store the carry); the median is over both blocks' calls"
              + ("; the first block's also applies the dropout mask and the tanh gradient of the sparse-input layer (reads H0 and the mask)"
                 if _tuning.FUSE_ACT_BWD else ""))
     else:
-        mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (gemm_rows_kernel, two A operands into one accumulator)", 'gemm_kcat', 2 * fl,
-             4 * act + 2 * wb, 'f32', "operand bytes: dZ, dU read, the carry read and dH written")
+        mfma("dH = dZ . Wh^T + dU . Wt^T [+ carry]  (%s, two A operands into one accumulator)" % rows.split(':')[0], 'gemm_kcat', 2 * fl,
+             4 * act + 2 * wb, fp, "operand bytes: dZ, dU read, the carry read and dH written")
     # single products (every GEMM of the bf16 / bf16x3 configurations, the output layer's in all): label = shape and form
     for key in sorted(k for k in ms if k.startswith('gemm:')):
         _, form, prec, M_, N_, K_, cb, acc = key.split(':')
@@ -276,20 +289,23 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
         opb = 4 * (M_ * K_ + K_ * N_) + cb * M_ * N_ * (2 if acc else 1)
         kern = {'f32': 'gemm_tn_direct_kernel' if form == 'tn' else
                        ('gemm_rows_kernel' if (form == 'nt' or N_ in range(193, 257) or N_ in range(449, 513)) and M_ >= 32768 and N_ <= 640
-                        and -(-K_ // 16) * 16 in (256, 304) else 'gemm_kernel'), 'bf16x3': 'gemm_bf16_kernel<NS=3>', 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
+                        and -(-K_ // 16) * 16 in (256, 304) else 'gemm_kernel'),
+                'bf16x3': ('x3_tn_kernel' if form == 'tn' and N_ > 160 else 'x3_rows_kernel' if form != 'tn' and M_ >= 32768 and N_ <= 640 and K_ <= 640
+                           else 'exact fp32 kernel'),
+                'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
         mfma("%s product %d x %d x %d (%s; C %s%s)" % ({'nn': 'A . B', 'nt': 'A . B^T', 'tn': 'A^T . B'}[form], M_, N_, K_, kern,
                                                          'bf16' if cb == 2 else 'fp32', ', accumulating' if acc else ''),
-             key, 2.0 * M_ * N_ * K_, opb, 'bf16' if prec == 'bf16' else 'f32',
-             "bf16x3 is priced against the fp32 peak (its result is fp32-class)" if prec == 'bf16x3' else '')
+             key, 2.0 * M_ * N_ * K_, opb, prec if kern != 'exact fp32 kernel' else 'f32')
     return out
 
 
 def baseline_config(shape, hid, precision, world):
     """Which entry of BASELINE.json `configs` this invocation is -- or that it is none of them."""
     hid = list(hid)
-    if shape == 'cmu' and hid == [300, 300, 300] and precision == 'f32' and world == 1:
+    # (configs[1..3] name an fp32 model: 'f32' = exact fp32 products, 'bf16x3' = fp32-class split-bf16 products -- config.gemm says which)
+    if shape == 'cmu' and hid == [300, 300, 300] and precision in ('f32', 'bf16x3') and world == 1:
         return 'BASELINE configs[1]'
-    if shape == 'twus' and hid == [300, 300, 300] and precision == 'f32':
+    if shape == 'twus' and hid == [300, 300, 300] and precision in ('f32', 'bf16x3'):
         return 'BASELINE configs[2]' if world == 1 else 'BASELINE configs[3]'
     if shape == 'twus' and hid == [600] * 6 and precision == 'bf16':
         return 'BASELINE configs[4]' + ('' if world == 8 else ' on %d GPU%s instead of 8' % (world, '' if world == 1 else 's'))
@@ -377,6 +393,118 @@ def partition_check(make_clf, comms, X, A, Y, tr, dev, rank, n_steps=2):
     return res
 
 
+def layer_block(g, N, nnz, F, device, precision, reps=50):
+    """SURVEY.md section 8d (ii) on the GPU: ONE ConvolutionDenseLayer2 forward + backward (300 -> 300; gcnmodel.py:114-136 and what
+    autodiff derives from it) and ONE highway block (gcnmodel.py:268-288) on the full graph, the launches the model makes for them,
+    event-timed over `reps` repetitions after 3 warm-up ones; edges/s = nnz(A_hat) / time of one forward + backward."""
+    import torch
+    from geographconv_amd import ops
+    A = g['A']
+    rng = np.random.RandomState(11)
+
+    def dm(scale=1.0):
+        return ops.DMat.from_numpy((rng.randn(N, F) * scale).astype(np.float32), device)
+    H, G = dm(), dm(1e-3)
+    W = ops.DMat.from_numpy((rng.randn(F, F) * 0.05).astype(np.float32), device)
+    W2 = ops.DMat.from_numpy((rng.randn(F, F) * 0.05).astype(np.float32), device)
+    b = torch.zeros(ops.pad4(F), device=device)
+    db, db2 = torch.zeros_like(b), torch.zeros_like(b)
+    dW, dW2 = W.like(), W2.like()
+    Z = ops.DMat.empty(N, F, device, ld=ops.gather_ld(F))
+
+    def conv_layer():
+        ops.gemm(H, W, out=Z, precision=precision)                                  # Z = H . W
+        S = ops.spmm(A.fwd, Z, bias=b, act=ops.ACT_TANH)                            # S = tanh(A_hat . Z + b)
+        dS = ops.act_bwd_colsum(G, S, ops.ACT_TANH, db, out=ops.DMat.empty(N, F, device, ld=ops.gather_ld(F)))
+        dZ = ops.spmm(A.bwd, dS)                                                    # A_hat^T . dS
+        ops.gemm(H, dZ, out=dW, transA=True, precision=precision)                   # dW = H^T . dZ
+        return ops.gemm(dZ, W, transB=True, precision=precision)                    # dH = dZ . W^T
+
+    def highway_block():
+        _, T = ops.gemm_dual(H, W, W2, out0=Z, bias1=b, act1=ops.ACT_SIGMOID, precision=precision)      # Z = H . Wh, T = sigmoid(H . Wt + bt)
+        Hc, Hout = ops.spmm_highway(A.fwd, Z, b, T, H)                              # Hc = tanh(A_hat . Z + bh), Hout = T Hc + (1 - T) H
+        dS, dU, _ = ops.highway_bwd(G, T, Hc, H, dbS=db, dbU=db2, carry=False)
+        dZ = ops.spmm(A.bwd, dS)
+        ops.gemm_dual(H, dZ, dU, out0=dW, out1=dW2, transA=True, precision=precision)
+        return ops.gemm_kcat(dZ, W, dU, W2, transB=True, gate_carry=ops.GateCarry(G, T), precision=precision)
+
+    out = {"how": "the launches GraphConv makes for the layer, forward then backward, event-timed over %d repetitions after 3 warm-up "
+                  "ones on the full graph (N = %d, %d -> %d, GEMM precision %s); edges/s = nnz(A_hat) / time" % (reps, N, F, F, precision)}
+    for name, fn in (("conv_layer_fwd_bwd", conv_layer), ("highway_block_fwd_bwd", highway_block)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"ms": ms, "value": nnz / ms * 1e3, "unit": "edges/s"}
+    out["conv_layer_fwd_bwd"]["what"] = ("ConvolutionDenseLayer2 (gcnmodel.py:114-136): Z = H.W, S = tanh(A_hat.Z + b); backward: dS = G (1 - S^2) "
+                                         "+ bias gradient, dZ = A_hat^T.dS, dW = H^T.dZ, dH = dZ.W^T")
+    out["highway_block_fwd_bwd"]["what"] = ("highway_dense (gcnmodel.py:268-288): (Z, T) = (H.Wh, sigmoid(H.Wt + bt)), Hout = T tanh(A_hat.Z + bh) + (1 - T) H; "
+                                            "backward: the gating layer's three gradients + both bias gradients, dZ = A_hat^T.dS, (dWh, dWt) = H^T.[dZ | dU], "
+                                            "dH = dZ.Wh^T + dU.Wt^T + G (1 - T)")
+    return out
+
+
+def gather_ceiling(table_mb=512, row_bytes=1280):
+    """The rate at which this GPU can gather `row_bytes`-byte rows from a table beyond L2 (tools/micro/gather_bw.hip, built by
+    __graft_entry__.build() into tools/micro/bin/): what a graph product on the pinned graph -- half of whose column references
+    are uniformly random -- can move at most.  Measured live; None when the helper is not built."""
+    import subprocess
+    exe = os.path.join(ROOT, 'tools', 'micro', 'bin', 'gather_bw')
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, '--json', str(table_mb), str(row_bytes)], capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        d["source"] = "tools/micro/gather_bw.hip run by this invocation (16-lane groups, %d-byte rows drawn uniformly from a %d MB table)" % (row_bytes, table_mb)
+        return d
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def _git_commit():
+    import subprocess
+    try:
+        return subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+class Watchdog:
+    """Per-scheme wall-clock guard of an N > 1 invocation: a collective that never returns cannot be interrupted from Python, so when
+    the timer fires rank 0 prints the line it has (the schemes already timed, the guarded one reported as an error) and EVERY rank
+    leaves with os._exit -- the headline survives a hang in a scheme timed after it."""
+
+    def __init__(self, rank):
+        self.rank, self.timer, self.on_fire = rank, None, None
+
+    def arm(self, seconds, what, on_fire):
+        import threading
+        self.disarm()
+
+        def fire():
+            log('[bench] rank %d: %s did not finish within %.0f s: leaving with what has been measured' % (self.rank, what, seconds))
+            try:
+                if self.rank == 0:
+                    on_fire("timeout: not finished within %.0f s (wall-clock guard)" % seconds)
+            finally:
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(0)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -387,14 +515,17 @@ def main():
                     help='node renumbering applied on the device side (outputs stay in original ids)')
     ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
     ap.add_argument('--dropout', type=float, default=0.5)
-    ap.add_argument('--gemm-precision', default='f32', choices=['f32', 'bf16x3', 'bf16'],
-                    help='f32 = exact fp32 MFMA (the headline configuration)')
+    ap.add_argument('--gemm-precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+                    help="default: geographconv_amd.tuning.GEMM_PRECISION (bf16x3 = fp32-class split-bf16 products where a kernel takes the "
+                         "shape, exact fp32 elsewhere); f32 = the exact fp32 MFMA everywhere")
     ap.add_argument('--cpu-sample', default='step', choices=['step', 'layer', 'none'])
     ap.add_argument('--exchange', default='auto', choices=['auto', 'a2a', 'allgather', 'agpipe', 'halo'],
-                    help='N > 1: exchange scheme whose time is `value` (auto: all-gather at 2 ranks, a2a from 3); the other '
-                         'scheme is timed too and reported under `alt`')
-    ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the `value` scheme')
+                    help="N > 1: the exchange scheme timed FIRST (auto: the north_star's all-gather); the others are timed after it, each "
+                         "behind its own try/except and wall-clock guard, and `value` is the fastest that finished")
+    ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the first scheme')
     ap.add_argument('--no-check', action='store_true', help='N > 1: skip the partition_check block')
+    ap.add_argument('--no-extras', action='store_true', help='N = 1: skip alt_exact_f32, the layer block and the gather ceiling')
+    ap.add_argument('--scheme-timeout', type=float, default=900.0, help='N > 1: wall-clock guard per scheme / check, seconds')
     ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B aid: override an attribute of geographconv_amd/tuning.py for this run (e.g. --set FUSE_CARRY=0); '
                          'recorded in config.tuning_overrides -- a line with overrides is not the headline configuration')
@@ -415,6 +546,7 @@ def main():
         new = (val not in ('0', 'false', 'False', '')) if isinstance(old, bool) else type(old)(val)
         setattr(tuning, name, new)
         overrides[name] = new
+    precision = args.gemm_precision or ops.GEMM_PRECISION
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -426,9 +558,9 @@ def main():
     # ranks share cuda:0 and the collectives are staged through the host and gloo (geographconv_amd/dist.py)
     from geographconv_amd import dist as gdist
     staged = gdist.backend_name() == 'staged-gloo'
-    comm = None
     force_dist = os.environ.get('GEOGCN_BENCH_FORCE_DIST') == '1'      # exercise the partitioned path at world 1
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
@@ -437,24 +569,41 @@ def main():
     else:
         torch.cuda.set_device(local)
         device = torch.device('cuda', local)
+    # test hook: GEOGCN_BENCH_INJECT="a2a:raise;agpipe:hang" makes the named scheme fail that way on every rank (tests/test_dist_gpu.py)
+    inject = dict(kv.split(':') for kv in os.environ.get('GEOGCN_BENCH_INJECT', '').split(';') if ':' in kv)
+
+    # who is here: world size as the process group sees it, the collective library's version, every rank's device
+    dist_info = None
+    if distributed:
+        import torch.distributed as tdist
+        dist_info = {"world_size_seen": tdist.get_world_size(), "torch_backend": tdist.get_backend(), "staged": staged}
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            mine = {"rank": rank, "local_rank": local, "device": str(device), "name": pr.name,
+                    "pci": "%04x:%02x:%02x" % (getattr(pr, 'pci_domain_id', 0), getattr(pr, 'pci_bus_id', 0), getattr(pr, 'pci_device_id', 0))}
+            everyone = [None] * tdist.get_world_size()
+            tdist.all_gather_object(everyone, mine)
+            dist_info["ranks"] = everyone
+        except Exception as e:
+            dist_info["ranks_error"] = repr(e)
+        try:
+            dist_info["rccl_version"] = '.'.join(map(str, torch.cuda.nccl.version()))
+        except Exception as e:
+            dist_info["rccl_version"] = repr(e)
 
     t0 = time.time()
     A, X, Y, (tr, dev, te), C = synth.make_graph(args.shape)
     N, nnz = A.shape[0], int(A.nnz)
     if rank == 0:
         log('[bench] %s graph generated in %.1fs: N=%d nnz(A)=%d nnz(X)=%d' % (args.shape, time.time() - t0, N, nnz, X.nnz))
-    alt_comm = pipe_comm = None
-    if world > 1 or force_dist:
-        from geographconv_amd.dist import TorchDistComm
-        comm = TorchDistComm(N, device, exchange=None if args.exchange == 'auto' else args.exchange)
-        if world > 1 and not args.no_alt:
-            alt_comm = TorchDistComm(N, device, exchange='allgather' if comm.exchange == 'a2a' else 'a2a')
-            # ... and the north_star's scheme with its all-gather pipelined by feature slabs
-            pipe_comm = TorchDistComm(N, device, exchange='agpipe') if comm.exchange != 'agpipe' else None
 
-    def make_clf(c, dropout):
+    def make_comm(exchange):
+        from geographconv_amd.dist import TorchDistComm
+        return TorchDistComm(N, device, exchange=exchange)
+
+    def make_clf(c, dropout, prec=None):
         m = GraphConv(X.shape[1], C, args.hid, 0.0, dropout, highway=True, device=device, comm=c,
-                      gemm_precision=args.gemm_precision, reorder=args.reorder)
+                      gemm_precision=prec or precision, reorder=args.reorder)
         m.build_model(A, seed=77)
         m._force_dist = force_dist and c is not None
         return m
@@ -478,76 +627,41 @@ def main():
             t = float(tt.item())
         return t
 
-    bf16_operand = args.gemm_precision == 'bf16'
+    bf16_operand = precision == 'bf16'
+    n_conv = len(args.hid)
 
-    def run_scheme(c):
-        m = make_clf(c, args.dropout)
+    def run_scheme(c, prec=None):
+        """W warm-up + K timed steps of one configuration -> everything the line needs from it."""
+        how = inject.get(c.exchange if c is not None else 'single')
+        if how == 'raise':
+            raise RuntimeError("injected failure (GEOGCN_BENCH_INJECT) in scheme %s" % c.exchange)
+        if how == 'hang':
+            while True:
+                time.sleep(1.0)
+        m = make_clf(c, args.dropout, prec)
         # the dense operand of the timed SpMM: F = hid at one GPU; one feature panel per rank under the a2a scheme
         F = args.hid[-1]
         if c is not None and c.exchange == 'a2a':
             F = c.panel_width(args.hid[-1], bf16_operand)
         g = m._device_graph(X, A)
         t, step_ms, kern_ms, last = timed_region(m, lambda: m.f_train(X, y_tr, y_dev, A, tr, dev), args.steps, args.warmup, barrier, F, g)
-        return m, g, F, reduce_max(t), step_ms, kern_ms, last
+        return {"comm": c, "clf": m, "g": g, "F": F, "t": reduce_max(t), "step_ms": step_ms, "kern_ms": kern_ms, "last": last}
 
-    clf, g0, F_spmm, t, step_ms, kern_ms, last = run_scheme(comm)
-    n_conv = len(args.hid)
-    value = n_conv * nnz * args.steps / t
-    alt = alt2 = None
-    runs = {}             # exchange scheme -> what the headline needs, for the schemes timed besides the first
+    notes = {'allgather': "the north_star's 1-D row split of A_hat + all-gather of H",
+             'agpipe': "the north_star's 1-D row split of A_hat + all-gather of H in feature slabs, slab q + 1 on the wire while slab q is multiplied",
+             'a2a': "feature repartition with two all-to-alls", 'halo': "halo exchange"}
 
-    def time_alt(c):
-        _m, _g, _F, t_alt, step_ms_alt, _k, last_alt = run_scheme(c)
-        runs[c.exchange] = (c, _g, _F, t_alt, step_ms_alt, _k, last_alt)
-        res = {"exchange": c.exchange, "value": n_conv * nnz * args.steps / t_alt, "unit": "edges/s",
-               "ms_per_step": t_alt / args.steps * 1e3, "step_ms_median": step_ms_alt[len(step_ms_alt) // 2],
-               "train_loss_last": float(last_alt[0]),
-               "note": "same job, same K/W, another exchange scheme (%s)" % {
-                   'allgather': "the north_star's 1-D row split of A_hat + all-gather of H",
-                   'agpipe': "the north_star's 1-D row split of A_hat + all-gather of H in %d feature slabs, slab q + 1 on the wire "
-                             "while slab q is multiplied" % c.slabs,
-                   'a2a': "feature repartition with two all-to-alls", 'halo': "halo exchange"}[c.exchange]}
-        del _m, _g
-        return res
-    if alt_comm is not None:
-        alt = time_alt(alt_comm)
-    if pipe_comm is not None:
-        alt2 = time_alt(pipe_comm)
-    choice = None
-    first_comm = comm
-    if world > 1 and args.exchange == 'auto' and runs:
-        # `--exchange auto` on N > 1 GPUs: every scheme was timed over the SAME K steps after the same W warm-up steps, each between
-        # barriers (max over ranks): `value` is the FASTEST of them -- a measured choice instead of a rule; the others stay in
-        # `alt` / `alt2` (every rank sees the same reduced times, so every rank makes the same choice)
-        first = {"exchange": comm.exchange, "value": value, "unit": "edges/s", "ms_per_step": t / args.steps * 1e3,
-                 "step_ms_median": step_ms[len(step_ms) // 2], "train_loss_last": float(last[0]),
-                 "note": "same job, same K/W: the scheme TorchDistComm(exchange='auto') picks by rule at this world size"}
-        best = min(runs, key=lambda e: runs[e][3])
-        choice = {"how": "every exchange scheme timed over the same %d steps after %d warm-up steps; value = the fastest" % (args.steps, args.warmup),
-                  "rule_pick": comm.exchange, "ms_per_step": dict({comm.exchange: t / args.steps * 1e3},
-                                                                   **{e: r[3] / args.steps * 1e3 for e, r in runs.items()})}
-        if runs[best][3] < t:
-            c_b, g_b, F_b, t_b, step_ms_b, kern_b, last_b = runs[best]
-            others = [first] + [x for x in (alt, alt2) if x is not None and x["exchange"] != best]
-            comm, g0, F_spmm, t, step_ms, kern_ms, last = c_b, g_b, F_b, t_b, step_ms_b, kern_b, last_b
-            value = n_conv * nnz * args.steps / t
-            alt, alt2 = (others + [None, None])[:2]
-        choice["picked"] = comm.exchange
-    check = None
-    if world > 1 and not args.no_check:
-        comms = {first_comm.exchange: first_comm}
-        if alt_comm is not None:
-            comms[alt_comm.exchange] = alt_comm
-        if pipe_comm is not None:
-            comms[pipe_comm.exchange] = pipe_comm
-        check = partition_check(make_clf, comms, X, A, Y, tr, dev, rank)
+    def summary(name, r):
+        return {"exchange": name, "value": n_conv * nnz * args.steps / r["t"], "unit": "edges/s", "ms_per_step": r["t"] / args.steps * 1e3,
+                "step_ms_median": r["step_ms"][len(r["step_ms"]) // 2], "train_loss_last": float(r["last"][0]),
+                "note": "same job, same K/W, exchange scheme: %s" % notes.get(name, name)}
 
-    if rank == 0:
-        g = g0
+    def build_line(r, extras):
+        """The JSON line with scheme result `r` as the headline (rank 0)."""
+        comm, g, F = r["comm"], r["g"], r["F"]
+        t, step_ms, kern_ms, last = r["t"], r["step_ms"], r["kern_ms"], r["last"]
         csr = g['A'].fwd
-        rp = csr.rowptr_host
-        deg = np.diff(rp)
-        F = F_spmm
+        deg = np.diff(csr.rowptr_host)
         # one product = spmm_rows_kernel over every stored edge of the local row block (short rows with the fused epilogue
         # + the 128-nonzero chunks of the long rows) + the long rows' ordered combine: algorithmic bytes = SURVEY.md §8d
         alg = spmm_algorithmic_bytes(len(deg), csr.shape[1], int(csr.nnz), F, 2 if bf16_operand else 4)
@@ -575,71 +689,49 @@ def main():
                                         "the timed region (the backward products of the hidden layers), hipEvent pairs recorded by "
                                         "the library on the launch stream around row kernel + long-row combine" % (F, int(csr.nnz)),
                     "edges_per_launch": int(csr.nnz), "bytes_per_edge": alg / max(1, int(csr.nnz))}
-        if world == 1 and args.shape != 'cmu':
-            try:
-                roofline["others"] = other_kernels(clf, lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), g, args.hid, N, C,
-                                                   args.gemm_precision)
-            except Exception as e:                       # evidence only: never fail the headline line over it
-                roofline["others_error"] = repr(e)
-        clocks = None
-        if world == 1:
-            try:
-                clocks = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 3.0, torch.cuda.synchronize)
-            except Exception as e:
-                clocks = {"error": repr(e)}
+        roofline.update(extras.get("roofline", {}))
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
-        dist_info = None
-        if world > 1 or force_dist:
-            import torch.distributed as tdist
-            dist_info = {"world_size_seen": tdist.get_world_size(), "torch_backend": tdist.get_backend(),
-                         "data_path": type(comm.dist).__name__ if hasattr(comm, 'dist') and not isinstance(comm.dist, type(tdist)) else "torch.distributed",
-                         "exchange": comm.exchange, "staged": staged}
+        di = None
+        if dist_info is not None:
+            di = dict(dist_info, exchange=comm.exchange,
+                      data_path=type(comm.dist).__name__ if hasattr(comm, 'dist') and not isinstance(comm.dist, type(torch.distributed)) else "torch.distributed")
         out = {
-            "metric": "GCN-layer fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
+            "metric": "GCN-layer fwd+bwd edges/sec", "value": n_conv * nnz * args.steps / t, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3,
             "step_ms": {"median": step_ms[len(step_ms) // 2], "p10": step_ms[int(0.1 * (len(step_ms) - 1))],
                         "p90": step_ms[int(round(0.9 * (len(step_ms) - 1)))], "min": step_ms[0], "max": step_ms[-1],
                         "how": "torch.cuda.Event after every step of the timed region (device time between consecutive steps)"},
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.gemm_precision != "bf16" else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if precision != "bf16" else "bf16", "data": "synthetic",
             "config": {"workload": "%s synthetic CSR (%s): N=%d, nnz(A_hat)=%d, "
                                    "X %dx%d nnz=%d, C=%d; %s highway GCN, dropout %.2f, Adam; full-graph f_train step"
                                    % ({'twus': 'TwitterUS-shape power-law', 'cmu': 'CMU-shape power-law',
                                        'twus_sbm': 'TwitterUS-size community-structured'}[args.shape],
-                                      baseline_config(args.shape, args.hid, args.gemm_precision, world), N, nnz, N, X.shape[1], X.nnz, C,
+                                      baseline_config(args.shape, args.hid, precision, world), N, nnz, N, X.shape[1], X.nnz, C,
                                       'x'.join(map(str, args.hid)), args.dropout),
                        "edges_per_step": n_conv * nnz,
                        "edges_traversed_per_step": 2 * (n_conv - 1) * nnz + nnz + nnz_bwd_out,
                        "parallelism": "rows%d" % world if world > 1 else "single",
                        "world_size": world, "collectives": None if comm is None else ("%s, exchange = %s" % ("STAGED through the host + gloo (functional check, NOT a measurement)" if staged else "RCCL (torch.distributed nccl)", comm.exchange)),
-                       "dist": dist_info,
+                       "dist": di,
                        "reorder": args.reorder,
                        "tuning_overrides": overrides or None,
                        "dropout_stream": "Philox keyed by device row: with --reorder the dropped entries differ from the "
                                          "un-reordered run of the same seed (statistically equivalent, not bitwise)" if args.reorder else "Philox",
-                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)", "bf16x3": "3-term bf16 split MFMA, fp32 accumulate",
-                                "bf16": "bf16 MFMA, fp32 accumulate"}[args.gemm_precision],
+                       "gemm": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in every product",
+                                "bf16x3": "bf16x3 split MFMA, fp32 accumulate (fp32-class): every fp32 operand split exactly into three bf16 terms, six "
+                                          "v_mfma_f32_16x16x32_bf16 cross terms per product (csrc/gemm_x3.hip) where a kernel takes the shape -- "
+                                          "the TwitterUS-size products -- exact fp32 MFMA elsewhere; inputs, outputs and accumulation fp32; the GPU "
+                                          "suite holds it to the tolerances stated for the exact kernels (0 argmax mismatches over 440,000 rows)",
+                                "bf16": "bf16 MFMA, fp32 accumulate"}[precision],
                        "train_loss_last": float(last[0])},
             "roofline": roofline,
-            "clocks": clocks,
         }
-        if choice is not None:
-            out["exchange_choice"] = choice
-        if alt is not None:
-            out["alt"] = alt
-        if alt2 is not None:
-            out["alt2"] = alt2
-        if check is not None:
-            out["partition_check"] = check
-        if world == 1 and args.cpu_sample != 'none':
-            log('[bench] timing the CPU oracle (%s sample)...' % args.cpu_sample)
-            out["cpu_baseline"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample)
-            log('[bench] ... and with the sparse products on all cores')
-            try:
-                out["cpu_baseline_mt"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample, multithreaded=True)
-            except Exception as e:
-                out["cpu_baseline_mt"] = {"error": repr(e)}
-        else:
-            out["cpu_baseline"] = None
+        for k in ("clocks", "alt_exact_f32", "layer", "exchange_choice", "alt", "alt2", "partition_check", "cpu_baseline", "cpu_baseline_mt"):
+            if k in extras:
+                out[k] = extras[k]
+        return out
+
+    def emit(out):
         # RCCL prints a version banner through C stdio; flush it so that the JSON line is the LAST line of stdout
         try:
             import ctypes
@@ -648,8 +740,132 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
+
+    # ---- the headline scheme: at N > 1 the north_star's all-gather, timed FIRST; its line is printed before anything else can fail ------
+    watchdog = Watchdog(rank)
+    first_name = None
+    comm = None
+    if distributed:
+        first_name = 'allgather' if args.exchange == 'auto' else args.exchange
+        comm = make_comm(first_name)
+    results = {}
+    first = run_scheme(comm)
+    results[first_name] = first
+    extras = {}
+    if world > 1 and rank == 0:
+        early = build_line(first, {})
+        early["note"] = ("early line: the first scheme only, printed before the other schemes and the partition check run -- a later line of "
+                         "this invocation supersedes it")
+        emit(early)
+
+    # ---- N > 1: the other schemes, each behind its own try/except and wall-clock guard ----------------------------------------------------
+    failed = []
+
+    def final_line(pending_error=None):
+        done = {k: v for k, v in results.items() if k is not None}
+        best = min(done, key=lambda e: done[e]["t"]) if done else None
+        head = done[best] if best is not None else first
+        ex = dict(extras)
+        if world > 1:
+            others = [summary(k, v) for k, v in done.items() if k != best] + failed + ([pending_error] if pending_error else [])
+            ex["exchange_choice"] = {"how": "the north_star's all-gather timed first; every other scheme over the same %d steps after %d warm-up steps, each "
+                                            "behind a try/except and a %.0f s wall-clock guard; value = the fastest that finished" % (args.steps, args.warmup, args.scheme_timeout),
+                                     "timed_first": first_name, "picked": best,
+                                     "ms_per_step": {k: v["t"] / args.steps * 1e3 for k, v in done.items()}}
+            if others:
+                ex["alt"] = others[0]
+            if len(others) > 1:
+                ex["alt2"] = others[1]
+            if len(others) > 2:
+                ex["alt_more"] = others[2:]
+        return build_line(head, ex)
+
+    if world > 1 and not args.no_alt:
+        for name in [n for n in ('allgather', 'a2a', 'agpipe') if n != first_name]:
+            watchdog.arm(args.scheme_timeout, 'exchange scheme %s' % name,
+                         lambda msg, name=name: emit(final_line({"exchange": name, "error": msg})))
+            try:
+                results[name] = run_scheme(make_comm(name))
+            except Exception as e:                       # (other ranks may now be out of step: the guard of the next scheme covers that)
+                failed.append({"exchange": name, "error": repr(e)})
+                log('[bench] rank %d: exchange scheme %s failed: %r' % (rank, name, e))
+            finally:
+                watchdog.disarm()
+    if world > 1 and not args.no_check:
+        watchdog.arm(args.scheme_timeout, 'partition_check',
+                     lambda msg: emit(dict(final_line(), partition_check={"error": msg})))
+        try:
+            comms = {k: v["comm"] for k, v in results.items() if k is not None}
+            extras["partition_check"] = partition_check(make_clf, comms, X, A, Y, tr, dev, rank)
+        except Exception as e:
+            extras["partition_check"] = {"error": repr(e)}
+        finally:
+            watchdog.disarm()
+
+    if rank == 0:
+        clf, g = first["clf"], first["g"]
+        if world == 1:
+            rf = {}
+            if args.shape != 'cmu':
+                try:
+                    rf["others"] = other_kernels(clf, lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), g, args.hid, N, C, precision)
+                except Exception as e:                       # evidence only: never fail the headline line over it
+                    rf["others_error"] = repr(e)
+            try:
+                extras["clocks"] = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 3.0, torch.cuda.synchronize)
+            except Exception as e:
+                extras["clocks"] = {"error": repr(e)}
+            if not args.no_extras and args.shape != 'cmu':
+                # what a gather of the product's row size can move on this GPU, measured now: the algorithmic fraction above
+                # next to the fraction of THAT ceiling the counted traffic reaches
+                try:
+                    gc_ = gather_ceiling(512, 4 * ops.gather_ld(first["F"]))
+                    if gc_ is not None:
+                        rf["gather_ceiling"] = gc_
+                        if gc_.get("tbps"):
+                            rf["gather_ceiling_tbps"] = gc_["tbps"]
+                            rf["gather_ceiling_source"] = "%s at commit %s" % (gc_.get("source"), _git_commit())
+                            pm_traffic = build_line(first, {})["roofline"]["traffic"]
+                            avg_ms = float(np.mean(first["kern_ms"])) if first["kern_ms"] else None
+                            if pm_traffic and avg_ms:
+                                rf["frac_of_gather_ceiling"] = pm_traffic / (avg_ms * 1e-3) / 1e12 / gc_["tbps"]
+                                rf["frac_of_gather_ceiling_how"] = ("counted HBM-side traffic per launch (`traffic`) / this run's average launch time / "
+                                                                    "gather_ceiling_tbps: how close the product is to what a gather can move; `frac` stays the "
+                                                                    "SURVEY.md 8d algorithmic fraction")
+                except Exception as e:
+                    rf["gather_ceiling_error"] = repr(e)
+                try:
+                    extras["layer"] = layer_block(g, N, nnz, args.hid[0], device, precision)
+                except Exception as e:
+                    extras["layer"] = {"error": repr(e)}
+            extras["roofline"] = rf
+            if not args.no_extras and precision == 'bf16x3':
+                # the same job with the exact fp32 MFMA in every product, same K / W, right after the headline (same box, same clocks state)
+                try:
+                    del clf
+                    r32 = run_scheme(None, 'f32')
+                    extras["alt_exact_f32"] = {"value": n_conv * nnz * args.steps / r32["t"], "unit": "edges/s", "ms_per_step": r32["t"] / args.steps * 1e3,
+                                               "step_ms_median": r32["step_ms"][len(r32["step_ms"]) // 2], "train_loss_last": float(r32["last"][0]),
+                                               "gemm": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in every product (--gemm-precision f32)",
+                                               "note": "same job, same K / W, timed after the headline in the same process"}
+                    del r32
+                except Exception as e:
+                    extras["alt_exact_f32"] = {"error": repr(e)}
+        if world == 1 and args.cpu_sample != 'none':
+            log('[bench] timing the CPU oracle (%s sample)...' % args.cpu_sample)
+            extras["cpu_baseline"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample)
+            log('[bench] ... and with the sparse products on all cores')
+            try:
+                extras["cpu_baseline_mt"] = cpu_baseline(args.shape, A, X, Y, tr, dev, args.hid, C, args.cpu_sample, multithreaded=True)
+            except Exception as e:
+                extras["cpu_baseline_mt"] = {"error": repr(e)}
+        else:
+            extras["cpu_baseline"] = None
+        emit(final_line())
+    if distributed:
+        watchdog.arm(60.0, 'destroy_process_group', lambda msg: None)
         torch.distributed.destroy_process_group()
+        watchdog.disarm()
 
 
 if __name__ == '__main__':

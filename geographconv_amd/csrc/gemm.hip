@@ -1246,11 +1246,15 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
         const int kp = rows_kp(c, false, transB != 0);
         return kp ? rows_ws_bytes(c, kp) : 0;
     }
-    if (!transA && precision == GEOGCN_GEMM_BF16X3) {   // the split-bf16 whole-rows kernel's weights, or the staged kernel's planes
+    if (!transA && precision == GEOGCN_GEMM_BF16X3) {
+        // the split-bf16 whole-rows kernel's weights; the exact whole-rows kernel's (the shapes gemm_x3.hip does not take run exact
+        // fp32); the staged split-bf16 kernel's planes (panel outputs)
         GemmCall c{};
         c.M = M; c.n_nseg = 1; c.n_kseg = 1; c.N[0] = N; c.K[0] = K; c.precision = precision;
         const int kc = x3_rows_kc(c, false, transB != 0);
-        return std::max(kc ? x3_rows_ws_bytes(c, kc) : (size_t)0, gemm_bf16_workspace_bytes(precision, N, K));
+        const int kp = rows_kp(c, false, transB != 0);
+        return std::max(std::max(kc ? x3_rows_ws_bytes(c, kc) : (size_t)0, kp ? rows_ws_bytes(c, kp) : (size_t)0),
+                        gemm_bf16_workspace_bytes(precision, N, K));
     }
     if (!transA) return gemm_bf16_workspace_bytes(precision, N, K);
     if (precision == GEOGCN_GEMM_BF16) {
@@ -1318,16 +1322,10 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
         GEOGCN_REQUIRE(!bias && act == GEOGCN_ACT_NONE, GEOGCN_E_ARG, "%s: K = 0 with a bias / activation", fn);
         return zero_rows_async((float*)Cv, M, (N + 3) & ~(int64_t)3, ldc, st);
     }
-    if (!transA && precision == GEOGCN_GEMM_BF16X3 && !c_bf16 && !panel_w) {
-        // the split-bf16 whole-rows kernel where it takes the shape (TwitterUS-size operands); else the staged split-bf16 kernel below
-        GemmCall c{};
-        c.M = M; c.n_nseg = 1; c.n_kseg = 1;
-        c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = (float*)Cv; c.ldc[0] = ldc; c.bias[0] = bias;
-        c.N[0] = N; c.K[0] = K; c.act[0] = act; c.act[1] = GEOGCN_ACT_NONE; c.accumulate = accumulate; c.precision = precision;
-        if (const int kc = x3_rows_kc(c, false, transB != 0); kc && ws && aligned16(ws) && ws_bytes >= x3_rows_ws_bytes(c, kc))
-            return x3_run_rows(kc, transB != 0, c, ws, st);
-    }
-    if (!transA && precision != GEOGCN_GEMM_F32)
+    // GEOGCN_GEMM_BF16X3 is a permission: the split-bf16 kernels of gemm_x3.hip where they take the shape (run_call below), the staged
+    // split-bf16 kernel for panel outputs, exact fp32 for everything else -- so that a fused launch and its separate launches stay
+    // bit-identical at every size
+    if (!transA && (precision == GEOGCN_GEMM_BF16 || (precision == GEOGCN_GEMM_BF16X3 && panel_w)))
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
                                   ws_bytes, st, panel_w, panel_R);
     float* C = (float*)Cv;
@@ -1483,7 +1481,7 @@ int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const
             return x3_run_rows(kc, transB != 0, c, ws, st);
         }
     }
-    if (precision != GEOGCN_GEMM_F32) {
+    if (precision == GEOGCN_GEMM_BF16) {
         const GateOps gate{G, ldg, T, ldt};
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, nullptr, GEOGCN_ACT_NONE, 0, ws, ws_bytes, st,
                                   0, 0, &gate);

@@ -389,8 +389,9 @@ def spmm_highway(A: CSR, B, bias: torch.Tensor, T: DMat, H: DMat, Hc: DMat = Non
 
 _gemm_ws = {}
 
-# How the activation x weight products are formed (include/geogcn.h GEOGCN_GEMM_*): 'f32' = exact fp32
-# MFMA, 'bf16x3' = three-term bf16 split (fp32-class accuracy, HBM-bound), 'bf16' = BASELINE config 5.
+# How the activation x weight products are formed (include/geogcn.h GEOGCN_GEMM_*): 'f32' = exact fp32 MFMA everywhere,
+# 'bf16x3' (default since round 5) = three-term bf16 split with fp32 accumulation (fp32-class accuracy) on the kernels of
+# csrc/gemm_x3.hip where they take the shape -- the TwitterUS-size products -- and exact fp32 elsewhere, 'bf16' = BASELINE config 5.
 GEMM_PRECISIONS = {'f32': _ffi.GEMM_F32, 'bf16x3': _ffi.GEMM_BF16X3, 'bf16': _ffi.GEMM_BF16}
 GEMM_PRECISION = tuning.GEMM_PRECISION
 
@@ -511,9 +512,10 @@ def gemm_gated_native(n, F, precision=None):
     off) form the carry in its epilogue?  bf16: the whole-rows kernel takes every GCN width (any other falls back to carry +
     accumulate at the cost of the stored carry); fp32: from 32,768 rows on."""
     p = precision or GEMM_PRECISION
-    if p in ('bf16', 'bf16x3'):         # (bf16x3: the split-bf16 whole-rows kernel, or the staged one behind the same entry point)
+    if p == 'bf16':
         return True
-    return p == 'f32' and _ffi.lib().geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_F32) > 0
+    # (bf16x3: the split-bf16 whole-rows kernel takes every shape the exact one does)
+    return p in ('f32', 'bf16x3') and _ffi.lib().geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_F32) > 0
 
 
 def kcat_gated_native(n, F, precision=None):

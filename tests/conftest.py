@@ -27,3 +27,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=['bf16x3', 'f32'])
+def both_gemm_precisions(request, monkeypatch):
+    """Parity tests run under BOTH precisions of the activation x weight products with the SAME tolerances: 'bf16x3' (the default:
+    fp32-class split-bf16 products where a kernel takes the shape) and 'f32' (the exact fp32 MFMA everywhere).  Use through
+    `pytestmark = pytest.mark.usefixtures('both_gemm_precisions')` or on single tests."""
+    from geographconv_amd import ops
+    monkeypatch.setattr(ops, 'GEMM_PRECISION', request.param)
+    return request.param

@@ -12,7 +12,8 @@ import pytest
 from geographconv_amd import synth
 from oracle import gcn_oracle as O
 
-pytestmark = pytest.mark.gpu
+# every test of this file under both GEMM precisions, same tolerances (tests/conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('both_gemm_precisions')]
 
 LOGIT_ATOL = 5e-5        # |logit_gpu - logit_cpu32|; both are within 2e-5 of the fp64 result
 PROB_ATOL = 2e-6
@@ -489,7 +490,7 @@ def test_first_layers_gradient_in_the_epilogue_of_the_first_blocks_product(cmu, 
     c = cmu
     for name in ('40k', 'cmu'):
         if name == 'cmu':
-            monkeypatch.setattr(ops, 'kcat_gated_native', lambda n, F: True)
+            monkeypatch.setattr(ops, 'kcat_gated_native', lambda n, F, precision=None: True)
         runs = {}
         for fused in (True, False):
             for graph in (False, True):
@@ -524,7 +525,7 @@ def test_carry_gradient_handed_down_at_sizes_the_whole_rows_kernel_does_not_take
     outs = {}
     for mode in ('stored', 'handed'):
         monkeypatch.setattr(tuning, 'FUSE_GATE_CARRY', mode != 'stored')
-        monkeypatch.setattr(ops, 'kcat_gated_native', (lambda n, F: True) if mode != 'stored' else ops.kcat_gated_native)
+        monkeypatch.setattr(ops, 'kcat_gated_native', (lambda n, F, precision=None: True) if mode != 'stored' else ops.kcat_gated_native)
         del made[:], formed[:]
         clf = _clf(c)
         clf.inject_dropout_mask(c['mask'])

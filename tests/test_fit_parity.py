@@ -180,6 +180,7 @@ def _check_against_oracle(clf, r, params0, n_epochs, max_down):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures('both_gemm_precisions')
 @pytest.mark.parametrize('name,n_epochs,max_down,use_mask', [
     ('tiny_plain_reg', 40, 2, False),        # dev loss rises from the first epoch: best 0, stops by the 2 * max_down clause
     ('tiny_plain_reg', 40, 3, False),
@@ -227,6 +228,7 @@ def test_fit_matches_the_oracle_loop_on_the_fixtures(name, n_epochs, max_down, u
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures('both_gemm_precisions')
 @pytest.mark.parametrize('labels,n_epochs,max_down', [('random', 40, 3), ('random', 40, 2), ('planted', 45, 2)])
 def test_fit_matches_the_oracle_loop_at_cmu_shape(labels, n_epochs, max_down):
     """CMU-shape graph, [64, 64] highway, dropout 0.  Random labels: the dev loss turns after a few epochs, training stops

@@ -136,6 +136,7 @@ def test_f_train_full_size_is_finite_and_learns(twus):
     assert pred.shape == (1000,) and np.array_equal(pred, probs.argmax(-1))
 
 
+@pytest.mark.usefixtures('both_gemm_precisions')
 def test_forward_full_size_matches_oracle_argmax_exact(twus):
     """BASELINE configs[2] at its FULL size against the oracle itself (deterministic forward of the 3x300 highway GCN
     over all 440,000 nodes, ~15 s of CPU): probabilities within the stated fp32 tolerance on every row, argmax labels
@@ -181,6 +182,7 @@ def test_forward_full_size_matches_oracle_argmax_exact(twus):
     assert np.abs(probs - ref64).max() <= tol + 3e-5
 
 
+@pytest.mark.usefixtures('both_gemm_precisions')
 def test_train_step_full_size_matches_oracle(twus):
     """One complete f_train step (forward, backward, Adam) at the FULL TwitterUS shape against the oracle's step on the
     same (A, X, Y), same parameters, same injected dropout mask: losses, hit counts, every gradient and the updated

@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+@pytest.fixture(autouse=True)
+def _exact_products_by_default(monkeypatch):
+    """This file holds the EXACT fp32 kernels to the oracle and to each other bit for bit: products whose precision a test does not
+    name run 'f32' here (the library's default is 'bf16x3'; the split-bf16 kernels have tests/test_x3_gpu.py)."""
+    from geographconv_amd import ops
+    monkeypatch.setattr(ops, 'GEMM_PRECISION', 'f32')
+
+
 @pytest.fixture(scope="module")
 def dev():
     from geographconv_amd import ops
@@ -526,7 +534,7 @@ def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
     A = ops.DMat.from_numpy(_rand((M, K), 1), dev)
     W0, W1 = ops.DMat.from_numpy(_rand((K, N0), 2, 0.1), dev), ops.DMat.from_numpy(_rand((K, N1), 3, 0.1), dev)
     b1 = torch.from_numpy(_rand((ops.pad4(N1),), 4)).to(dev)
-    assert lib.geogcn_gemm_dual_workspace_bytes(0, M, N0, N1, K) > 0            # this shape is taken by the rows kernel
+    assert lib.geogcn_gemm_dual_workspace_bytes(0, M, N0, N1, K, _ffi.GEMM_F32) > 0            # this shape is taken by the rows kernel
     got0 = ops.DMat.empty(M, N0, dev, ld=ops.gather_ld(N0))
     got0.t.zero_()
     got0, got1 = ops.gemm_dual(A, W0, W1, out0=got0, bias1=b1, act1=ops.ACT_SIGMOID)
@@ -535,7 +543,7 @@ def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
     ref1 = ops.DMat(M, N1, dev)
     _ffi.check(lib.geogcn_gemm_dual_f32(0, M, N0, N1, K, ops._p(A.t), A.ld, ops._p(W0.t), W0.ld, ops._p(W1.t), W1.ld,
                                         ops._p(ref0.t), ref0.ld, ops._p(ref1.t), ref1.ld, None, 0, ops._p(b1), ops.ACT_SIGMOID,
-                                        None, 0, st), 'dual, staged')
+                                        _ffi.GEMM_F32, None, 0, st), 'dual, staged')
     assert torch.equal(got0.t, ref0.t) and torch.equal(got1.t, ref1.t)
     assert torch.all(got1.t[:, N1:] == 0)
     # and against the fp64 product
@@ -547,14 +555,14 @@ def test_whole_rows_kernel_equals_the_staged_kernel_bitwise(dev, M, K, N0, N1):
         for transB in (True, False):
             V0 = ops.DMat.from_numpy(_rand((N0, K) if transB else (K, N0), 6, 0.1), dev)
             V1 = ops.DMat.from_numpy(_rand((N0, K) if transB else (K, N0), 7, 0.1), dev)
-            assert lib.geogcn_gemm_kcat_workspace_bytes(int(transB), M, N0, K, K) > 0
+            assert lib.geogcn_gemm_kcat_workspace_bytes(int(transB), M, N0, K, K, _ffi.GEMM_F32) > 0
             for acc in (False, True):
                 carry = _rand((M, N0), 8)
                 out = ops.DMat.from_numpy(carry, dev)
                 want = ops.DMat.from_numpy(carry, dev)
                 ops.gemm_kcat(G0, V0, G1, V1, out=out, transB=transB, accumulate=acc)
                 _ffi.check(lib.geogcn_gemm_kcat_f32(int(transB), M, N0, K, K, ops._p(G0.t), G0.ld, ops._p(V0.t), V0.ld, ops._p(G1.t),
-                                                    G1.ld, ops._p(V1.t), V1.ld, ops._p(want.t), want.ld, int(acc), None, 0, st),
+                                                    G1.ld, ops._p(V1.t), V1.ld, ops._p(want.t), want.ld, int(acc), _ffi.GEMM_F32, None, 0, st),
                            'kcat, staged')
                 assert torch.equal(out.t, want.t), (transB, acc)
 

@@ -76,7 +76,7 @@ Z2 = ops.DMat.empty(N, F, dev, ld=320)
 dW = ops.DMat(F, F, dev)
 ws_sp = dA._ws.get(lib.geogcn_spmm_workspace_bytes(dA._plan, F))
 ws_tn = torch.empty(lib.geogcn_gemm_workspace_bytes(1, 0, F, F, N, 0), dtype=torch.uint8, device=dev)
-ws_dual = torch.empty(lib.geogcn_gemm_dual_workspace_bytes(0, N, F, F, F), dtype=torch.uint8, device=dev)
+ws_dual = torch.empty(lib.geogcn_gemm_dual_workspace_bytes(0, N, F, F, F, 0), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 
 
@@ -93,7 +93,7 @@ def gemm_gate(st):          # T = sigmoid(H.Wt + bt): the staged kernel (what a 
 
 def gemm_dual(st):          # (Z, T) in one launch on the whole-rows kernel: what the step runs today
     rc = lib.geogcn_gemm_dual_f32(0, N, F, F, F, p(H.t), H.ld, p(Wh.t), Wh.ld, p(Wt.t), Wt.ld, p(Z2.t), Z2.ld, p(T.t), T.ld,
-                                  None, 0, p(bt), 2, p(ws_dual), ws_dual.numel(), st)
+                                  None, 0, p(bt), 2, 0, p(ws_dual), ws_dual.numel(), st)
     assert rc == 0, rc
 
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -56,7 +57,25 @@ double run(const float4* T, long row_f4, unsigned n_rows, int groups, int iters,
     return bytes / ms / 1e9;   // TB/s
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc >= 4 && !strcmp(argv[1], "--json")) {
+        // one point, machine-readable (bench.py: roofline.gather_ceiling): `--json <table MB> <row bytes: 256 | 512 | 1280>`, best of 3
+        const size_t bytes = (size_t)atol(argv[2]) << 20;
+        const int row = atoi(argv[3]);
+        float4* T; float4* out;
+        if (hipMalloc(&T, bytes) != hipSuccess || hipMalloc(&out, 1 << 24) != hipSuccess) { printf("{\"error\": \"hipMalloc\"}\n"); return 1; }
+        hipMemset(T, 0, bytes);
+        const int groups = 256 * 8 * 16 * 4;
+        double best = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            const double r = row == 256 ? run<1, 0>(T, 16, (unsigned)(bytes / 256), groups, 64, out)
+                           : row == 512 ? run<2, 0>(T, 32, (unsigned)(bytes / 512), groups, 32, out)
+                                        : run<5, 0>(T, 80, (unsigned)(bytes / 1280), groups, 16, out);
+            if (r > best) best = r;
+        }
+        printf("{\"table_mb\": %zu, \"row_bytes\": %d, \"tbps\": %.3f}\n", bytes >> 20, row == 256 || row == 512 ? row : 1280, best);
+        return 0;
+    }
     const size_t maxb = (size_t)4 << 30;
     float4* T; float4* out;
     hipMalloc(&T, maxb); hipMalloc(&out, 1 << 24);
