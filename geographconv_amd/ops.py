@@ -998,7 +998,9 @@ def spmm_t(x: SparseOperand, G: DMat, out: DMat = None, precision=None):
     else:
         out = spmm(x.bwd, G, out=out)                 # tail rows (head rows come out as zeros)
     if x.head_dense is not None:
-        head = gemm(x.head_dense, G, transA=True, precision=precision)  # K x F on the MFMA pipe, deterministic split-K
+        # K x F on the MFMA pipe, deterministic split-K -- fp32-class in every configuration (the bf16 configuration rounds the
+        # H . W products, not the sparse input's gradient)
+        head = gemm(x.head_dense, G, transA=True, precision=None if precision == 'bf16' else precision)
         scatter_rows(head, x.head_idx, out)
     return out
 
