@@ -334,9 +334,22 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
             const float4 hc = epilogue4<ACT>(acc[k], q * 4, F, bias);
             out[q] = hc;
             if constexpr (HW == 1) {
+#ifdef GEOGCN_SPMM_HW_NT          // A/B build only: streaming cache policy for the epilogue's operands (1: T / H loads, 2: Hout store)
+                typedef float f4v_ __attribute__((ext_vector_type(4)));
+                const f4v_* tp = reinterpret_cast<const f4v_*>(hw.T + (int64_t)row * hw.ld) + q;
+                const f4v_* hp = reinterpret_cast<const f4v_*>(hw.H + (int64_t)row * hw.ld) + q;
+                const f4v_ tv = (GEOGCN_SPMM_HW_NT & 1) ? __builtin_nontemporal_load(tp) : *tp;
+                const f4v_ hv = (GEOGCN_SPMM_HW_NT & 1) ? __builtin_nontemporal_load(hp) : *hp;
+                const float4 mix = highway_mix(make_float4(tv.x, tv.y, tv.z, tv.w), hc, make_float4(hv.x, hv.y, hv.z, hv.w));
+                f4v_* op = reinterpret_cast<f4v_*>(hw.Hout + (int64_t)row * hw.ld) + q;
+                const f4v_ mv = {mix.x, mix.y, mix.z, mix.w};
+                if (GEOGCN_SPMM_HW_NT & 2) __builtin_nontemporal_store(mv, op);
+                else *op = mv;
+#else
                 const float4 t = reinterpret_cast<const float4*>(hw.T + (int64_t)row * hw.ld)[q];
                 const float4 h = reinterpret_cast<const float4*>(hw.H + (int64_t)row * hw.ld)[q];
                 reinterpret_cast<float4*>(hw.Hout + (int64_t)row * hw.ld)[q] = highway_mix(t, hc, h);
+#endif
             }
         }
     }

@@ -397,7 +397,9 @@ class DenseLayer(Layer):
                 or isinstance(tape.get(below, {}).get('x'), K.DMat)):
             return None
         y0 = tape[below]['y']
-        if not isinstance(y0, K.DMat) or y0.F % 4 or tuple(keep.shape) != (y0.n, y0.F) or not K.kcat_gated_native(y0.n, y0.F, kwargs.get('gemm_precision')):
+        # (an injected mask of another dtype / layout / device -- parity runs -- takes the unfused Masked / act_bwd path, which accepts it)
+        if (not isinstance(y0, K.DMat) or y0.F % 4 or tuple(keep.shape) != (y0.n, y0.F) or str(keep.dtype) != 'torch.uint8'
+                or not keep.is_contiguous() or keep.device != y0.device or not K.kcat_gated_native(y0.n, y0.F, kwargs.get('gemm_precision'))):
             return None
         return below, y0, keep, 1.0 / (1.0 - d.p)
 

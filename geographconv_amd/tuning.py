@@ -104,8 +104,8 @@ ROW_COST_IN_EDGES = 45.0
 # link of the pair: any smaller halo pays for its pack launch (60 us against 3.4 ms of wire per exchange) -> 0.9.
 # The pinned power-law graph sits at 0.87-0.95, a community graph numbered by label propagation at 0.27 (8 ranks) / 0.67
 # (2 ranks) (dist.halo_sizes)
+DIST_HALO_MAX_FRACTION = 0.5
+DIST_HALO_MAX_FRACTION_2_RANKS = 0.9
 # 'agpipe' exchange: feature slabs per all-gather (slab q + 1 on the wire while slab q is multiplied).  4: at F = 300 a slab is 76
 # columns = 304 B of a row (3 lines); unmeasured on real links (1-GPU boxes) -- the arithmetic is in DESIGN.md section 5
 DIST_AG_SLABS = 4
-DIST_HALO_MAX_FRACTION = 0.5
-DIST_HALO_MAX_FRACTION_2_RANKS = 0.9

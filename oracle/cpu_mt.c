@@ -97,9 +97,10 @@ void geogcn_cpu_ce_grad_f32(int64_t n, int64_t C, const float* P, const int64_t*
 static void colsum2_(int64_t n, int64_t F, const float* X0, const float* X1, float* s0, float* s1) {
     const int nt = omp_get_max_threads();
     float* part = (float*)calloc((size_t)nt * 2 * F, sizeof(float));
-#pragma omp parallel num_threads(nt)
-    {
-        const int t = omp_get_thread_num();
+    /* the nt row blocks are loop iterations, not thread ids: every block is summed exactly once whatever team the runtime
+     * delivers (OMP_DYNAMIC, OMP_THREAD_LIMIT, cgroup limits, nesting may give fewer threads than omp_get_max_threads) */
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < nt; ++t) {
         const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
         float* p0 = part + (size_t)t * 2 * F;
         float* p1 = p0 + F;

@@ -51,7 +51,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int6
 }
 
 // PF = stages of global loads in flight per thread.  PROBE: 1 = no global loads, 2 = no LDS stores (and no split), 4 = no MFMAs
-template <int BM, int BN, int PF, int PROBE = 0>
+template <int BM, int BN, int PF, int PROBE = 0, int IG = 0>
 __global__ __launch_bounds__(512, 1) void x3_tn_kernel(const float* __restrict__ A, int64_t lda, int64_t M, const float* __restrict__ B,
                                                        int64_t ldb, int64_t N, int64_t K, float* __restrict__ W, int64_t ldw, int n_mt,
                                                        int n_nt, int nsplit, int64_t kchunk) {
@@ -134,24 +134,32 @@ __global__ __launch_bounds__(512, 1) void x3_tn_kernel(const float* __restrict__
             if (live && !(PROBE & 4)) {
                 const unsigned char* As = smem_raw;
                 const unsigned char* Bs = smem_raw + kImgA;
-                bf16x8 af[MR][3];
+                constexpr int GI = IG ? IG : MR;          // row tiles whose A fragments are held at a time
 #pragma unroll
-                for (int i = 0; i < MR; ++i)
+                for (int i0 = 0; i0 < MR; i0 += GI) {
+                    bf16x8 af[GI][3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * kPlane + (wm * (BM / 2) + i * 16 + li) * ROWB + lg * 16);
+                    for (int i = 0; i < GI; ++i)
 #pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    bf16x8 bf[3];
+                        for (int pl = 0; pl < 3; ++pl)
+                            if (i0 + i < MR) af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * kPlane + (wm * (BM / 2) + (i0 + i) * 16 + li) * ROWB + lg * 16);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bf[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * kPlane + (wn * (BN / 4) + j * 16 + li) * ROWB + lg * 16);
+                    for (int j = 0; j < NR; ++j) {
+                        bf16x8 bf[3];
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            bf[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * kPlane + (wn * (BN / 4) + j * 16 + li) * ROWB + lg * 16);
 #define X3_TERM(PB, PA)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < MR; ++i) acc[i][j] =                                                  \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[PB], af[i][PA], acc[i][j], 0, 0, 0);
-                    X3_TERM(0, 2) X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 1) X3_TERM(1, 0) X3_TERM(0, 0)
+    _Pragma("unroll") for (int i = 0; i < GI; ++i) if (i0 + i < MR) acc[i0 + i][j] =                            \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[PB], af[i][PA], acc[i0 + i][j], 0, 0, 0);
+                        X3_TERM(0, 2) X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 1) X3_TERM(1, 0) X3_TERM(0, 0)
+#undef X3_TERM
+                    }
+                }
+#if 0
 #undef X3_TERM
                 }
+#endif
             }
         }
     }
@@ -181,7 +189,7 @@ __global__ void reduce_kernel(int M, int N, int nsplit, const float* W, int64_t 
     C[e] = s;
 }
 
-template <int BM, int BN, int PF, int PROBE>
+template <int BM, int BN, int PF, int PROBE, int IG = 0>
 static void run(const char* name, const float* dH, int M, const float* dG, int N, int64_t K, float* dW, float* dC, const std::vector<float>& hH,
                 const std::vector<float>& hG) {
     const int n_mt = (M + BM - 1) / BM, n_nt = (N + BN - 1) / BN;
@@ -193,7 +201,7 @@ static void run(const char* name, const float* dH, int M, const float* dG, int N
     const int grid = tiles * ((nsplit + kNumXCD - 1) / kNumXCD) * kNumXCD;
     const int64_t ldw = (N + 3) & ~3;
     const int lds = 3 * (BM + BN) * ROWB;
-    auto kern = x3_tn_kernel<BM, BN, PF, PROBE>;
+    auto kern = x3_tn_kernel<BM, BN, PF, PROBE, IG>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dH, (int64_t)M, (int64_t)M, dG, (int64_t)N, (int64_t)N, K, dW, ldw, n_mt, n_nt, nsplit, kchunk);
     CK(hipDeviceSynchronize());
@@ -250,6 +258,11 @@ int main() {
         printf("M = %d, N = %d, K = %lld (%.1f GFLOP)\n", M, N, (long long)K, 2.0 * M * N * K / 1e9);
         run<160, 320, 1, 0>("x3 A^T.B, 160 x 320, 1 stage ahead", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 0>("x3 A^T.B, 160 x 320, 2 stages ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 1, 0, 3>("x3 A^T.B, 160 x 320, 1 ahead, A frags 3+2", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 0, 3>("x3 A^T.B, 160 x 320, 2 ahead, A frags 3+2", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 3, 0, 3>("x3 A^T.B, 160 x 320, 3 ahead, A frags 3+2", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 0, 1>("x3 A^T.B, 160 x 320, 2 ahead, A frags one by one", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 3, 0, 1>("x3 A^T.B, 160 x 320, 3 ahead, A frags one by one", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 1>("  ablation: no global loads", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 3>("  ablation: MFMAs + fragment reads only", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 4>("  ablation: no MFMAs", dH, M, dG, N, K, dW, dC, hH, hG);
