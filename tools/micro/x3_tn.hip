@@ -180,6 +180,147 @@ __global__ __launch_bounds__(512, 1) void x3_tn_kernel(const float* __restrict__
     }
 }
 
+
+// ---- v2: 16-k stages (v_mfma_f32_16x16x16_bf16), TWO three-plane LDS images (2 x 69 KB): the split + store of stage s + 1 runs
+// under the MFMAs of stage s; one barrier per stage.  The two 4-wave halves of the block take the loading of alternate stages, so that
+// on every SIMD one wave splits while the other multiplies.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK2 = 16, ROWB2 = 48;          // 16 bf16 = 32 B + 16 B pad: conflict-free ds_read_b64 (12 dwords per row)
+
+template <int BM, int BN, int PF, int PROBE = 0>
+__global__ __launch_bounds__(512, 1) void x3_tn2_kernel(const float* __restrict__ A, int64_t lda, int64_t M, const float* __restrict__ B,
+                                                        int64_t ldb, int64_t N, int64_t K, float* __restrict__ W, int64_t ldw, int n_mt,
+                                                        int n_nt, int nsplit, int64_t kchunk) {
+    constexpr int MR = BM / 32, NR = BN / 64;
+    constexpr int kAItems = 2 * (BM / 4), kBItems = 2 * (BN / 4);          // patches of 8 k x 4 columns per 16-k stage
+    static_assert(kAItems + kBItems <= 256, "a stage's patches must fit one half of the block");
+    constexpr int kImgA = BM * ROWB2, kPlane = (BM + BN) * ROWB2, kBuf = 3 * kPlane;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3, li = lane & 15, lg = lane >> 4;
+    const int grp = wid >> 2;                   // which stages this half of the block loads: kt % 2 == grp
+    const int b = blockIdx.x;
+    const int xcd = b % kNumXCD, s = b / kNumXCD;
+    const int tiles = n_nt * n_mt;
+    const int tile = s % tiles;
+    const int nt = __builtin_amdgcn_readfirstlane(tile % n_nt);
+    const int mt = __builtin_amdgcn_readfirstlane(tile / n_nt);
+    const int z = __builtin_amdgcn_readfirstlane(xcd + kNumXCD * (s / tiles));
+    if (z >= nsplit) return;
+    const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+    const int64_t kbeg = (int64_t)z * kchunk, kend = K < kbeg + kchunk ? K : kbeg + kchunk;
+    const int nk = (int)((kend - kbeg + BK2 - 1) / BK2);
+
+    const int t2 = tid & 255;
+    const bool isA = t2 < kAItems;
+    const int it = isA ? t2 : t2 - kAItems;
+    const int cols4 = isA ? BM / 4 : BN / 4;
+    const bool active = it < 2 * cols4;
+    const int k8 = it / cols4, c4 = it % cols4;
+    const float* P = isA ? A : B;
+    const int64_t ld = isA ? lda : ldb;
+    const int64_t c0 = isA ? m0 : n0;
+    const int64_t ctot = isA ? M : N;
+    const bool col_ok = active && (c4 * 4 < ((ctot + 3) & ~(int64_t)3) - c0);
+    f32x4 ring[PF][8];
+    auto gload = [&](f32x4 (&r)[8], int kt) {
+        const int64_t k0 = kbeg + (int64_t)kt * BK2;
+        const __amdgpu_buffer_rsrc_t rs = mk_rsrc(P + k0 * ld + c0, ((kend - k0) * ld - c0) * 4);
+        const uint32_t ld4 = (uint32_t)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t off = (uint32_t)(k8 * 8 + i) * ld4 + (uint32_t)c4 * 16u;
+            r[i] = (PROBE & 1) ? f32x4{1.f, 2.f, 3.f, 4.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(col_ok ? off : 0x80000000u), 0, 0));
+        }
+    };
+    auto sstore = [&](int buf, const f32x4 (&r)[8]) {
+        if (!active || (PROBE & 2)) return;
+        unsigned char* img = smem_raw + buf * kBuf + (isA ? 0 : kImgA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t p[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split3_pair(r[2 * q][e], r[2 * q + 1][e], p[q]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint4*>(img + pl * kPlane + (c4 * 4 + e) * ROWB2 + k8 * 16) = make_uint4(p[0][pl], p[1][pl], p[2][pl], p[3][pl]);
+        }
+    };
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // my stages: grp, grp + 2, grp + 4, ...; ring slot d holds my (d)-th next stage
+#pragma unroll
+    for (int d = 0; d < PF; ++d) gload(ring[d], grp + 2 * d);
+    if (grp == 0) sstore(0, ring[0]);            // stage 0 -> image 0
+    if (grp == 0) gload(ring[0], 2 * PF);
+    __syncthreads();
+    // (stage kt is multiplied from image kt % 2; before that its loader half writes stage kt + 1 into the other image)
+    // ring bookkeeping: group 0 has consumed slot 0 (stage 0) above; its next is stage 2 = slot 1 ... handled by a running slot index in
+    // an unrolled-by-(2 PF) loop so that slots stay compile-time constants
+#pragma unroll 1
+    for (int kt0 = 0; kt0 < nk; kt0 += 2 * PF) {
+#pragma unroll
+        for (int u = 0; u < 2 * PF; ++u) {
+            const int kt = kt0 + u;
+            const bool live = kt < nk;
+            // the loader of stage kt + 1 is group (kt + 1) % 2 = (u + 1) % 2; for that group stage kt + 1 sits in ring slot:
+            //   group 0 loads even stages: stage 2 q in slot q % PF (slot 0 was stage 0); group 1 loads odd stages: stage 2 q + 1 in slot q % PF
+            constexpr int dummy = 0;
+            (void)dummy;
+            if (((u + 1) & 1) == grp) {
+                const int q = (kt + 1) >> 1;              // my q-th stage
+                const int slot_c = ((u + 1) >> 1) % PF;   // compile-time: kt0 is a multiple of 2 PF
+                (void)q;
+                if (kt + 1 < nk) sstore((kt + 1) & 1, ring[slot_c]);
+                gload(ring[slot_c], kt + 1 + 2 * PF);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (live && !(PROBE & 4)) {
+                const unsigned char* As = smem_raw + (kt & 1) * kBuf;
+                const unsigned char* Bs = As + kImgA;
+                bf16x4 af[MR][3];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[i][pl] = *reinterpret_cast<const bf16x4*>(As + pl * kPlane + (wm * (BM / 2) + i * 16 + li) * ROWB2 + lg * 8);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    bf16x4 bf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bf[pl] = *reinterpret_cast<const bf16x4*>(Bs + pl * kPlane + (wn * (BN / 4) + j * 16 + li) * ROWB2 + lg * 8);
+#define X3_TERM2(PB, PA)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MR; ++i) acc[i][j] =                                                   \
+        __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf[PB], af[i][PA], acc[i][j], 0, 0, 0);
+                    X3_TERM2(0, 2) X3_TERM2(2, 0) X3_TERM2(1, 1) X3_TERM2(0, 1) X3_TERM2(1, 0) X3_TERM2(0, 0)
+#undef X3_TERM2
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float* Wz = W + (int64_t)z * M * ldw;
+    const int64_t n_store = (N + 3) & ~(int64_t)3;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int64_t row = m0 + wm * (BM / 2) + i * 16 + li;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int64_t col0 = n0 + wn * (BN / 4) + j * 16 + lg * 4;
+            f32x4 x = acc[i][j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col0 + q >= N) x[q] = 0.f;
+            if (row < M && col0 < n_store) *reinterpret_cast<f32x4*>(Wz + row * ldw + col0) = x;
+        }
+    }
+}
+
 __global__ void reduce_kernel(int M, int N, int nsplit, const float* W, int64_t ldw, float* C) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= M * N) return;
@@ -189,7 +330,7 @@ __global__ void reduce_kernel(int M, int N, int nsplit, const float* W, int64_t 
     C[e] = s;
 }
 
-template <int BM, int BN, int PF, int PROBE, int IG = 0>
+template <int BM, int BN, int PF, int PROBE, int IG = 0, int V2 = 0>
 static void run(const char* name, const float* dH, int M, const float* dG, int N, int64_t K, float* dW, float* dC, const std::vector<float>& hH,
                 const std::vector<float>& hG) {
     const int n_mt = (M + BM - 1) / BM, n_nt = (N + BN - 1) / BN;
@@ -200,8 +341,9 @@ static void run(const char* name, const float* dH, int M, const float* dG, int N
     const int nsplit = (int)((K + kchunk - 1) / kchunk);
     const int grid = tiles * ((nsplit + kNumXCD - 1) / kNumXCD) * kNumXCD;
     const int64_t ldw = (N + 3) & ~3;
-    const int lds = 3 * (BM + BN) * ROWB;
-    auto kern = x3_tn_kernel<BM, BN, PF, PROBE, IG>;
+    const int lds = V2 ? 2 * 3 * (BM + BN) * ROWB2 : 3 * (BM + BN) * ROWB;
+    void (*kern)(const float*, int64_t, int64_t, const float*, int64_t, int64_t, int64_t, float*, int64_t, int, int, int, int64_t);
+    if constexpr (V2) kern = x3_tn2_kernel<BM, BN, PF, PROBE>; else kern = x3_tn_kernel<BM, BN, PF, PROBE, IG>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dH, (int64_t)M, (int64_t)M, dG, (int64_t)N, (int64_t)N, K, dW, ldw, n_mt, n_nt, nsplit, kchunk);
     CK(hipDeviceSynchronize());
@@ -258,11 +400,11 @@ int main() {
         printf("M = %d, N = %d, K = %lld (%.1f GFLOP)\n", M, N, (long long)K, 2.0 * M * N * K / 1e9);
         run<160, 320, 1, 0>("x3 A^T.B, 160 x 320, 1 stage ahead", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 0>("x3 A^T.B, 160 x 320, 2 stages ahead", dH, M, dG, N, K, dW, dC, hH, hG);
-        run<160, 320, 1, 0, 3>("x3 A^T.B, 160 x 320, 1 ahead, A frags 3+2", dH, M, dG, N, K, dW, dC, hH, hG);
-        run<160, 320, 2, 0, 3>("x3 A^T.B, 160 x 320, 2 ahead, A frags 3+2", dH, M, dG, N, K, dW, dC, hH, hG);
-        run<160, 320, 3, 0, 3>("x3 A^T.B, 160 x 320, 3 ahead, A frags 3+2", dH, M, dG, N, K, dW, dC, hH, hG);
-        run<160, 320, 2, 0, 1>("x3 A^T.B, 160 x 320, 2 ahead, A frags one by one", dH, M, dG, N, K, dW, dC, hH, hG);
-        run<160, 320, 3, 0, 1>("x3 A^T.B, 160 x 320, 3 ahead, A frags one by one", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 1, 0, 0, 1>("v2: 16-k stages, two images, 1 ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 0, 0, 1>("v2: 16-k stages, two images, 2 ahead", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 1, 0, 1>("  v2 ablation: no global loads", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 3, 0, 1>("  v2 ablation: MFMAs + fragment reads only", dH, M, dG, N, K, dW, dC, hH, hG);
+        run<160, 320, 2, 4, 0, 1>("  v2 ablation: no MFMAs", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 1>("  ablation: no global loads", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 3>("  ablation: MFMAs + fragment reads only", dH, M, dG, N, K, dW, dC, hH, hG);
         run<160, 320, 2, 4>("  ablation: no MFMAs", dH, M, dG, N, K, dW, dC, hH, hG);
