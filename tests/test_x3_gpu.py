@@ -199,3 +199,31 @@ def test_tn_slab_limit_falls_back_to_the_staged_kernel(dev):
     finally:
         lib.geogcn_debug_set_tn_slab_limit(0)
     _check(ops.gemm(dA, dB, transA=True, precision='f32').numpy(), ref, mag, 'direct')
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_x3_random_shapes(dev, seed):
+    """Seeded random shapes round the kernels' limits (K and N up to 640, ragged row counts, widths that are no multiple of 4 or 16,
+    both weight orientations, with and without bias / accumulate): whatever kernel the library picks, the fp32 envelope holds."""
+    from geographconv_amd import ops
+    r = np.random.RandomState(1000 + seed)
+    M = int(r.randint(32768, 36000))
+    K = int(r.choice([r.randint(1, 641), 300, 256, 129, 33]))
+    N = int(r.choice([r.randint(1, 641), 300, 256, 304, 17]))
+    A, B = _wide_range((M, K), seed), _rand((K, N), seed + 50, 0.2)
+    bias = _rand((N,), seed + 99)
+    dA = ops.DMat.from_numpy(A, dev)
+    transB = bool(r.randint(2))
+    dB = ops.DMat.from_numpy(np.ascontiguousarray(B.T) if transB else B, dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(N) - N))).to(dev)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    _check(ops.gemm(dA, dB, transB=transB, precision='bf16x3').numpy(), ref, mag, 'random A.B %s' % ((M, N, K, transB),))
+    got = ops.gemm(dA, dB, transB=transB, bias=db, precision='bf16x3').numpy()
+    _check(got, ref + bias, mag, 'random A.B + bias %s' % ((M, N, K, transB),), extra=2e-7 * np.abs(ref + bias))
+    # the transposed product over the same operands: (A^T . G)[K x N2], reduction over the M rows
+    N2 = int(r.choice([300, 256, 600, r.randint(161, 321)]))
+    G = _rand((M, N2), seed + 7, 1e-2)
+    dG = ops.DMat.from_numpy(G, dev)
+    ref_t = A.T.astype(np.float64) @ G.astype(np.float64)
+    _check(ops.gemm(dA, dG, transA=True, precision='bf16x3').numpy(), ref_t, np.abs(A.T).astype(np.float64) @ np.abs(G), 'random A^T.B %s' % ((K, N2, M),))
