@@ -53,8 +53,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int6
 // PROBE: 1 = no C stores, 2 = no A loads (LDS holds garbage), 4 = no MFMAs, 8 = no B loads, 16 = one B plane loaded (a third of the
 // B bytes), 32 = every B load from the first 15 KB (L1 hits), 64 = no LDS fragment reads,
 // 256 = C stores as whole 128-byte lines (address pattern only: wrong values), 512 = non-temporal C stores, 1024 = non-temporal A loads
-template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64>
-__global__ __launch_bounds__(256, BM == 64 ? 2 : 1) void x3_rows_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
+template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1>
+__global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
                                                          const unsigned short* __restrict__ Bf, int N, float* __restrict__ C,
                                                          int64_t ldc, int n_mt, int passes, long long* tim = nullptr) {
     constexpr int MR = BM / 16;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 2 : 1) void x3_rows_kernel(const fl
                 for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             // B ring: slot j holds the three planes of column tile j for the k-step about to be multiplied; it is refilled with the
             // next k-step's as soon as its MFMAs have been issued
-            bf16x8 ring[WCT][3];
+            bf16x8 ring[RD][WCT][3];
             auto bload = [&](bf16x8 (&b)[3], int j, int kt) {
                 const int kk = kt < NK ? kt : NK - 1;
 #pragma unroll
@@ -128,12 +128,16 @@ __global__ __launch_bounds__(256, BM == 64 ? 2 : 1) void x3_rows_kernel(const fl
             };
             if (!(PROBE & 8)) {
 #pragma unroll
-                for (int j = 0; j < WCT; ++j) bload(ring[j], j, 0);
+                for (int d = 0; d < RD; ++d)
+#pragma unroll
+                    for (int j = 0; j < WCT; ++j) bload(ring[d][j], j, d);
             } else {
+#pragma unroll
+                for (int d = 0; d < RD; ++d)
 #pragma unroll
                 for (int j = 0; j < WCT; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) ring[j][pl] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+                    for (int pl = 0; pl < 3; ++pl) ring[d][j][pl] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
             }
 #pragma unroll 1
             for (int ch = 0; ch < NCH; ++ch) {
@@ -178,11 +182,11 @@ __global__ __launch_bounds__(256, BM == 64 ? 2 : 1) void x3_rows_kernel(const fl
                             // the one before it (operands swapped: a lane owns 4 consecutive columns of one row of C)
 #define X3_TERM(PB, PA)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < MR; ++i) acc[i][j] =                                                  \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[j][PB], af[i][PA], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ks % RD][j][PB], af[i][PA], acc[i][j], 0, 0, 0);
                             X3_TERM(0, 2) X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 1) X3_TERM(1, 0) X3_TERM(0, 0)
 #undef X3_TERM
                         }
-                        if (!(PROBE & 8)) bload(ring[j], j, kt + 1);
+                        if (!(PROBE & 8)) bload(ring[ks % RD][j], j, kt + RD);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -237,7 +241,7 @@ static float h_bf16_f(unsigned short h) {
     return f;
 }
 
-template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64>
+template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1>
 static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC,
                 int64_t ldc, const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
     const int my = g_ordinal++;
@@ -245,7 +249,8 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     const int n_mt = (int)((M + BM - 1) / BM);
     const int passes = N <= 4 * WCT * 16 ? 1 : 2;
     const size_t lds = (size_t)3 * BM * (KC * 2 + 16);
-    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM>;
+    static_assert(RD == 1 || (KC / 32) % RD == 0, "ring depth must divide the k-steps of a chunk");
+    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD>;
     static long long* dT = nullptr;
     if (!dT) CK(hipMalloc(&dT, 64 * 8));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -349,6 +354,10 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 1024>("  probe: non-temporal A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 256 + 512 + 1024>("  probe: all three", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0>("  one chunk of 320, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<320, 1, 5, 0, 0, 64, 2>("  one chunk of 320, one block per CU, B two k-steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<320, 1, 5, 0, 3, 64, 2>("    ... no A loads, no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<320, 1, 5, 0, 3, 64, 1>("    ... no A loads, no C stores, B one k-step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<320, 1, 5, 0, 11, 64, 1>("    ... MFMAs only", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<160, 2, 5, 0, 0, 128>("128 rows, 2 chunks of 160, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<160, 2, 5, 0, 11, 128>("  128 rows: MFMAs only", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<160, 2, 5, 0, 3, 128>("  128 rows: no A loads, no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);

@@ -9,11 +9,11 @@ out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/pmc_gemm_rows'
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
-        if 'gemm' not in k or 'prep' in k or 'splitk' in k:
+        k = r['Kernel_Name'].replace('void ', '').replace('geogcn::', '').replace('(anonymous namespace)::', '')
+        if ('gemm' not in k and 'x3_' not in k) or 'prep' in k or 'splitk' in k:
             continue
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        agg[k.split('(')[0][:60] + ' grid ' + r.get('Grid_Size', '')][r['Counter_Name']].append((float(r['Counter_Value']), us))
+        agg[k.split('(')[0][:60]][r['Counter_Name']].append((float(r['Counter_Value']), us))
 print('| kernel | launches | us (profiled) | SQ_VALU_MFMA_BUSY_CYCLES | GRBM_GUI_ACTIVE | MFMA pipe busy | shader clock |')
 print('|---|---|---|---|---|---|---|')
 for k, c in sorted(agg.items()):
