@@ -53,7 +53,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int6
 // PROBE: 1 = no C stores, 2 = no A loads (LDS holds garbage), 4 = no MFMAs, 8 = no B loads, 16 = one B plane loaded (a third of the
 // B bytes), 32 = every B load from the first 15 KB (L1 hits), 64 = no LDS fragment reads,
 // 256 = C stores as whole 128-byte lines (address pattern only: wrong values), 512 = non-temporal C stores, 1024 = non-temporal A loads
-template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1>
+template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1, int STG = 0>
 __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
                                                          const unsigned short* __restrict__ Bf, int N, float* __restrict__ C,
                                                          int64_t ldc, int n_mt, int passes, long long* tim = nullptr) {
@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
         }
     };
 
+    // STG: the second resident block of every CU starts late by STG x ~8k cycles, so that its load / split / store phases fall into the
+    // first block's MFMA phases instead of coinciding with its load phases
+    if (STG && blockIdx.x >= gridDim.x / 2) {
+#pragma unroll 1
+        for (int i = 0; i < STG; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (int mt = blockIdx.x; mt < n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
 #pragma unroll 1
@@ -241,7 +247,7 @@ static float h_bf16_f(unsigned short h) {
     return f;
 }
 
-template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1>
+template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1, int STG = 0>
 static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC,
                 int64_t ldc, const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
     const int my = g_ordinal++;
@@ -250,7 +256,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     const int passes = N <= 4 * WCT * 16 ? 1 : 2;
     const size_t lds = (size_t)3 * BM * (KC * 2 + 16);
     static_assert(RD == 1 || (KC / 32) % RD == 0, "ring depth must divide the k-steps of a chunk");
-    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD>;
+    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD, STG>;
     static long long* dT = nullptr;
     if (!dT) CK(hipMalloc(&dT, 64 * 8));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -354,6 +360,10 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 1024>("  probe: non-temporal A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 256 + 512 + 1024>("  probe: all three", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0>("  one chunk of 320, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 0, 64, 1, 1>("  second block of a CU starts 8k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 2>("  second block of a CU starts 16k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 4>("  second block of a CU starts 32k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 8>("  second block of a CU starts 65k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0, 64, 2>("  one chunk of 320, one block per CU, B two k-steps ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<320, 1, 5, 0, 3, 64, 2>("    ... no A loads, no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<320, 1, 5, 0, 3, 64, 1>("    ... no A loads, no C stores, B one k-step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
