@@ -13,7 +13,7 @@ RT=$(ls /usr/lib/x86_64-linux-gnu/libasan.so.? | head -1)
 cd $ROOT
 if [ "${1:-}" = build ]; then
   mkdir -p /tmp/asan_obj
-  for f in core spmm spmm_hot xt gemm gemm_bf16 elementwise softmax_adam comm; do
+  for f in core spmm spmm_hot xt gemm gemm_x3 gemm_bf16 elementwise softmax_adam comm; do
     hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize \
       -fno-omit-frame-pointer -Wno-unused-function -c geographconv_amd/csrc/$f.hip -o /tmp/asan_obj/$f.o || exit 1 &
   done
@@ -30,7 +30,7 @@ export LD_PRELOAD="$RT $(ls /usr/lib/x86_64-linux-gnu/libstdc++.so.6)"      # (l
 # (libasan's dlopen interceptor becomes the caller of torch's lazy dlopen()s: their $ORIGIN run-paths no longer apply)
 export LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:${LD_LIBRARY_PATH:-}
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0
-{ echo "# host ASAN run: $(date -u) runtime $RT"; python -m pytest tests/test_fuzz_gpu.py tests/test_abi.py tests/test_kernels_gpu.py -q -m "gpu or not gpu" -p no:cacheprovider 2>&1 | tail -25; } > gpurun_out/asan_fuzz.log 2>&1
+{ echo "# host ASAN run: $(date -u) runtime $RT"; python -m pytest tests/test_fuzz_gpu.py tests/test_abi.py tests/test_kernels_gpu.py tests/test_x3_gpu.py -q -m "gpu or not gpu" -p no:cacheprovider 2>&1 | tail -25; } > gpurun_out/asan_fuzz.log 2>&1
 unset LD_PRELOAD
 cp /tmp/libgeogcn_plain.so geographconv_amd/libgeogcn.so
 grep -c "ERROR: AddressSanitizer" gpurun_out/asan_fuzz.log
