@@ -303,6 +303,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
 
 int main(int argc, char** argv) {
     if (argc >= 3 && !strcmp(argv[1], "loop")) { g_only = atoi(argv[2]); g_loop_reps = 4000; }
+    if (argc >= 3 && !strcmp(argv[1], "pmc")) { g_only = atoi(argv[2]); g_loop_reps = 5; }          // one variant, few launches (rocprofv3 --pmc)
     const int64_t M = 440000;
     const int K = 300;
     const int64_t lda = 300;
