@@ -42,6 +42,17 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t (&p)[3]
     p[2] = bf16_pack(s0, s1);
 }
 
+// truncation split (probe): x = t1 + t2 + t3 EXACTLY as well (the top 8 significant bits three times), bit masks + subtracts only
+__device__ __forceinline__ void split3_pair_trunc(float x0, float x1, uint32_t (&p)[3]) {
+    const uint32_t u0 = __float_as_uint(x0) & 0xffff0000u, u1 = __float_as_uint(x1) & 0xffff0000u;
+    p[0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0), r1 = x1 - __uint_as_float(u1);
+    const uint32_t v0 = __float_as_uint(r0) & 0xffff0000u, v1 = __float_as_uint(r1) & 0xffff0000u;
+    p[1] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0), s1 = r1 - __uint_as_float(v1);
+    p[2] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int64_t bytes) {
     const uint32_t n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes);
     const uint64_t b = reinterpret_cast<uint64_t>(base);
@@ -98,8 +109,8 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
             const int idx = tt + 256 * i;
             const int r = idx / F4R, c = idx - r * F4R;
             uint32_t p01[3], p23[3];
-            split3_pair(v[i][0], v[i][1], p01);
-            split3_pair(v[i][2], v[i][3], p23);
+            if (PROBE & 2048) { split3_pair_trunc(v[i][0], v[i][1], p01); split3_pair_trunc(v[i][2], v[i][3], p23); }
+            else { split3_pair(v[i][0], v[i][1], p01); split3_pair(v[i][2], v[i][3], p23); }
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(As + pl * PLANE + r * PITCH + c * 8) = make_uint2(p01[pl], p23[pl]);
         }
@@ -361,6 +372,7 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 1024>("  probe: non-temporal A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 256 + 512 + 1024>("  probe: all three", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0>("  one chunk of 320, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 2048>("  probe: truncation split of A (B planes stay RNE)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 1>("  second block of a CU starts 8k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 2>("  second block of a CU starts 16k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 4>("  second block of a CU starts 32k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
