@@ -139,13 +139,15 @@ __global__ __launch_bounds__(TPB, 2) void x3_rows_kernel(const X3RowsArgs a) {
 #pragma unroll
                 for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             // B ring: slot j holds the three planes of column tile j for the k-step about to be multiplied and is refilled with the next
-            // k-step's as soon as its MFMAs have been issued (requests past the last step re-read it: no branch around a load)
+            // k-step's as soon as its MFMAs have been issued; nothing is requested past the last step (a wave-uniform branch: the re-read
+            // of the last step that a branch-free form costs was a tenth of the B stream -- 0.92 -> 0.88 ms for the dual launch,
+            // profiles/r05_x3_rows_micro_v12.txt)
             bf16x8 ring[WCT][3];
             auto bload = [&](bf16x8 (&b)[3], int j, int kt) {
-                const int kk = kt < NK ? kt : NK - 1;
+                if (kt >= NK) return;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((tile0 + j) * NK + kk) * 3 + pl) * 1024, 0));
+                    b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((tile0 + j) * NK + kt) * 3 + pl) * 1024, 0));
             };
 #pragma unroll
             for (int j = 0; j < WCT - 1; ++j) bload(ring[j], j, 0);

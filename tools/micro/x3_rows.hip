@@ -64,7 +64,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int6
 // PROBE: 1 = no C stores, 2 = no A loads (LDS holds garbage), 4 = no MFMAs, 8 = no B loads, 16 = one B plane loaded (a third of the
 // B bytes), 32 = every B load from the first 15 KB (L1 hits), 64 = no LDS fragment reads,
 // 256 = C stores as whole 128-byte lines (address pattern only: wrong values), 512 = non-temporal C stores, 1024 = non-temporal A loads
-template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1, int STG = 0>
+template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1, int STG = 0, int CONT = 0>
 __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
                                                          const unsigned short* __restrict__ Bf, int N, float* __restrict__ C,
                                                          int64_t ldc, int n_mt, int passes, long long* tim = nullptr) {
@@ -122,11 +122,25 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
 #pragma unroll 1
         for (int i = 0; i < STG; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    bf16x8 ring[RD][WCT][3];
+    if (false && CONT == 1 && !(PROBE & 8)) {          // the block's first pass: its first k-step's fragments (every later pass finds its own in the ring)
+#pragma unroll
+        for (int d = 0; d < RD; ++d)
+#pragma unroll
+            for (int j = 0; j < WCT; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ring[d][j][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((wid * passes * WCT + j) * NK + d) * 3 + pl) * 1024, 0));
+    }
     for (int mt = blockIdx.x; mt < n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
 #pragma unroll 1
         for (int ps = 0; ps < passes; ++ps) {
             const int tile0 = (wid * passes + ps) * WCT;
+            // (CONT) the column tiles of the pass after this one: the next pass of the tile, or the first pass of the block's next tile
+            const int tile0_next = (wid * passes + (ps + 1 < passes ? ps + 1 : 0)) * WCT;
+            const int tile0_next4 = __builtin_amdgcn_readfirstlane(tile0_next);
+            if (CONT == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (debug: every carried request landed before the pass begins)
             const int ncol0 = tile0 * 16;
             f32x4 acc[MR][WCT];
 #pragma unroll
@@ -135,15 +149,15 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                 for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             // B ring: slot j holds the three planes of column tile j for the k-step about to be multiplied; it is refilled with the
             // next k-step's as soon as its MFMAs have been issued
-            bf16x8 ring[RD][WCT][3];
             auto bload = [&](bf16x8 (&b)[3], int j, int kt) {
-                const int kk = kt < NK ? kt : NK - 1;
+                const int kk = kt < NK ? kt : (CONT ? kt - NK : NK - 1);
+                const int tsel = (CONT && kt >= NK) ? (CONT == 4 ? tile0_next4 : tile0_next) : tile0;
 #pragma unroll
                 for (int pl = 0; pl < ((PROBE & 16) ? 1 : 3); ++pl)
-                    b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (PROBE & 32) ? (j * 3 + pl) * 1024 : (((tile0 + j) * NK + kk) * 3 + pl) * 1024, 0));
+                    b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (PROBE & 32) ? (j * 3 + pl) * 1024 : (((tsel + j) * NK + kk) * 3 + pl) * 1024, 0));
                 if (PROBE & 16) { b[1] = b[0]; b[2] = b[0]; }
             };
-            if (!(PROBE & 8)) {
+            if (!(PROBE & 8) && ((CONT != 1 && CONT != 4) || (mt == (int)blockIdx.x && ps == 0))) {
 #pragma unroll
                 for (int d = 0; d < RD; ++d)
 #pragma unroll
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                             X3_TERM(0, 2) X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 1) X3_TERM(1, 0) X3_TERM(0, 0)
 #undef X3_TERM
                         }
-                        if (!(PROBE & 8)) bload(ring[ks % RD][j], j, kt + RD);
+                        if (!(PROBE & 8) && !(CONT == 2 && kt + RD >= NK)) bload(ring[ks % RD][j], j, kt + RD);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -258,7 +272,7 @@ static float h_bf16_f(unsigned short h) {
     return f;
 }
 
-template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1, int STG = 0>
+template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1, int STG = 0, int CONT = 0>
 static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC,
                 int64_t ldc, const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
     const int my = g_ordinal++;
@@ -267,7 +281,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     const int passes = N <= 4 * WCT * 16 ? 1 : 2;
     const size_t lds = (size_t)3 * BM * (KC * 2 + 16);
     static_assert(RD == 1 || (KC / 32) % RD == 0, "ring depth must divide the k-steps of a chunk");
-    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD, STG>;
+    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD, STG, CONT>;
     static long long* dT = nullptr;
     if (!dT) CK(hipMalloc(&dT, 64 * 8));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -286,7 +300,8 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
     double worst = 0;
-    const int64_t rows[] = {0, 1, 63, 64, 12345, M - 65, M - 1};
+    int nbad = 0;
+    const int64_t rows[] = {0, 1, 63, 64, 12345, 512 * 64 + 5, 3 * 512 * 64 + 64 * 7 + 1, M - 65, M - 1};
     std::vector<float> hc(N);
     for (int64_t r : rows) {
         CK(hipMemcpy(hc.data(), dC + r * ldc, (size_t)N * 4, hipMemcpyDeviceToHost));
@@ -297,6 +312,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
                 mag += fabs((double)hA[r * lda + k] * (double)hW[(size_t)k * N + n]);
             }
             worst = fmax(worst, fabs(s - hc[n]) / (1e-6 + mag));
+            if ((CONT == 1 || CONT == 4) && !PROBE && fabs(s - hc[n]) / (1e-6 + mag) > 1e-3 && nbad++ < 12) printf("      bad: row %lld col %d got %g want %g\n", (long long)r, n, hc[n], s);
         }
     }
     const double flops = 2.0 * M * N * K;
@@ -372,6 +388,12 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 1024>("  probe: non-temporal A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 256 + 512 + 1024>("  probe: all three", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0>("  one chunk of 320, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 1>("B ring carried across passes and tiles", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 3>("  carried AND re-filled (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 4>("  carried, next tile index through readfirstlane (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 2>("  no request past the last k-step, ring re-filled per pass", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 1, 64, 1, 0, 1>("  ... no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 1>("B ring carried across passes and tiles (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 2048>("  probe: truncation split of A (B planes stay RNE)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 1>("  second block of a CU starts 8k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 2>("  second block of a CU starts 16k cycles late", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
