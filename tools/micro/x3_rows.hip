@@ -157,12 +157,12 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                     b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (PROBE & 32) ? (j * 3 + pl) * 1024 : (((tsel + j) * NK + kk) * 3 + pl) * 1024, 0));
                 if (PROBE & 16) { b[1] = b[0]; b[2] = b[0]; }
             };
-            if (!(PROBE & 8) && ((CONT != 1 && CONT != 4) || (mt == (int)blockIdx.x && ps == 0))) {
+            if (!(PROBE & 8) && ((CONT != 1 && CONT != 4 && CONT != 5) || (mt == (int)blockIdx.x && ps == 0))) {
 #pragma unroll
                 for (int d = 0; d < RD; ++d)
 #pragma unroll
                     for (int j = 0; j < WCT; ++j) bload(ring[d][j], j, d);
-            } else {
+            } else if (PROBE & 8) {
 #pragma unroll
                 for (int d = 0; d < RD; ++d)
 #pragma unroll
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                             X3_TERM(0, 2) X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 1) X3_TERM(1, 0) X3_TERM(0, 0)
 #undef X3_TERM
                         }
-                        if (!(PROBE & 8) && !(CONT == 2 && kt + RD >= NK)) bload(ring[ks % RD][j], j, kt + RD);
+                        if (!(PROBE & 8) && !((CONT == 2 || CONT == 5) && kt + RD >= NK)) bload(ring[ks % RD][j], j, kt + RD);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -246,6 +246,10 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                 }
             }
             { const long long t = tick(); t_epi += t; }
+            if (CONT == 5 && !(PROBE & 8)) {          // (debug) the next pass's first fragments requested AFTER this pass's stores
+#pragma unroll
+                for (int j = 0; j < WCT; ++j) bload(ring[0][j], j, NK);
+            }
         }
     }
     if ((PROBE & 128) && tim && blockIdx.x == 7 && lane == 0) {
@@ -312,7 +316,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
                 mag += fabs((double)hA[r * lda + k] * (double)hW[(size_t)k * N + n]);
             }
             worst = fmax(worst, fabs(s - hc[n]) / (1e-6 + mag));
-            if ((CONT == 1 || CONT == 4) && !PROBE && fabs(s - hc[n]) / (1e-6 + mag) > 1e-3 && nbad++ < 12) printf("      bad: row %lld col %d got %g want %g\n", (long long)r, n, hc[n], s);
+            if ((CONT == 1 || CONT == 4 || CONT == 5) && !PROBE && fabs(s - hc[n]) / (1e-6 + mag) > 1e-3 && nbad++ < 12) printf("      bad: row %lld col %d got %g want %g\n", (long long)r, n, hc[n], s);
         }
     }
     const double flops = 2.0 * M * N * K;
@@ -389,6 +393,7 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 256 + 512 + 1024>("  probe: all three", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0>("  one chunk of 320, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<160, 2, 5, 0, 0, 64, 1, 0, 1>("B ring carried across passes and tiles", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 5>("  carried, requested after the stores (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 0, 3>("  carried AND re-filled (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 0, 4>("  carried, next tile index through readfirstlane (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 0, 2>("  no request past the last k-step, ring re-filled per pass", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
