@@ -6,7 +6,7 @@
 
 A "step" is one full-graph ``GraphConv.f_train``: forward + backward + Adam of the 3x300 highway
 GCN (BASELINE.json configs[2]: synthetic TwitterUS-shape CSR, N=440,000, nnz(A_hat)=10,730,596,
-V=10,000, C=256, fp32, dropout 0.5) with (A_hat, X, Y) already resident in HBM.  Every step runs
+V=10,000, C=256, fp32 in HBM and in every accumulator, dropout 0.5) with (A_hat, X, Y) already resident in HBM.  Every step runs
 3 graph-convolution layers forward and backward over the stored edges, so
 
     value = n_conv_layers * nnz(A_hat) * K / t_K        [GCN-layer fwd+bwd edges/s, whole job]
@@ -14,14 +14,25 @@ V=10,000, C=256, fp32, dropout 0.5) with (A_hat, X, Y) already resident in HBM. 
 (nominal: the output layer's backward product only walks the edges into the training nodes, because the
 cross-entropy gradient is zero elsewhere; `config.edges_traversed_per_step` has the exact count.)
 
-With --gpus N the SAME graph is row-partitioned over N ranks (strong scaling; per conv layer and
-direction the SpMM operand is exchanged over RCCL: in-place all-gather at 2 ranks, a feature
-repartition with two all-to-alls from 3 ranks -- DESIGN.md section 5).  The JSON line also carries
+GEMM precision: `geographconv_amd.tuning.GEMM_PRECISION` (default "bf16x3": fp32-class split-bf16 products where a kernel takes the shape,
+exact fp32 elsewhere; `dtype` stays "f32" -- inputs, outputs and accumulation are fp32 -- and `config.gemm` says what ran); at N = 1 the
+same job is timed again with the exact fp32 MFMA in every product (`alt_exact_f32`).
+
+With --gpus N the SAME graph is row-partitioned over N ranks (strong scaling; per conv layer and direction the SpMM operand is exchanged
+over RCCL -- DESIGN.md section 5).  The north_star's scheme (1-D row split of A_hat + all-gather of H) is timed FIRST and its line is
+printed at once (marked "early line"); the other schemes (feature repartition with two all-to-alls, slab-pipelined all-gather) and the
+partition check follow, each behind a try/except and a wall-clock guard (--scheme-timeout): whatever happens to them, the last line of
+stdout is one JSON line whose `value` is the fastest scheme that finished (`exchange_choice`, `alt`, `alt2`; a failed scheme is reported
+as {"exchange": ..., "error": ...}); `config.dist` carries the world size seen, the RCCL version and every rank's device.
+The JSON line also carries
   roofline       : the dominant kernel (spmm_rows_kernel, A_hat^T . dS at F=300: the two plain full-graph products of
                    a step), algorithmic bytes / average duration measured live with library-side hipEvent pairs on the
                    launch stream around every such product inside the timed region; `traffic` comes from a separate
-                   rocprofv3 --pmc pass (profiles/, `traffic_source` says which); `others` = the other hot kernels timed
-                   live in isolation on the same operands right after the timed region;
+                   rocprofv3 --pmc pass (profiles/, `traffic_source` says which); `gather_ceiling_tbps` = the rate at which this GPU
+                   gathers rows of the product's size from a table beyond L2, measured by this invocation (tools/micro/gather_bw.hip),
+                   and `frac_of_gather_ceiling` = counted traffic / launch time / that ceiling; `others` = the other hot kernels timed
+                   inside further steps right after the timed region;
+  layer          : SURVEY.md 8d (ii): one ConvolutionDenseLayer2 forward + backward and one highway block on the full graph, edges/s;
   step_ms        : median / p10 / p90 of the per-step times (events per step, same region);
   cpu_baseline   : the NumPy/SciPy oracle (oracle/gcn_oracle.py, kind "port": SpMM single-threaded like Theano's
                    StructuredDot, BLAS sgemm on all threads) timed on this box's host cores (rank 0, N=1 only);

@@ -174,11 +174,23 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
             for (int ch = 0; ch < NCH; ++ch) {
                 t_mark = tick();
                 if (!(PROBE & 2)) {
-                    if constexpr (PF != 0) {
+                    if constexpr (PF == 1) {
                         // (prefetched: the first chunk of a pass / tile was requested during the previous chunk's MFMAs)
                         if (mt == (int)blockIdx.x && ps == 0 && ch == 0) aload(pre, mt, 0);
                         __syncthreads();          // everybody done with the chunk before
                         astore(pre);
+                    } else if constexpr (PF == 2) {
+                        if (ch == 0) {
+                            // (the first chunk of a pass was requested ahead of the previous pass's stores)
+                            if (mt == (int)blockIdx.x && ps == 0) aload(pre, mt, 0);
+                            __syncthreads();
+                            astore(pre);
+                        } else {
+                            f32x4 v[ITERS];
+                            aload(v, mt, ch);
+                            __syncthreads();
+                            astore(v);
+                        }
                     } else {
                         f32x4 v[ITERS];
                         aload(v, mt, ch);
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                 }
                 __syncthreads();
                 { const long long t = tick(); t_load += t - t_mark; t_mark = t; }
-                if constexpr (PF != 0 && !(PROBE & 2)) {
+                if constexpr (PF == 1 && !(PROBE & 2)) {
                     // next chunk in program order: (ch + 1), else the next pass's chunk 0, else the next tile's
                     const int nch = ch + 1 < NCH ? ch + 1 : 0;
                     const int nmt = (ch + 1 < NCH || ps + 1 < passes) ? mt : mt + (int)gridDim.x;
@@ -222,6 +234,10 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                     }
                 }
                 { const long long t = tick(); t_mfma += t - t_mark; }
+            }
+            if constexpr (PF == 2 && !(PROBE & 2)) {
+                aload(pre, ps + 1 < passes ? mt : mt + (int)gridDim.x, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // epilogue
             // (t_mfma: everything since the last chunk's second barrier, all chunks of the pass)
@@ -392,6 +408,7 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 1024>("  probe: non-temporal A loads", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 256 + 512 + 1024>("  probe: all three", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<320, 1, 5, 0, 0>("  one chunk of 320, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 2, 0, 64, 1, 0, 1>("B ring carried + next pass's first A chunk ahead of the stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 0, 1>("B ring carried across passes and tiles", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 0, 5>("  carried, requested after the stores (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0, 64, 1, 0, 3>("  carried AND re-filled (debug)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
