@@ -118,60 +118,43 @@ __global__ __launch_bounds__(TPB, 2) void x3_rows_kernel(const X3RowsArgs a) {
     const int P = a.n_nseg == 2 ? a.passes[0] + a.passes[1] : a.passes[0];
     const int n_chunks = a.n_kseg == 2 ? a.nch[0] + a.nch[1] : a.nch[0];
     const int NK = a.nk_total;
-    // column tiles of pass ps of row tile mt for this wave: first tile inside its segment / inside the fragment array, tiles the wave
-    // takes per pass, whether its LAST tile holds a real column (wave-uniform)
-    struct PassTiles { int seg, ltile0, tile0, w; bool last_real; };
-    auto pass_tiles = [&](int mt, int ps) {
-        PassTiles t;
-        t.seg = ps >= a.passes[0] ? 1 : 0;
-        const int lps = t.seg ? ps - a.passes[0] : ps;
-        // column group of this wave, rotated with the row tile (gemm_rows_kernel: the group whose last tile is all padding visits every SIMD)
-        const int cg = (wid + mt) & 3;
-        t.w = t.seg ? a.wct[1] : a.wct[0];
-        t.ltile0 = (cg * (t.seg ? a.passes[1] : a.passes[0]) + lps) * t.w;
-        t.tile0 = (t.seg ? a.tile_base[1] : a.tile_base[0]) + t.ltile0;
-        t.last_real = __builtin_amdgcn_readfirstlane((int)(t.w == WCT && (int64_t)(t.ltile0 + WCT - 1) * 16 < (t.seg ? a.N[1] : a.N[0]))) != 0;
-        return t;
-    };
-    const int n_tiles_all = (a.n_nseg == 2 ? a.tile_base[1] + 4 * a.passes[1] * WCT : 4 * a.passes[0] * WCT);
-    const __amdgpu_buffer_rsrc_t brs = mk_rsrc(a.Bf, (int64_t)n_tiles_all * NK * 3072);
-    // B ring: slot j holds the three planes of column tile j for the k-step about to be multiplied and is refilled with the next
-    // k-step's as soon as its MFMAs have been issued.  It is carried ACROSS passes and row tiles: at a pass's last k-step the slots
-    // take the FIRST k-step of the pass that follows (the next pass of this row tile, or the first pass of the block's next one) --
-    // nothing is re-read, and those requests are in flight ahead of the epilogue's stores instead of queued behind them
-    // (tools/micro/x3_rows.hip: 0.924 -> 0.885 ms for the dual launch, of which the dropped re-read is 0.022)
-    bf16x8 ring[WCT][3];
-    auto bfrag = [&](bf16x8 (&b)[3], int tile, int kt) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile * NK + kt) * 3 + pl) * 1024, 0));
-    };
-    if ((int)blockIdx.x < a.n_mt) {          // the block's first pass
-        const PassTiles t = pass_tiles((int)blockIdx.x, 0);
-#pragma unroll
-        for (int j = 0; j < WCT - 1; ++j) bfrag(ring[j], t.tile0 + j, 0);
-        if (t.last_real) bfrag(ring[WCT - 1], t.tile0 + WCT - 1, 0);
-    }
     for (int mt = blockIdx.x; mt < a.n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
         const int64_t rows_here = std::min<int64_t>(BM, a.M - m0);
 #pragma unroll 1
         for (int ps = 0; ps < P; ++ps) {
-            const PassTiles pt = pass_tiles(mt, ps);
-            const int seg = pt.seg, w = pt.w, ltile0 = pt.ltile0, tile0 = pt.tile0;
-            const bool last_real = pt.last_real;
-            // the pass after this one (past the block's last tile: a tile that does not exist -- its fragments do, nobody multiplies them)
-            const PassTiles nx = ps + 1 < P ? pass_tiles(mt, ps + 1) : pass_tiles(mt + (int)gridDim.x, 0);
+            const int seg = ps >= a.passes[0] ? 1 : 0;                  // wave-uniform
+            const int lps = seg ? ps - a.passes[0] : ps;
+            // column group of this wave, rotated with the row tile (gemm_rows_kernel: the group whose last tile is all padding visits every SIMD)
+            const int cg = (wid + mt) & 3;
+            const int w = seg ? a.wct[1] : a.wct[0];
+            const int ltile0 = (cg * (seg ? a.passes[1] : a.passes[0]) + lps) * w;      // first column tile inside the segment
+            const int tile0 = (seg ? a.tile_base[1] : a.tile_base[0]) + ltile0;          // ... inside the fragment array
+            const bool last_real = __builtin_amdgcn_readfirstlane((int)(w == WCT && (int64_t)(ltile0 + WCT - 1) * 16 < (seg ? a.N[1] : a.N[0]))) != 0;
+            const int n_tiles_all = (a.n_nseg == 2 ? a.tile_base[1] + 4 * a.passes[1] * WCT : 4 * a.passes[0] * WCT);
+            const __amdgpu_buffer_rsrc_t brs = mk_rsrc(a.Bf, (int64_t)n_tiles_all * NK * 3072);
             f32x4 acc[MR][WCT];
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < WCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // (slot j after its MFMAs of k-step kt - 1: this pass's k-step kt, or the next pass's first)
+            // B ring: slot j holds the three planes of column tile j for the k-step about to be multiplied and is refilled with the next
+            // k-step's as soon as its MFMAs have been issued; nothing is requested past the last step (a wave-uniform branch: the re-read
+            // of the last step that a branch-free form costs was a tenth of the B stream: -0.05 ms per step, profiles/
+            // r05_x3_no_wasted_request_ab.txt).  Carrying the ring across passes and row tiles -- the next pass's first fragments
+            // requested at the last k-step, ahead of the epilogue's stores -- is 1.6 % faster still in the micro-benchmark
+            // (r05_x3_rows_micro_v18.txt) and 13 % SLOWER here: with this kernel's epilogues the loop-carried ring costs 50-110
+            // spilled registers (r05_x3_carried_ring_ab.txt); not taken
+            bf16x8 ring[WCT][3];
             auto bload = [&](bf16x8 (&b)[3], int j, int kt) {
-                if (kt < NK) bfrag(b, tile0 + j, kt);
-                else if (j < WCT - 1 || nx.last_real) bfrag(b, nx.tile0 + j, 0);
+                if (kt >= NK) return;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, (((tile0 + j) * NK + kt) * 3 + pl) * 1024, 0));
             };
+#pragma unroll
+            for (int j = 0; j < WCT - 1; ++j) bload(ring[j], j, 0);
+            if (last_real) bload(ring[WCT - 1], WCT - 1, 0);
 #pragma unroll 1
             for (int c = 0; c < n_chunks; ++c) {
                 {
@@ -227,9 +210,6 @@ __global__ __launch_bounds__(TPB, 2) void x3_rows_kernel(const X3RowsArgs a) {
                         constexpr int j = WCT - 1;
                         GEOGCN_X3_SIX(GEOGCN_ACC_, ring[j], GEOGCN_AF_, MR)
                         bload(ring[j], j, kt + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if (kt + 1 >= NK && nx.last_real) {          // (... but the pass after this one may need the slot)
-                        bfrag(ring[WCT - 1], nx.tile0 + WCT - 1, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #undef GEOGCN_ACC_
