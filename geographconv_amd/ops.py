@@ -396,7 +396,7 @@ GEMM_PRECISIONS = {'f32': _ffi.GEMM_F32, 'bf16x3': _ffi.GEMM_BF16X3, 'bf16': _ff
 GEMM_PRECISION = tuning.GEMM_PRECISION
 
 
-def _gemm_label(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None):
+def _gemm_label(A, B, out=None, transA=False, transB=False, bias=None, act=ACT_NONE, accumulate=False, precision=None, gate_carry=None):
     # 'gemm:<form>:<precision>:<M>:<N>:<K>:<bytes per element of C>:<accumulate>' (bench.py prices the entry from it)
     M, K = (A.F, A.n) if transA else (A.n, A.F)
     N = B.n if transB else B.F
