@@ -205,7 +205,11 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  *                      1.0-1.4e-7 sum|a.b| at K = 300, the exact kernel 1.4-1.5e-7), 2.7x fewer MFMA cycles.  It is a
  *                      PERMISSION, not a promise: shapes no split-bf16 kernel takes run exact fp32 (csrc/gemm_x3.hip: whole
  *                      rows of A for M >= 32,768, K <= 640, N <= 640; transA = 1 for 128 / 160 x 256 / 320 tiles; the
- *                      staged kernel of csrc/gemm_bf16.hip for any other transA = 0 shape);
+ *                      staged split-bf16 kernel of csrc/gemm_bf16.hip only where the output is feature panels,
+ *                      geogcn_gemm_panels_f32).  Non-finite operands: an Inf or NaN in A or B gives NaN in every output
+ *                      it reaches (the split's residual Inf - Inf), where the exact kernels would give Inf for an Inf times a
+ *                      non-zero; so does a finite |x| >= 0x1.ffp+127 (3.396e38: it rounds to the bf16 infinity).  Every other fp32
+ *                      value, subnormals included, splits exactly;
  *   GEOGCN_GEMM_BF16   one bf16 term per operand (BASELINE config 5: "bf16 H.W on MFMA, fp32 accumulate").
  * BF16 applies to both orientations: transA = 1 (dW, the
  * reduction over the node dimension) rounds both operands to bf16 on their way into LDS for outputs wider than

@@ -76,11 +76,63 @@ def test_x3_rows_single_products(dev, N, K):
     _check(dC.numpy(), ref + C0, mag, 'accumulate', extra=2e-7 * np.abs(ref + C0))
 
 
+@pytest.mark.parametrize("M", [32768, 32769])
+@pytest.mark.parametrize("N,K", [(640, 640), (513, 33), (200, 40), (193, 257)])
+def test_x3_rows_boundaries(dev, M, N, K):
+    """The threshold row count (a multiple of 64, and one row more: a last tile of ONE row), the widest K and N, a second column pass of
+    one tile, a K of one chunk with most of its k-steps past the end."""
+    from geographconv_amd import ops
+    A = _wide_range((M, K), 11)
+    B = _rand((K, N), 12, 0.1)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+    # the rows the check looks at: the first and last tiles and a sample in between (fp64 of the whole product takes a while at 640 x 640)
+    rows = np.unique(np.concatenate([np.arange(0, 130), np.arange(M - 130, M), np.random.RandomState(5).randint(0, M, 500)]))
+    ref = A[rows].astype(np.float64) @ B.astype(np.float64)
+    mag = np.abs(A[rows]).astype(np.float64) @ np.abs(B).astype(np.float64)
+    guard = torch.full((64 * ops.pad4(N),), 7.0, device=dev)          # right behind C in memory most of the time: a ragged tile must not write past row M
+    got = ops.gemm(dA, dB, precision='bf16x3')
+    _check(got.numpy()[rows], ref, mag, 'A.B %d x %d x %d' % (M, N, K))
+    assert bool((guard == 7.0).all())
+    full = got.t.cpu().numpy().reshape(M, got.ld)
+    assert not full[:, N:ops.pad4(N)].any()
+    exact = ops.gemm(dA, dB, precision='f32').numpy()
+    assert np.all(np.abs(got.numpy()[rows] - exact[rows]) <= 2 * ENV * mag + 1e-30)
+    # (a shape the split-bf16 kernel does not take runs the exact kernels: the same bits)
+    assert not np.array_equal(got.numpy(), exact), "the split-bf16 whole-rows kernel did not take %d x %d x %d" % (M, N, K)
+
+
+def test_x3_non_finite_operands_stay_visible(dev):
+    """include/geogcn.h: an Inf / NaN in an operand must come out as a non-finite value in every output it reaches (NaN under bf16x3, where
+    the exact kernels give Inf or NaN) and must not touch the other rows."""
+    from geographconv_amd import ops
+    M, N, K = M0, 300, 300
+    A = _rand((M, K), 21)
+    B = _rand((K, N), 22, 0.1)
+    clean = ops.gemm(ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev), precision='bf16x3').numpy()
+    A2 = A.copy()
+    A2[5, 7] = np.inf
+    A2[64 * 100 + 3, 0] = np.nan
+    A2[M - 1, K - 1] = -np.inf
+    A2[777, 10] = 3.4e38          # finite in fp32, beyond the largest bf16
+    got = ops.gemm(ops.DMat.from_numpy(A2, dev), ops.DMat.from_numpy(B, dev), precision='bf16x3').numpy()
+    hit = [5, 64 * 100 + 3, M - 1, 777]
+    assert not np.isfinite(got[hit]).any()
+    rest = np.setdiff1d(np.arange(M), hit)
+    assert np.array_equal(got[rest], clean[rest])
+    # A^T . B: a non-finite row of A poisons the columns of C it multiplies into -- here all of them in the poisoned row of A^T
+    At = _rand((40000, 300), 23)
+    Bt = _rand((40000, 300), 24)
+    At[123, 17] = np.inf
+    gt = ops.gemm(ops.DMat.from_numpy(At, dev), ops.DMat.from_numpy(Bt, dev), transA=True, precision='bf16x3').numpy()
+    assert not np.isfinite(gt[17]).any()
+    assert np.isfinite(np.delete(gt, 17, axis=0)).all()
+
+
 def test_x3_rows_shapes_really_take_the_kernel(dev):
     """(the tests above would pass on the staged kernel too: make sure the TwitterUS shapes are routed to the whole-rows kernel)"""
     for (N, K, tb) in [(300, 300, 0), (256, 300, 0), (300, 256, 1), (300, 300, 1)]:
         assert _takes_x3(440000, N, K, bool(tb)), (N, K, tb)
-    assert not _takes_x3(9475, 300, 300)            # CMU size: the staged split-bf16 kernel
+    assert not _takes_x3(9475, 300, 300)            # CMU size: not taken (such a call runs the exact fp32 kernels)
 
 
 @pytest.mark.parametrize("N0,N1,K", [(300, 300, 300), (256, 300, 300), (300, 129, 256), (600, 300, 300)])
