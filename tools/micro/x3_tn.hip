@@ -330,9 +330,13 @@ __global__ void reduce_kernel(int M, int N, int nsplit, const float* W, int64_t 
     C[e] = s;
 }
 
+static int g_loop_reps = 0, g_ordinal = 0, g_only = -1;          // `x3_tn loop <ordinal>`: one variant, 3,000 launches (tools/clock_watch.py)
+
 template <int BM, int BN, int PF, int PROBE, int IG = 0, int V2 = 0>
 static void run(const char* name, const float* dH, int M, const float* dG, int N, int64_t K, float* dW, float* dC, const std::vector<float>& hH,
                 const std::vector<float>& hG) {
+    const int my = g_ordinal++;
+    if (g_only >= 0 && my != g_only) return;
     const int n_mt = (M + BM - 1) / BM, n_nt = (N + BN - 1) / BN;
     const int tiles = n_mt * n_nt;
     int ns = 256 / tiles;
@@ -350,7 +354,7 @@ static void run(const char* name, const float* dH, int M, const float* dG, int N
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const int reps = 20;
+    const int reps = g_loop_reps ? g_loop_reps : 20;
     CK(hipEventRecord(e0));
     for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, dH, (int64_t)M, (int64_t)M, dG, (int64_t)N, (int64_t)N, K, dW, ldw, n_mt, n_nt, nsplit, kchunk);
     CK(hipEventRecord(e1));
@@ -374,11 +378,12 @@ static void run(const char* name, const float* dH, int M, const float* dG, int N
             }
             worst = fmax(worst, fabs(s - hc[(size_t)m * N + n]) / sa);
         }
-    printf("%-44s grid %4d (%d x %d tiles x %d slabs) lds %6d  %.3f ms  %.1f TF(fp32-equiv)   max err / sum|terms| %.2e\n", name, grid, n_mt, n_nt,
+    printf("[%2d] %-44s grid %4d (%d x %d tiles x %d slabs) lds %6d  %.3f ms  %.1f TF(fp32-equiv)   max err / sum|terms| %.2e\n", my, name, grid, n_mt, n_nt,
            nsplit, lds, ms, 2.0 * M * N * K / ms / 1e9, worst);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc >= 3 && !strcmp(argv[1], "loop")) { g_only = atoi(argv[2]); g_loop_reps = 3000; }
     const int64_t K = 440000;
     const int M = 300;
     for (int N : {600, 300, 256}) {
