@@ -27,8 +27,10 @@ as {"exchange": ..., "error": ...}); `config.dist` carries the world size seen, 
 The JSON line also carries
   roofline       : the dominant kernel (spmm_rows_kernel, A_hat^T . dS at F=300: the two plain full-graph products of
                    a step), algorithmic bytes / average duration measured live with library-side hipEvent pairs on the
-                   launch stream around every such product inside the timed region; `traffic` comes from a separate
-                   rocprofv3 --pmc pass (profiles/, `traffic_source` says which); `gather_ceiling_tbps` = the rate at which this GPU
+                   launch stream around every such product inside the timed region; `traffic` = the kernel's HBM-side bytes per
+                   launch counted by THIS invocation at N = 1 (--traffic live, the default: two `rocprofv3 --pmc` child passes of the same
+                   job for 2 steps, FETCH_SIZE and WRITE_SIZE separately, after the timed region; a stored pass under profiles/ when the
+                   counters cannot run -- `traffic_source` says which); `gather_ceiling_tbps` = the rate at which this GPU
                    gathers rows of the product's size from a table beyond L2, measured by this invocation (tools/micro/gather_bw.hip),
                    and `frac_of_gather_ceiling` = counted traffic / launch time / that ceiling; `others` = the other hot kernels timed
                    inside further steps right after the timed region;
@@ -477,6 +479,55 @@ def gather_ceiling(table_mb=512, row_bytes=1280):
         return {"error": repr(e)}
 
 
+def pmc_per_dispatch(directory, counter, kernel_substr):
+    """{(file, dispatch id): counter value} over every rocprofv3 counter table under `directory`, for the dispatches of kernels whose name
+    contains `kernel_substr` (a dispatch's rows -- one per counter instance when the tool splits them -- are summed)."""
+    import csv
+    import glob
+    per_dispatch = {}
+    for f in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row['Counter_Name'] == counter and kernel_substr in row['Kernel_Name']:
+                key = (f, row['Dispatch_Id'])
+                per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row['Counter_Value'])
+    return per_dispatch
+
+
+def traffic_live(child_args, kernel_substr, timeout=300.0):
+    """HBM-side bytes per launch of the dominant kernel, counted by THIS invocation: two `rocprofv3 --pmc` child passes (FETCH_SIZE, then
+    WRITE_SIZE -- one counter per pass, nothing else traced, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of this script with
+    `child_args` (the same job, 2 timed steps).  gfx950 correction of that guide: FETCH_SIZE tallies 128-byte read requests as 64 bytes,
+    so the read side is 2 x FETCH_SIZE.  Returns a dict with `bytes` or with `error` (the caller then falls back to the stored pass)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if 'rocprofiler' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+        return {"error": "this invocation runs under a profiler itself: no nested counter passes"}
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix='geogcn_pmc_', dir='/tmp')
+    kb, n_launch, secs = {}, {}, {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'p', '--', sys.executable, os.path.abspath(__file__)] + child_args
+            t0 = time.time()
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True, timeout=timeout)
+            secs[counter] = round(time.time() - t0, 1)
+            per_dispatch = pmc_per_dispatch(d, counter, kernel_substr)
+            if not per_dispatch:
+                return {"error": "pass %s: no dispatch of %s in the counter table (child rc %d: %s)" % (counter, kernel_substr, r.returncode, (r.stderr or '')[-300:])}
+            kb[counter] = sum(per_dispatch.values()) / len(per_dispatch)
+            n_launch[counter] = len(per_dispatch)
+        return {"bytes": (2.0 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024.0, "fetch_size_kb": kb['FETCH_SIZE'], "write_size_kb": kb['WRITE_SIZE'],
+                "launches_counted": n_launch, "pass_seconds": secs}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _git_commit():
     import subprocess
     try:
@@ -537,10 +588,19 @@ def main():
     ap.add_argument('--no-check', action='store_true', help='N > 1: skip the partition_check block')
     ap.add_argument('--no-extras', action='store_true', help='N = 1: skip alt_exact_f32, the layer block and the gather ceiling')
     ap.add_argument('--scheme-timeout', type=float, default=900.0, help='N > 1: wall-clock guard per scheme / check, seconds')
+    ap.add_argument('--traffic', default=None, choices=['live', 'stored', 'none'],
+                    help="roofline.traffic of the headline configuration at N = 1: live = two rocprofv3 --pmc child passes of this command run by "
+                         "this invocation (+ ~1 min; falls back to `stored` when they cannot run; the default without --no-extras); "
+                         "stored = the committed pass under profiles/ (the default with --no-extras)")
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child of a `--traffic live` pass: the timed steps only
     ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B aid: override an attribute of geographconv_amd/tuning.py for this run (e.g. --set FUSE_CARRY=0); '
                          'recorded in config.tuning_overrides -- a line with overrides is not the headline configuration')
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_extras, args.cpu_sample, args.traffic = True, 'none', 'none'
+    if args.traffic is None:
+        args.traffic = 'stored' if args.no_extras else 'live'
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
@@ -640,6 +700,7 @@ def main():
 
     bf16_operand = precision == 'bf16'
     n_conv = len(args.hid)
+    live_traffic = {}          # filled by the `--traffic live` passes (N = 1, headline configuration) before the line is built
 
     def run_scheme(c, prec=None):
         """W warm-up + K timed steps of one configuration -> everything the line needs from it."""
@@ -680,7 +741,13 @@ def main():
         achieved = alg / (avg_ms * 1e-3) / 1e9 if kern_ms else None
         traffic, traffic_source = None, None
         pmc_file = os.path.join(ROOT, 'profiles', 'pmc_spmm_bf16_latest.json' if bf16_operand else 'pmc_spmm_latest.json')
-        if os.path.exists(pmc_file) and world == 1 and F == 300 and args.shape == 'twus' and args.reorder is None:
+        if live_traffic.get("bytes"):
+            traffic = live_traffic["bytes"]
+            traffic_source = ("measured by this invocation: two rocprofv3 --pmc child passes (FETCH_SIZE, then WRITE_SIZE; one counter per pass) of this "
+                              "command with --steps 2 --warmup 1, averaged over the %s launches of %s they saw; 2 x FETCH_SIZE (gfx950: 128-byte "
+                              "requests tallied as 64) + WRITE_SIZE per launch; the counters tally L2 -> fabric requests, Infinity-Cache hits included"
+                              % (live_traffic["launches_counted"], live_traffic["kernel"]))
+        elif args.traffic != 'none' and os.path.exists(pmc_file) and world == 1 and F == 300 and args.shape == 'twus' and args.reorder is None:
             try:
                 pm = json.load(open(pmc_file))
                 traffic = pm.get('hbm_bytes_per_launch')
@@ -688,6 +755,8 @@ def main():
                                   "at state %s (commit %s; table %s), %s; 2 x FETCH_SIZE + WRITE_SIZE per launch; the counter tallies "
                                   "L2 -> fabric requests, Infinity-Cache hits included" % (pm.get('state'), pm.get('commit'), pm.get('summary'),
                                                                                          os.path.relpath(pmc_file, ROOT)))
+                if live_traffic.get("error"):
+                    traffic_source += "  [the live passes of this invocation did not run: %s]" % live_traffic["error"]
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "spmm_rows_kernel<%d,*> + spmm_long_reduce_kernel (A_hat^T . dS, F=%d%s)" % (
@@ -700,6 +769,8 @@ def main():
                                         "the timed region (the backward products of the hidden layers), hipEvent pairs recorded by "
                                         "the library on the launch stream around row kernel + long-row combine" % (F, int(csr.nnz)),
                     "edges_per_launch": int(csr.nnz), "bytes_per_edge": alg / max(1, int(csr.nnz))}
+        if live_traffic.get("bytes"):
+            roofline["traffic_counters"] = {k: live_traffic[k] for k in ("fetch_size_kb", "write_size_kb", "launches_counted", "pass_seconds")}
         roofline.update(extras.get("roofline", {}))
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
         di = None
@@ -817,13 +888,26 @@ def main():
         clf, g = first["clf"], first["g"]
         if world == 1:
             rf = {}
-            if args.shape != 'cmu':
+            if (args.traffic == 'live' and first["F"] == 300 and args.shape == 'twus' and args.reorder is None and not bf16_operand
+                    and not overrides and not force_dist):
+                # the dominant kernel's HBM-side traffic, counted now (the child runs the same job for 2 steps under the counters)
+                kern = 'spmm_rows_kernel<%d, 0, 16, 0, 0>' % ((first["F"] + 63) // 64)
+                child = ['--pmc-child', '--steps', '2', '--warmup', '1', '--shape', args.shape, '--dropout', str(args.dropout),
+                         '--gemm-precision', precision, '--hid'] + [str(h) for h in args.hid]
+                log('[bench] counting the HBM-side traffic of %s (two rocprofv3 --pmc child passes)...' % kern)
+                torch.cuda.synchronize()
+                live_traffic.update(traffic_live(child, kern))
+                live_traffic["kernel"] = kern
+                if live_traffic.get("error"):
+                    log('[bench] ... not counted: %s' % live_traffic["error"])
+            if args.shape != 'cmu' and not args.pmc_child:
                 try:
                     rf["others"] = other_kernels(clf, lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), g, args.hid, N, C, precision)
                 except Exception as e:                       # evidence only: never fail the headline line over it
                     rf["others_error"] = repr(e)
             try:
-                extras["clocks"] = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 3.0, torch.cuda.synchronize)
+                if not args.pmc_child:
+                    extras["clocks"] = ClockSampler(local).run(lambda: clf.f_train(X, y_tr, y_dev, A, tr, dev), 3.0, torch.cuda.synchronize)
             except Exception as e:
                 extras["clocks"] = {"error": repr(e)}
             if not args.no_extras and args.shape != 'cmu':

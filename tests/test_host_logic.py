@@ -240,6 +240,64 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
 
 
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_live_traffic_reads_the_counter_tables(tmp_path, monkeypatch):
+    """bench.py --traffic live: the two rocprofv3 --pmc child passes are parsed per dispatch (rows of one dispatch summed), only the named
+    kernel counts, 2 x FETCH_SIZE + WRITE_SIZE kilobytes -> bytes; a pass without the kernel, a missing tool and a profiler around the
+    invocation itself are reported as errors (the line then quotes the stored pass and says so)."""
+    import subprocess
+    bench = _load_bench()
+    head = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size",'
+            '"LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n')
+    kern = 'void geogcn::(anonymous namespace)::spmm_rows_kernel<5, 0, 16, 0, 0>(geogcn::SpmmArgs)'
+
+    def table(counter, values, other=123.0):
+        rows = [head]
+        for i, parts in enumerate(values):
+            for v in parts:          # (a dispatch split over several rows)
+                rows.append('%d,%d,"Agent 2",1,1,1,64,3,"%s",256,0,0,48,0,64,"%s",%f,10,20\n' % (i + 1, i + 1, kern, counter, v))
+        rows.append('99,99,"Agent 2",1,1,1,64,4,"void geogcn::(anonymous namespace)::spmm_rows_kernel<5, 1, 16, 0, 1>(x)",256,0,0,48,0,64,"%s",%f,10,20\n' % (counter, other))
+        return ''.join(rows)
+
+    calls = []
+
+    def fake_run(cmd, cwd=None, env=None, **kw):
+        counter = cmd[cmd.index('--pmc') + 1]
+        d = cmd[cmd.index('-d') + 1]
+        os.makedirs(os.path.join(d, 'host'), exist_ok=True)
+        vals = {'FETCH_SIZE': [[1000.0, 1000.0], [3000.0]], 'WRITE_SIZE': [[500.0], [700.0]]}[counter]
+        if not (counter == 'WRITE_SIZE' and calls and calls[0] == 'drop'):
+            open(os.path.join(d, 'host', 'p_counter_collection.csv'), 'w').write(table(counter, vals))
+        calls.append(counter)
+        assert '--pmc-child' in cmd and cwd == '/tmp' and env['TMPDIR'] == '/tmp'
+
+        class R:
+            returncode, stderr = 0, ''
+        return R()
+    for k in list(os.environ):
+        if k.startswith(('ROCPROF', 'ROCP_')):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv('LD_PRELOAD', '')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(bench.os.path, 'exists', lambda p, _e=os.path.exists: True if p.endswith('rocprofv3') else _e(p))
+    r = bench.traffic_live(['--pmc-child'], 'spmm_rows_kernel<5, 0, 16, 0, 0>')
+    assert r['fetch_size_kb'] == 2500.0 and r['write_size_kb'] == 600.0 and r['launches_counted'] == {'FETCH_SIZE': 2, 'WRITE_SIZE': 2}
+    assert r['bytes'] == (2 * 2500.0 + 600.0) * 1024
+    calls[:] = ['drop']
+    r = bench.traffic_live(['--pmc-child'], 'spmm_rows_kernel<5, 0, 16, 0, 0>')
+    assert 'error' in r and 'WRITE_SIZE' in r['error']
+    monkeypatch.setenv('ROCPROFILER_REGISTER_FORCE_LOAD', '1')
+    assert 'profiler' in bench.traffic_live(['--pmc-child'], 'x')['error']
+
+
 def test_dense_head_size_follows_the_cost_model():
     """ops.dense_head_size: the head panel of X^T . G takes whole GEMM tiles of the densest columns while a padded row of the
     split-K product (2 N flop per output column) is cheaper than gathering the entries it removes from the tail."""
