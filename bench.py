@@ -587,7 +587,8 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the first scheme')
     ap.add_argument('--no-check', action='store_true', help='N > 1: skip the partition_check block')
     ap.add_argument('--no-extras', action='store_true', help='N = 1: skip alt_exact_f32, the layer block and the gather ceiling')
-    ap.add_argument('--scheme-timeout', type=float, default=900.0, help='N > 1: wall-clock guard per scheme / check, seconds')
+    ap.add_argument('--scheme-timeout', type=float, default=None,
+                    help='N > 1: wall-clock guard per scheme / check, seconds (default 300; 900 under the host-staged functional-check backend)')
     ap.add_argument('--traffic', default=None, choices=['live', 'stored', 'none'],
                     help="roofline.traffic of the headline configuration at N = 1: live = two rocprofv3 --pmc child passes of this command run by "
                          "this invocation (+ ~1 min; falls back to `stored` when they cannot run; the default without --no-extras); "
@@ -629,6 +630,9 @@ def main():
     # ranks share cuda:0 and the collectives are staged through the host and gloo (geographconv_amd/dist.py)
     from geographconv_amd import dist as gdist
     staged = gdist.backend_name() == 'staged-gloo'
+    if args.scheme_timeout is None:
+        # a healthy scheme is a model build + W + K steps of tens of milliseconds: well under a minute on real links
+        args.scheme_timeout = 900.0 if staged else 300.0
     force_dist = os.environ.get('GEOGCN_BENCH_FORCE_DIST') == '1'      # exercise the partitioned path at world 1
     distributed = world > 1 or force_dist
     if distributed:
