@@ -326,7 +326,19 @@ def baseline_config(shape, hid, precision, world):
 
 
 def _free_port():
+    """A port for the rendezvous: below the range the kernel hands to outgoing connections (32768-60999 by default), so that none of the
+    job's own connects -- gloo / RCCL bootstrap pairs use ephemeral ports -- can take it between this probe and the launcher's bind."""
+    import random
     import socket
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e3))
+    for _ in range(64):
+        port = rng.randrange(20000, 32000)
+        with socket.socket() as so:
+            try:
+                so.bind(('127.0.0.1', port))
+                return port
+            except OSError:
+                continue
     with socket.socket() as so:
         so.bind(('127.0.0.1', 0))
         return so.getsockname()[1]
@@ -337,10 +349,19 @@ def self_launch(n):
     torch.distributed.run command the driver contract names) and hand their output through; rank 0 prints the line."""
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    log('[bench] --gpus %d without WORLD_SIZE: launching %s' % (n, ' '.join(cmd[1:9])))
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    rc = 1
+    for attempt in (0, 1):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        log('[bench] --gpus %d without WORLD_SIZE: launching %s' % (n, ' '.join(cmd[1:9])))
+        t0 = time.time()
+        rc = subprocess.run(cmd, env=env).returncode
+        # a launch that dies within seconds never got past the rendezvous (the port found free a moment ago was taken, a listener
+        # refused): one more try on another port; anything later is the job's own result
+        if rc == 0 or attempt == 1 or time.time() - t0 > 30.0:
+            break
+        log('[bench] the launch ended with code %d after %.0f s: once more on another port' % (rc, time.time() - t0))
+    raise SystemExit(rc)
 
 
 def timed_region(clf, step, steps, warmup, barrier, F_spmm, g):

@@ -225,6 +225,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
 
     def fake_run(cmd, env=None, **kw):
         seen['cmd'], seen['env'] = cmd, env
+        seen.setdefault('ports', []).append(cmd[cmd.index('--master-port') + 1])
         return R()
     monkeypatch.setattr(subprocess, 'run', fake_run)
     monkeypatch.delenv('WORLD_SIZE', raising=False)
@@ -238,6 +239,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
     assert 1024 < int(cmd[cmd.index('--master-port') + 1]) < 65536
     assert cmd[-8:] == ['--gpus', '4', '--steps', '3', '--warmup', '1', '--shape', 'cmu'] and cmd[-9].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert len(seen['ports']) == 2          # a launch that dies at once (here: code 7 in no time) is tried once more, on a port found anew
 
 
 def _load_bench():
