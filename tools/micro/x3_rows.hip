@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
 }
 
 static int g_loop_reps = 0;          // > 0: every run() launches this many times (clock / power watching: tools/clock_watch.py)
+static int g_ncu = 256;              // `loop <ordinal> <n>`: on n CUs only (CU-masked stream, n / 8 per XCD), the grid scaled by n / 256
+static hipStream_t g_stream = 0;
 static int g_ordinal = 0;
 static int g_only = -1;             // >= 0: only the run() with this ordinal
 
@@ -298,6 +300,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     const int my = g_ordinal++;
     if (g_only >= 0 && my != g_only) return;
     const int n_mt = (int)((M + BM - 1) / BM);
+    grid = grid * g_ncu / 256;
     const int passes = N <= 4 * WCT * 16 ? 1 : 2;
     const size_t lds = (size_t)3 * BM * (KC * 2 + 16);
     static_assert(RD == 1 || (KC / 32) % RD == 0, "ring depth must divide the k-steps of a chunk");
@@ -306,15 +309,15 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     if (!dT) CK(hipMalloc(&dT, 64 * 8));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(dC, 0, (size_t)M * ldc * 4));
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes, dT);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, g_stream, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes, dT);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int reps = g_loop_reps ? g_loop_reps : 20;
-    CK(hipEventRecord(e0));
-    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes, dT);
-    CK(hipEventRecord(e1));
+    CK(hipEventRecord(e0, g_stream));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, g_stream, dA, lda, M, K, dB, N, dC, ldc, n_mt, passes, dT);
+    CK(hipEventRecord(e1, g_stream));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
@@ -350,6 +353,14 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
 
 int main(int argc, char** argv) {
     if (argc >= 3 && !strcmp(argv[1], "loop")) { g_only = atoi(argv[2]); g_loop_reps = 4000; }
+    if (argc >= 4 && !strcmp(argv[1], "loop")) {
+        g_ncu = atoi(argv[3]);
+        g_loop_reps = 4000 * g_ncu / 256;
+        uint32_t words[8];
+        for (int x = 0; x < 8; ++x) words[x] = g_ncu / 8 >= 32 ? 0xffffffffu : ((1u << (g_ncu / 8)) - 1u);
+        CK(hipExtStreamCreateWithCUMask(&g_stream, 8, words));
+        printf("CU mask: %d CUs (%d per XCD)\n", g_ncu, g_ncu / 8);
+    }
     if (argc >= 3 && !strcmp(argv[1], "pmc")) { g_only = atoi(argv[2]); g_loop_reps = 5; }          // one variant, few launches (rocprofv3 --pmc)
     const int64_t M = 440000;
     const int K = 300;
