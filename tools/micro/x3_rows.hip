@@ -64,7 +64,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int6
 // PROBE: 1 = no C stores, 2 = no A loads (LDS holds garbage), 4 = no MFMAs, 8 = no B loads, 16 = one B plane loaded (a third of the
 // B bytes), 32 = every B load from the first 15 KB (L1 hits), 64 = no LDS fragment reads,
 // 256 = C stores as whole 128-byte lines (address pattern only: wrong values), 512 = non-temporal C stores, 1024 = non-temporal A loads
-template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1, int STG = 0, int CONT = 0>
+template <int KC, int NCH, int WCT, int PF, int PROBE = 0, int BM = 64, int RD = 1, int STG = 0, int CONT = 0, int AFPF = 0>
 __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K,
                                                          const unsigned short* __restrict__ Bf, int N, float* __restrict__ C,
                                                          int64_t ldc, int n_mt, int passes, long long* tim = nullptr) {
@@ -207,17 +207,55 @@ __global__ __launch_bounds__(256, (BM == 64 && RD == 1) ? 2 : 1) void x3_rows_ke
                     aload(pre, nmt, nch);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int kt = ch * KS + ks;
-                    bf16x8 af[MR][3];
+                // AFPF: the A fragments of k-step ks + 1 are read from LDS while k-step ks is multiplied (a single wave per SIMD has nobody
+                // to hide the ds_read latency behind)
+                bf16x8 afb[AFPF == 1 ? 2 : 1][MR][3];
+                auto afload = [&](bf16x8 (&a)[MR][3], int ks) {
 #pragma unroll
                     for (int i = 0; i < MR; ++i)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
-                            if (PROBE & 64) af[i][pl] = bf16x8{(short)i, (short)pl, 3, 4, 5, 6, 7, (short)ks};
-                            else af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLANE + (i * 16 + li) * PITCH + ks * 64 + lg * 16);
+                            if (PROBE & 64) a[i][pl] = bf16x8{(short)i, (short)pl, 3, 4, 5, 6, 7, (short)ks};
+                            else a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLANE + (i * 16 + li) * PITCH + ks * 64 + lg * 16);
                         }
+                };
+                // AFPF == 2: only the first half of the row tiles is read a k-step ahead; the second half is requested at the top of its own
+                // k-step and multiplied after the first half (24 MFMAs of cover), 144 instead of 192 fragment registers
+                constexpr int MH = MR / 2;
+                bf16x8 aflo[2][MH][3], afhi[MH][3];
+                auto afload_half = [&](bf16x8 (&a)[MH][3], int ks, int i0) {
+#pragma unroll
+                    for (int i = 0; i < MH; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLANE + ((i0 + i) * 16 + li) * PITCH + ks * 64 + lg * 16);
+                };
+                if (AFPF == 1) afload(afb[0], 0);
+                if (AFPF == 2) afload_half(aflo[0], 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int kt = ch * KS + ks;
+                    if (AFPF == 2) {
+                        afload_half(afhi, ks, MH);
+                        if (ks + 1 < KS) afload_half(aflo[(ks + 1) & 1], ks + 1, 0);
+#pragma unroll
+                        for (int j = 0; j < WCT; ++j) {
+#define X3_TERMH(PB, AF, I0)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) acc[I0 + i][j] =                                             \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ks % RD][j][PB], AF, acc[I0 + i][j], 0, 0, 0);
+                            X3_TERMH(0, aflo[ks & 1][i][2], 0) X3_TERMH(2, aflo[ks & 1][i][0], 0) X3_TERMH(1, aflo[ks & 1][i][1], 0)
+                            X3_TERMH(0, aflo[ks & 1][i][1], 0) X3_TERMH(1, aflo[ks & 1][i][0], 0) X3_TERMH(0, aflo[ks & 1][i][0], 0)
+                            X3_TERMH(0, afhi[i][2], MH) X3_TERMH(2, afhi[i][0], MH) X3_TERMH(1, afhi[i][1], MH)
+                            X3_TERMH(0, afhi[i][1], MH) X3_TERMH(1, afhi[i][0], MH) X3_TERMH(0, afhi[i][0], MH)
+#undef X3_TERMH
+                            if (!(PROBE & 8) && !((CONT == 2 || CONT == 5) && kt + RD >= NK)) bload(ring[ks % RD][j], j, kt + RD);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        continue;
+                    }
+                    if (AFPF) { if (ks + 1 < KS) afload(afb[(ks + 1) & 1], ks + 1); }
+                    else afload(afb[0], ks);
+                    bf16x8 (&af)[MR][3] = afb[AFPF == 1 ? (ks & 1) : 0];
 #pragma unroll
                     for (int j = 0; j < WCT; ++j) {
                         if (!(PROBE & 4)) {
@@ -294,7 +332,7 @@ static float h_bf16_f(unsigned short h) {
     return f;
 }
 
-template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1, int STG = 0, int CONT = 0>
+template <int KC, int NCH, int WCT, int PF, int PROBE, int BM = 64, int RD = 1, int STG = 0, int CONT = 0, int AFPF = 0>
 static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K, const unsigned short* dB, int N, float* dC,
                 int64_t ldc, const std::vector<float>& hA, const std::vector<float>& hW, int grid) {
     const int my = g_ordinal++;
@@ -304,7 +342,7 @@ static void run(const char* name, const float* dA, int64_t lda, int64_t M, int K
     const int passes = N <= 4 * WCT * 16 ? 1 : 2;
     const size_t lds = (size_t)3 * BM * (KC * 2 + 16);
     static_assert(RD == 1 || (KC / 32) % RD == 0, "ring depth must divide the k-steps of a chunk");
-    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD, STG, CONT>;
+    auto kern = x3_rows_kernel<KC, NCH, WCT, PF, PROBE, BM, RD, STG, CONT, AFPF>;
     static long long* dT = nullptr;
     if (!dT) CK(hipMalloc(&dT, 64 * 8));
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -444,6 +482,15 @@ int main(int argc, char** argv) {
         run<160, 2, 5, 0, 35>("  no A, no C, B loads hit L1, one block per CU", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         run<160, 2, 5, 0, 19>("  no A, no C, one B plane", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
         run<160, 2, 5, 0, 0>("x3 rows, 2 chunks of 160 (again)", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 128, 1, 0, 0, 1>("128 rows, A fragments one k-step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 11, 128, 1, 0, 0, 1>("  ... MFMAs only", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 3, 128, 1, 0, 0, 1>("  ... no A loads, no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 1, 0, 128, 1, 0, 0, 1>("128 rows, A fragments ahead, A chunk prefetched", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 0, 64, 1, 0, 0, 1>("64 rows, A fragments one k-step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 512);
+        run<160, 2, 5, 0, 0, 128, 1, 0, 0, 2>("128 rows, half the A fragments a k-step ahead", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 11, 128, 1, 0, 0, 2>("  ... MFMAs only", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 3, 128, 1, 0, 0, 2>("  ... no A loads, no C stores", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
+        run<160, 2, 5, 0, 0, 128, 1, 0, 2, 2>("  ... no B request past the last k-step", dA, lda, M, K, dF, N, dC, N, hA, hW, 256);
         CK(hipFree(dF));
     }
     return 0;
