@@ -34,13 +34,26 @@ def dump_obj(obj, filename, protocol=-1, serializer=pickle):
         serializer.dump(obj, fout, protocol)
 
 
+class _OldDumpUnpickler(pickle.Unpickler):
+    """The dumps the reference's users hold were written by Python 2.7 with the numpy / scipy of 2017 (README.md:32): their sparse
+    matrices name `scipy.sparse.csr` / `.csc` / `.coo` ... -- module paths scipy keeps only as deprecated aliases (gone in SciPy 2.0).
+    Every class of those modules lives in the public `scipy.sparse` namespace."""
+
+    def find_class(self, module, name):
+        if module.startswith('scipy.sparse.') and not module.startswith('scipy.sparse._') and hasattr(sps, name):
+            return getattr(sps, name)
+        return super().find_class(module, name)
+
+
 def load_obj(filename, serializer=pickle):
     with gzip.open(filename, 'rb') as fin:
-        try:
+        if serializer is not pickle:
             return serializer.load(fin)
-        except UnicodeDecodeError:               # python-2 pickles (README.md:32)
+        try:
+            return _OldDumpUnpickler(fin).load()
+        except UnicodeDecodeError:               # python-2 pickles (README.md:32): 8-bit strings, raw array bytes among them
             fin.seek(0)
-            return serializer.load(fin, encoding='latin1')
+            return _OldDumpUnpickler(fin, encoding='latin1').load()
 
 
 EARTH_RADIUS_KM = 6371.0088          # mean earth radius used by the `haversine` package the reference imports (gcnmain.py:20)

@@ -144,6 +144,39 @@ def test_dump_pkl_roundtrip_and_preprocess(tmp_path, monkeypatch):
         gcnmain.preprocess_data(str(tmp_path / 'nope'))
 
 
+def test_dump_pkl_written_by_python2_is_read(tmp_path):
+    """The dump.pkl a user of the reference holds is a Python-2 pickle (reference README.md:32; gcnmain.py:85-98 writes the 13-tuple):
+    8-bit strings -- the raw bytes of every array among them --, `scipy.sparse.csr.csr_matrix`, `numpy.core.multiarray`.  load_obj must
+    read it without help (plain pickle.load raises UnicodeDecodeError on it) and without leaning on scipy's deprecated module aliases."""
+    import pickletools
+    import warnings
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from py2_pickle import dumps
+    A = sps.random(50, 50, density=0.1, format='csr', dtype=np.float32, random_state=1)
+    X = sps.random(50, 30, density=0.2, format='csr', dtype=np.float32, random_state=0)
+    Y = np.arange(50) % 5
+    users = ['user%d' % i for i in range(49)] + [u'us\u00e9r49']          # one non-ASCII name: a Python-2 `unicode`
+    data = (A, X[:30], Y[:30], X[30:40], Y[30:40], X[40:], Y[40:], users[:30], users[30:40], users[40:],
+            {str(c): 30.0 + c for c in range(5)}, {str(c): -100.0 + c for c in range(5)}, {u: '40.7,-74.0' for u in users})
+    raw = dumps(data)
+    ops = {o.name for o, _, _ in pickletools.genops(raw)}
+    assert 'SHORT_BINSTRING' in ops and 'BINSTRING' in ops and 'BINBYTES' not in ops and 'SHORT_BINBYTES' not in ops
+    globs = {a for o, a, _ in pickletools.genops(raw) if o.name == 'GLOBAL'}
+    assert 'scipy.sparse.csr csr_matrix' in globs and 'numpy.core.multiarray _reconstruct' in globs
+    with pytest.raises(UnicodeDecodeError):
+        pickle.loads(raw)
+    f = tmp_path / 'dump.pkl'
+    with gzip.open(str(f), 'wb') as fout:
+        fout.write(raw)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')          # (scipy's "namespace is deprecated" warning would be an error here)
+        back = gcnmain.load_obj(str(f))
+    assert len(back) == 13 and sps.isspmatrix_csr(back[0]) and back[0].dtype == np.float32
+    assert (back[0] != A).nnz == 0 and (back[5] != X[40:]).nnz == 0 and np.array_equal(back[2], Y[:30]) and back[2].dtype == Y.dtype
+    assert back[7] == users[:30] and back[9][-1] == u'us\u00e9r49' and all(isinstance(u, str) for u in back[9])
+    assert back[10] == data[10] and back[12] == data[12]
+
+
 def test_reference_flag_set_is_accepted():
     # README.md:167,173 commands of the reference
     a = gcnmain.parse_args('-hid 300 300 300 -bucket 50 -batch 500 -d ./data/cmu -mindf 10 -reg 0.0 -dropout 0.5 -cel 5 -highway'.split())
