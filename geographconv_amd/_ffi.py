@@ -66,7 +66,6 @@ SIGNATURES = {
                                      c_ptr, c_i64, c_i32, c_i32, c_ptr, c_sz, c_ptr]),
     'geogcn_gemm_kcat_gated_f32': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                            c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_sz, c_ptr]),
-    'geogcn_debug_set_tn_slab_limit': (None, [c_i64]),
     'geogcn_gemm_dual_bf16_workspace_bytes': (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     'geogcn_gemm_dual_bf16': (c_i32, [c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32,
                                       c_ptr, c_i64, c_ptr, c_i32, c_ptr, c_sz, c_ptr]),

@@ -34,6 +34,12 @@ constexpr int kNumXCD = 8;
 
 void set_error(const char* fmt, ...);
 
+// The library's two TEST SEAMS (geographconv_amd/tuning.py lists them; nothing else in csrc/ reads the environment): an integer from the
+// environment, read at EVERY call so that a test's monkeypatch.setenv / delenv takes effect on the next launch (core.hip).
+//   GEOGCN_X3_ROWS_MIN_M     rows from which the split-bf16 whole-rows kernel takes an A . B (gemm_x3.hip; default 32,768)
+//   GEOGCN_TN_SLAB_LIMIT     bytes one buffer descriptor is taken to bound in the A^T . B slab kernels (gemm.hip; default 2^31 - 1)
+int64_t test_seam_i64(const char* name, int64_t dflt);
+
 #define GEOGCN_REQUIRE(cond, code, ...)             \
     do {                                            \
         if (!(cond)) {                              \
@@ -60,6 +66,20 @@ void set_error(const char* fmt, ...);
             return (int)e__;                                                   \
         }                                                                      \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, DEVICE): the attribute belongs to the device's copy of
+// the function, so a process that drives several GPUs sets it on each (a `static bool` per kernel set it on the first device only)
+struct LdsAttrOnce {
+    uint64_t done = 0;          // bit d: set on device d (devices >= 64: set at every launch)
+    int ensure(const void* kern, int bytes) {
+        int dev = 0;
+        GEOGCN_HIP(hipGetDevice(&dev));
+        if (dev < 64 && (done >> dev & 1)) return 0;
+        GEOGCN_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (dev < 64) done |= (uint64_t)1 << dev;
+        return 0;
+    }
+};
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,6 +1,8 @@
 // ABI version + thread-local error text for libgeogcn.so.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include <stdarg.h>
@@ -8,6 +10,14 @@
 namespace geogcn {
 namespace {
 thread_local char g_err[512] = "";
+}
+
+int64_t test_seam_i64(const char* name, int64_t dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long long v = strtoll(e, &end, 10);
+    return (end && *end == 0 && v > 0) ? (int64_t)v : dflt;
 }
 
 void set_error(const char* fmt, ...) {

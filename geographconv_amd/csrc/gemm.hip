@@ -477,7 +477,8 @@ struct TnDirectArgs {
     int64_t kchunk;
 };
 constexpr int TN_DEPTH = 5;
-int64_t kTnSlabByteLimit = 0x7FFFFFFFll;      // bytes one buffer descriptor bounds; geogcn_debug_set_tn_slab_limit lowers it (the fallback's test)
+// bytes one buffer descriptor bounds; the test seam GEOGCN_TN_SLAB_LIMIT (common.h) lowers it so that small operands reach the fallback
+inline int64_t tn_slab_byte_limit() { return test_seam_i64("GEOGCN_TN_SLAB_LIMIT", 0x7FFFFFFFll); }
 
 template <int MR, int NR>
 __global__ __launch_bounds__(512, 1) void gemm_tn_direct_kernel(const TnDirectArgs a) {
@@ -912,12 +913,8 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
 #define GEOGCN_GEMM_LAUNCH(ACT, MODE)                                                                    \
     do {                                                                                                  \
         auto kern = gemm_kernel<BM, BN, AT, BT, ACT, MODE, 0, WM, WN>;                                    \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done) {                                                                                 \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                           (int)Cfg::kLdsBytes));                                         \
-            attr_done = true;                                                                             \
-        }                                                                                                 \
+        static LdsAttrOnce lds_once;                                                                    \
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)Cfg::kLdsBytes)) return rc_; \
         hipLaunchKernelGGL(kern, grid, dim3(Cfg::NTH), Cfg::kLdsBytes, st, a);                             \
         GEOGCN_LAUNCH_CHECK("gemm_kernel");                                                               \
     } while (0)
@@ -950,7 +947,7 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
         // (a slab's rows must lie within one 2 GB buffer descriptor for its end to be a hardware bound -- checked on the slab these kernels
         //  actually take, after the cap above may have enlarged it; wider operands than the GCN's stay on the staged kernel)
         const int64_t max_ld = std::max(c.lda[0], std::max(c.ldb[0], c.n_nseg == 2 ? c.ldb[1] : 0));
-        const bool slab_ok = kchunk * max_ld * 4 < kTnSlabByteLimit;
+        const bool slab_ok = kchunk * max_ld * 4 < tn_slab_byte_limit();
         if (slab_ok && c.precision == GEOGCN_GEMM_BF16X3 && x3_tn_takes(BM, BN)) {
             // fp32-class split-bf16 products, operands transposed + split on their way into LDS (gemm_x3.hip)
             X3TnCall t{};
@@ -1112,30 +1109,21 @@ int launch_rows(const RowsArgs& a, int act, hipStream_t st) {
 #define GEOGCN_R(ACT)                                                                                            \
     do {                                                                                                         \
         auto kern = gemm_rows_kernel<KP, ACT>;                                                                   \
-        static bool attr_done = false;                                                                           \
-        if (!attr_done) {                                                                                        \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr_done = true;                                                                                    \
-        }                                                                                                        \
+        static LdsAttrOnce lds_once;                                                                           \
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_; \
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);                                      \
         GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");                                                                 \
     } while (0)
     if (a.gateG && a.postY) {
         auto kern = gemm_rows_kernel<KP, GEOGCN_ACT_NONE, true, true>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_done = true;
-        }
+        static LdsAttrOnce lds_once;
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_;
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);
         GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");
     } else if (a.gateG) {
         auto kern = gemm_rows_kernel<KP, GEOGCN_ACT_NONE, true>;          // (the gated form has no activation: geogcn_gemm_kcat_gated_f32)
-        static bool attr_done = false;
-        if (!attr_done) {
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_done = true;
-        }
+        static LdsAttrOnce lds_once;
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_;
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a);
         GEOGCN_LAUNCH_CHECK("gemm_rows_kernel");
     } else if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
@@ -1454,8 +1442,6 @@ int geogcn_gemm_dual_bf16(int64_t M, int64_t N0, int64_t N1, int64_t K, const fl
     return gemm_bf16_dual_dispatch(M, N0, N1, K, A, lda, B0, ldb0, B1, ldb1, C0, ldc0, c0_bf16, C1, ldc1, bias1, act1, ws, ws_bytes,
                                    (hipStream_t)stream);
 }
-
-void geogcn_debug_set_tn_slab_limit(int64_t bytes) { kTnSlabByteLimit = bytes > 0 ? bytes : 0x7FFFFFFFll; }
 
 int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                           int64_t ldb, float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,

@@ -380,12 +380,8 @@ int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
 #define GEOGCN_L(ACT)                                                                                          \
     do {                                                                                                        \
         auto kern = gemm_bf16_kernel<BM, BN, NS, ACT, NT>;                                                          \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                           Cfg::kLdsBytes));                                                    \
-            attr_done = true;                                                                                   \
-        }                                                                                                       \
+        static LdsAttrOnce lds_once;                                                                          \
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(Cfg::kLdsBytes))) return rc_; \
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NT), Cfg::kLdsBytes, st, a);                          \
         GEOGCN_LAUNCH_CHECK("gemm_bf16_kernel");                                                                \
     } while (0)
@@ -609,21 +605,15 @@ int launch_rows(const Bf16Args& a, int act, hipStream_t st) {
 #define GEOGCN_R(ACT)                                                                                           \
     do {                                                                                                        \
         auto kern = gemm_bf16_rows_kernel<KP, ACT>;                                                             \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr_done = true;                                                                                   \
-        }                                                                                                       \
+        static LdsAttrOnce lds_once;                                                                          \
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_; \
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);                             \
         GEOGCN_LAUNCH_CHECK("gemm_bf16_rows_kernel");                                                           \
     } while (0)
     if (a.gateG) {
         auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, true>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_done = true;
-        }
+        static LdsAttrOnce lds_once;
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_;
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);
         GEOGCN_LAUNCH_CHECK("gemm_bf16_rows_kernel");
     } else if (act == GEOGCN_ACT_TANH) GEOGCN_R(GEOGCN_ACT_TANH);
@@ -947,11 +937,8 @@ int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64
     do {                                                                                                        \
         auto kern = gemm_bf16_tn_kernel<BM_, BN_>;                                                              \
         constexpr int lds = 2 * (BM_ + BN_) * ROWB;                                                             \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr_done = true;                                                                                   \
-        }                                                                                                       \
+        static LdsAttrOnce lds_once;                                                                          \
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_; \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                  \
         GEOGCN_LAUNCH_CHECK("gemm_bf16_tn_kernel");                                                             \
     } while (0)

@@ -310,11 +310,8 @@ static int spmm_hot_launch(const char* fn, HotArgs a, int32_t n_hot, int32_t act
 #define GEOGCN_HOT(K, ACT, DROP)                                                                                    \
     do {                                                                                                            \
         auto kern = hot_kernel_for<K, ACT, DROP>(buf);                                                              \
-        static bool attr_done[2] = {false, false};                                                                  \
-        if (!attr_done[buf]) {                                                                                      \
-            GEOGCN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kHotLdsBytes)); \
-            attr_done[buf] = true;                                                                                  \
-        }                                                                                                           \
+        static LdsAttrOnce lds_once[2];                                                                  \
+        if (const int rc_ = lds_once[buf].ensure((const void*)kern, (int)(kHotLdsBytes))) return rc_; \
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);                                                 \
     } while (0)
 #define GEOGCN_HOT_ACT(K)                                                     \

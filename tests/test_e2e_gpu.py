@@ -58,6 +58,18 @@ def test_cmu_forward_logits_and_labels(cmu):
     assert np.abs(logits - ref64['logits']).max() <= LOGIT_ATOL
 
 
+def test_bf16x3_leg_runs_the_split_kernels_at_cmu_size(cmu, both_gemm_precisions, monkeypatch):
+    """What `both_gemm_precisions` means in this file: under 'bf16x3' the deterministic forward differs in bits from the exact-fp32
+    one (x3_rows_kernel ran: the library's test seam lowers its 32,768-row threshold), within the stated tolerance."""
+    from geographconv_amd import ops
+    c = cmu
+    probs = _clf(c).predict(c['X'], c['A'], c['te'])[1]
+    monkeypatch.setattr(ops, 'GEMM_PRECISION', 'f32')
+    exact = _clf(c).predict(c['X'], c['A'], c['te'])[1]
+    assert np.abs(probs - exact).max() <= PROB_ATOL
+    assert np.array_equal(probs, exact) == (both_gemm_precisions == 'f32')
+
+
 def test_cmu_train_step_matches_oracle(cmu):
     c = cmu
     clf = _clf(c)

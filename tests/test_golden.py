@@ -43,7 +43,9 @@ def test_oracle_reproduces_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
-def test_hip_path_matches_golden(name):
+def test_hip_path_matches_golden(name, both_gemm_precisions):
+    """Under 'f32' (exact fp32 MFMA) and under the default 'bf16x3' with the split-bf16 kernels forced onto these small shapes
+    (tests/conftest.py): the same tolerances."""
     z, A, X, params, cfg = load_case(name)
     clf = make_clf(cfg, params)
     clf.inject_dropout_mask(z['mask'])
@@ -72,6 +74,35 @@ def test_hip_path_matches_golden(name):
     srt = np.sort(z['val_probs'], axis=1)
     safe = (srt[:, -1] - srt[:, -2]) > 1e-4
     assert np.array_equal(pred[safe], z['val_pred'][safe])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_split_bf16_kernels_really_run_on_the_fixtures(name, monkeypatch):
+    """Proof that the 'bf16x3' leg of the test above is not the exact kernels under another label: with the library's test seam the first
+    training step's probabilities and gradients differ IN BITS from the exact-fp32 step's (and agree to the fp32 tolerance); without
+    the seam these sizes stay on the exact A . B kernels (only the A^T . B products are split)."""
+    from geographconv_amd import ops
+    from tests.conftest import force_x3_rows
+    z, A, X, params, cfg = load_case(name)
+    tr, dev, Y = z['tr'], z['dev'], z['Y']
+
+    def step(prec):
+        monkeypatch.setattr(ops, 'GEMM_PRECISION', prec)
+        clf = make_clf(cfg, params)
+        clf.inject_dropout_mask(z['mask'])
+        out = clf.f_train(X, Y[tr], Y[dev], A, tr, dev)
+        return np.asarray(out[4]).copy(), [g.copy() for g in clf.get_grads()]
+    P32, g32 = step('f32')
+    Pdef, gdef = step('bf16x3')                  # default threshold: forward = the exact kernels
+    assert np.array_equal(Pdef, P32)
+    force_x3_rows(monkeypatch)
+    Px3, gx3 = step('bf16x3')
+    assert not np.array_equal(Px3, P32), 'x3_rows_kernel did not run'
+    assert np.allclose(Px3, P32, rtol=1e-4, atol=PROB_ATOL)
+    assert any(not np.array_equal(a, b) for a, b in zip(gx3, g32))
+    for a, b in zip(gx3, g32):
+        assert np.allclose(a, b, rtol=GRAD_RTOL, atol=GRAD_ATOL + 1e-5 * np.abs(b).max())
 
 
 # ---- against reference-generated vectors, when somebody with a Theano install has produced them ------------------

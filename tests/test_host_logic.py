@@ -225,10 +225,11 @@ def test_content_keys_are_128_bit_and_frozen_arrays_are_hashed_once():
 
 def test_product_code_reads_only_the_documented_environment_variables():
     """geographconv_amd/tuning.py is the one table: four environment variables (+ the build script's GEOGCN_BUILD_DEFINES), no
-    getenv() in the kernels outside an ablation build."""
+    getenv() in the kernels outside an ablation build -- except through the ONE test-seam reader (csrc/core.hip test_seam_i64), whose two
+    names are pinned here as well."""
     import re
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'geographconv_amd')
-    seen = set()
+    seen, seams = set(), set()
     for dirpath, _, files in os.walk(root):
         for f in files:
             if f.endswith(('.py', '.hip', '.h')):
@@ -238,6 +239,9 @@ def test_product_code_reads_only_the_documented_environment_variables():
                 else:
                     src = re.sub(r'#ifdef GEOGCN_BF16_PROBE_BUILD.*?#endif', '', src, flags=re.S)
                     seen.update(re.findall(r'getenv\("(GEOGCN_[A-Z0-9_]+)"', src))
+                    assert len(re.findall(r'\bgetenv\(', src)) == (1 if f == 'core.hip' else 0), f      # only test_seam_i64 calls getenv
+                    seams.update(re.findall(r'test_seam_i64\("(GEOGCN_[A-Z0-9_]+)"', src))
+    assert seams == {'GEOGCN_X3_ROWS_MIN_M', 'GEOGCN_TN_SLAB_LIMIT'}, seams
     assert seen == {'GEOGCN_GEMM_PRECISION', 'GEOGCN_HIP_GRAPH', 'GEOGCN_DIST_EXCHANGE', 'GEOGCN_DIST_BACKEND',
                     'GEOGCN_BUILD_DEFINES'}, seen
 

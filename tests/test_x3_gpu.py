@@ -233,9 +233,9 @@ def test_x3_tn_dual(dev):
     assert np.array_equal(g0.numpy(), ops.gemm_dual(dA, d0, d1, transA=True, precision='bf16x3')[0].numpy())          # run to run
 
 
-def test_tn_slab_limit_falls_back_to_the_staged_kernel(dev):
+def test_tn_slab_limit_falls_back_to_the_staged_kernel(dev, monkeypatch):
     """A split-K slab that does not fit one buffer descriptor must not run on the kernels that end the slab with the descriptor
-    (the guard was taken on the slab before the slab-count cap enlarged it).  The limit is lowered through the test hook
+    (the guard was taken on the slab before the slab-count cap enlarged it).  The limit is lowered through the library's test seam
     so that small operands reach the fallback; results must not change beyond rounding."""
     from geographconv_amd import _ffi, ops
     K, M, N = 70000, 300, 300
@@ -243,14 +243,17 @@ def test_tn_slab_limit_falls_back_to_the_staged_kernel(dev):
     dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
     ref = A.T.astype(np.float64) @ B.astype(np.float64)
     mag = np.abs(A.T).astype(np.float64) @ np.abs(B).astype(np.float64)
-    lib = _ffi.lib()
-    try:
-        lib.geogcn_debug_set_tn_slab_limit(64 * 1024)
-        for prec in ('f32', 'bf16x3'):
-            _check(ops.gemm(dA, dB, transA=True, precision=prec).numpy(), ref, mag, 'staged fallback ' + prec)
-    finally:
-        lib.geogcn_debug_set_tn_slab_limit(0)
-    _check(ops.gemm(dA, dB, transA=True, precision='f32').numpy(), ref, mag, 'direct')
+    direct = {prec: ops.gemm(dA, dB, transA=True, precision=prec).numpy() for prec in ('f32', 'bf16x3')}
+    monkeypatch.setenv('GEOGCN_TN_SLAB_LIMIT', str(64 * 1024))          # the library's test seam (csrc/common.h), read at every call
+    for prec in ('f32', 'bf16x3'):
+        got = ops.gemm(dA, dB, transA=True, precision=prec).numpy()
+        _check(got, ref, mag, 'staged fallback ' + prec)
+        assert not np.array_equal(got, direct[prec]), 'the seam did not change the kernel (%s)' % prec
+    monkeypatch.delenv('GEOGCN_TN_SLAB_LIMIT')
+    for prec in ('f32', 'bf16x3'):
+        got = ops.gemm(dA, dB, transA=True, precision=prec).numpy()
+        _check(got, ref, mag, 'direct ' + prec)
+        assert np.array_equal(got, direct[prec])
 
 
 @pytest.mark.parametrize("seed", range(6))
