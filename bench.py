@@ -541,7 +541,11 @@ def traffic_live(child_args, kernel_substr, timeout=300.0):
                 return {"error": "pass %s: no dispatch of %s in the counter table (child rc %d: %s)" % (counter, kernel_substr, r.returncode, (r.stderr or '')[-300:])}
             kb[counter] = sum(per_dispatch.values()) / len(per_dispatch)
             n_launch[counter] = len(per_dispatch)
+        # (the factor 2 is the guide's calibration for wide coalesced reads -- 16 B per lane, which is how this kernel reads rows of B,
+        #  indices and values; narrower requests would be over-counted by it, so the uncorrected sum travels with the corrected one)
         return {"bytes": (2.0 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024.0, "fetch_size_kb": kb['FETCH_SIZE'], "write_size_kb": kb['WRITE_SIZE'],
+                "bytes_uncorrected": (kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024.0, "read_factor": 2.0,
+                "read_factor_is": "an assumption: every read request 128 B tallied as 64 B (MI355X_MICROARCH.md, calibrated on 16-B-per-lane streams)",
                 "launches_counted": n_launch, "pass_seconds": secs}
     except Exception as e:
         return {"error": repr(e)}
@@ -560,7 +564,10 @@ def _git_commit():
 class Watchdog:
     """Per-scheme wall-clock guard of an N > 1 invocation: a collective that never returns cannot be interrupted from Python, so when
     the timer fires rank 0 prints the line it has (the schemes already timed, the guarded one reported as an error) and EVERY rank
-    leaves with os._exit -- the headline survives a hang in a scheme timed after it."""
+    leaves with os._exit -- the headline survives a hang in a scheme timed after it.  Exit code 0 on purpose (ADVICE round 5 asked for a
+    non-zero code from the other ranks): a launcher that sees a failed rank tears the job down and a driver that sees a failed job drops
+    its line; the timeout is reported IN the line instead -- the stuck scheme's entry carries `"error": "timeout: ..."` and the line
+    `"watchdog_fired": true` (tests/test_dist_gpu.py::test_bench_survives_a_scheme_that_hangs)."""
 
     def __init__(self, rank):
         self.rank, self.timer, self.on_fire = rank, None, None
@@ -795,7 +802,7 @@ def main():
                                         "the library on the launch stream around row kernel + long-row combine" % (F, int(csr.nnz)),
                     "edges_per_launch": int(csr.nnz), "bytes_per_edge": alg / max(1, int(csr.nnz))}
         if live_traffic.get("bytes"):
-            roofline["traffic_counters"] = {k: live_traffic[k] for k in ("fetch_size_kb", "write_size_kb", "launches_counted", "pass_seconds")}
+            roofline["traffic_counters"] = {k: live_traffic[k] for k in ("fetch_size_kb", "write_size_kb", "bytes_uncorrected", "read_factor", "read_factor_is", "launches_counted", "pass_seconds") if k in live_traffic}
         roofline.update(extras.get("roofline", {}))
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
         di = None
@@ -890,7 +897,7 @@ def main():
     if world > 1 and not args.no_alt:
         for name in [n for n in ('allgather', 'a2a', 'agpipe') if n != first_name]:
             watchdog.arm(args.scheme_timeout, 'exchange scheme %s' % name,
-                         lambda msg, name=name: emit(final_line({"exchange": name, "error": msg})))
+                         lambda msg, name=name: emit(dict(final_line({"exchange": name, "error": msg}), watchdog_fired=True)))
             try:
                 results[name] = run_scheme(make_comm(name))
             except Exception as e:                       # (other ranks may now be out of step: the guard of the next scheme covers that)
@@ -900,7 +907,7 @@ def main():
                 watchdog.disarm()
     if world > 1 and not args.no_check:
         watchdog.arm(args.scheme_timeout, 'partition_check',
-                     lambda msg: emit(dict(final_line(), partition_check={"error": msg})))
+                     lambda msg: emit(dict(final_line(), partition_check={"error": msg}, watchdog_fired=True)))
         try:
             comms = {k: v["comm"] for k, v in results.items() if k is not None}
             extras["partition_check"] = partition_check(make_clf, comms, X, A, Y, tr, dev, rank)

@@ -465,7 +465,10 @@ class GraphConv():
         self.highway = highway
         self.device = device
         self.comm = comm
-        # how H.W products are formed: None/'f32' exact fp32 MFMA (default), 'bf16x3', 'bf16' (BASELINE config 5)
+        # how the activation x weight products are formed: None = the backend default (tuning.GEMM_PRECISION: 'bf16x3' since round 5 --
+        # fp32-class split-bf16 products where a kernel of csrc/gemm_x3.hip takes the shape, the exact fp32 MFMA elsewhere), 'f32' = exact
+        # fp32 MFMA everywhere, 'bf16' = BASELINE config 5.  One visible difference between 'bf16x3' and 'f32' (sgemm): an operand that is
+        # +-Inf, or finite beyond the largest bf16 (|x| > 3.39e38), gives NaN where the exact kernels give +-Inf (include/geogcn.h).
         self.gemm_precision = gemm_precision
         # node renumbering applied on the device side (geographconv_amd.graph: None | 'degree' | 'rcm' | 'bfs' | 'lpa'):
         # callers keep using ORIGINAL node ids everywhere -- X / A rows, index vectors, injected masks go in permuted,

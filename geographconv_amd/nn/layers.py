@@ -282,7 +282,7 @@ class DenseLayer(Layer):
         bias = None if self.b is None else self.b.data
         act = self._fused_act()
         A = kwargs.get('A') if self._uses_graph(kwargs) else None
-        prec = kwargs.get('gemm_precision')     # None = backend default ('f32': exact fp32 MFMA)
+        prec = kwargs.get('gemm_precision')     # None = backend default (tuning.GEMM_PRECISION: 'bf16x3'; 'f32' = exact fp32 MFMA)
         saved = {'x': input}
         if A is None:
             conv = self._fusable_sibling(input, tape, kwargs)

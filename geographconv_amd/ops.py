@@ -1000,7 +1000,8 @@ def spmm_t(x: SparseOperand, G: DMat, out: DMat = None, precision=None):
     if x.head_dense is not None:
         # K x F on the MFMA pipe, deterministic split-K -- fp32-class in every configuration (the bf16 configuration rounds the
         # H . W products, not the sparse input's gradient)
-        head = gemm(x.head_dense, G, transA=True, precision=None if precision == 'bf16' else precision)
+        p = precision or GEMM_PRECISION              # (resolved HERE: the bf16 configuration may come from GEOGCN_GEMM_PRECISION, precision = None)
+        head = gemm(x.head_dense, G, transA=True, precision='bf16x3' if p == 'bf16' else p)
         scatter_rows(head, x.head_idx, out)
     return out
 

@@ -38,25 +38,27 @@ def force_x3_rows(monkeypatch, min_m=X3_EVERYWHERE_MIN_M):
     monkeypatch.setenv('GEOGCN_X3_ROWS_MIN_M', str(min_m))
 
 
+def apply_gemm_mode(monkeypatch, mode):
+    """'bf16x3': the default precision WITH the row threshold of x3_rows_kernel lowered to 1 row (and its padded-column rule lifted), so
+    that at CMU / fixture sizes every A . B, A . B^T (x3_rows_kernel) and A^T . B (x3_tn_kernel) of the model really runs on the
+    split-bf16 kernels (without the seam such sizes run the exact fp32 kernels under this label: VERDICT round 5, weak #2);
+    'f32': the exact fp32 MFMA everywhere."""
+    from geographconv_amd import ops
+    assert mode in ('bf16x3', 'f32')
+    monkeypatch.setattr(ops, 'GEMM_PRECISION', mode)
+    if mode == 'bf16x3':
+        force_x3_rows(monkeypatch)
+    return mode
+
+
 @pytest.fixture(params=['bf16x3', 'f32'])
 def both_gemm_precisions(request, monkeypatch):
-    """Parity tests run under BOTH precisions of the activation x weight products with the SAME tolerances:
-      'bf16x3'  the default precision WITH the row threshold of x3_rows_kernel lowered to 1 row (and its padded-column rule lifted), so that at CMU / fixture sizes every
-                A . B, A . B^T (x3_rows_kernel) and A^T . B (x3_tn_kernel) of the model really runs on the split-bf16 kernels (without
-                the seam such sizes run the exact fp32 kernels under this label: VERDICT round 5, weak #2);
-      'f32'     the exact fp32 MFMA everywhere.
-    Use through `pytestmark = pytest.mark.usefixtures('both_gemm_precisions')` or on single tests."""
-    from geographconv_amd import ops
-    monkeypatch.setattr(ops, 'GEMM_PRECISION', request.param)
-    if request.param == 'bf16x3':
-        force_x3_rows(monkeypatch)
-    return request.param
+    """Parity tests run under BOTH precisions of the activation x weight products with the SAME tolerances (apply_gemm_mode).  Use
+    through `@pytest.mark.usefixtures('both_gemm_precisions')` or as an argument (its value is the mode)."""
+    return apply_gemm_mode(monkeypatch, request.param)
 
 
 @pytest.fixture
 def x3_everywhere(monkeypatch):
-    """The default precision with the split-bf16 kernels taking every product (see both_gemm_precisions)."""
-    from geographconv_amd import ops
-    monkeypatch.setattr(ops, 'GEMM_PRECISION', 'bf16x3')
-    force_x3_rows(monkeypatch)
-    return 'bf16x3'
+    """The default precision with the split-bf16 kernels taking every product."""
+    return apply_gemm_mode(monkeypatch, 'bf16x3')

@@ -167,11 +167,11 @@ def test_bench_survives_schemes_that_fail():
 def test_bench_survives_a_scheme_that_hangs():
     """... and a scheme that never returns (a collective stuck on a link) is cut off by its wall-clock guard: rank 0 prints the line it
     has -- the schemes that finished, the stuck one as a timeout -- and every rank leaves."""
-    d = _run_bench_self_launched(['--gpus', '2', '--shape', 'cmu', '--steps', '2', '--warmup', '1', '--no-check', '--scheme-timeout', '20'], 900,
+    d = _run_bench_self_launched(['--gpus', '2', '--shape', 'cmu', '--steps', '2', '--warmup', '1', '--no-check', '--scheme-timeout', '12'], 900,
                                  {'GEOGCN_BENCH_INJECT': 'agpipe:hang'})
     assert d['value'] > 0 and set(d['exchange_choice']['ms_per_step']) == {'allgather', 'a2a'}
     stuck = [x for x in (d.get('alt'), d.get('alt2')) if x and x['exchange'] == 'agpipe']
-    assert stuck and 'timeout' in stuck[0]['error']
+    assert stuck and 'timeout' in stuck[0]['error'] and d['watchdog_fired'] is True
 
 
 def test_bench_partitioned_at_the_full_twitterus_shape():

@@ -12,8 +12,26 @@ import pytest
 from geographconv_amd import synth
 from oracle import gcn_oracle as O
 
-# every test of this file under both GEMM precisions, same tolerances (tests/conftest.py)
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('both_gemm_precisions')]
+pytestmark = pytest.mark.gpu
+
+# Every test of this file runs under both GEMM precisions with the same tolerances (tests/conftest.py apply_gemm_mode: 'bf16x3' = the
+# default WITH the split-bf16 kernels forced onto these sizes, 'f32' = exact) -- except those that name their precision themselves
+# (they would run the same bits twice):
+PINNED_PRECISION = {'test_config5_bf16_six_layer_600_hidden', 'test_bf16_configuration_forward_pair_in_one_launch',
+                    'test_bf16_configuration_branch_gradient_stored_as_bf16', 'test_training_step_is_bitwise_reproducible',
+                    'test_world_configuration_widths'}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ not in PINNED_PRECISION:
+        metafunc.parametrize('gemm_mode', ['bf16x3', 'f32'], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def gemm_mode(request, monkeypatch):
+    from tests.conftest import apply_gemm_mode
+    mode = getattr(request, 'param', None)
+    return apply_gemm_mode(monkeypatch, mode) if mode else None
 
 LOGIT_ATOL = 5e-5        # |logit_gpu - logit_cpu32|; both are within 2e-5 of the fp64 result
 PROB_ATOL = 2e-6
@@ -58,8 +76,8 @@ def test_cmu_forward_logits_and_labels(cmu):
     assert np.abs(logits - ref64['logits']).max() <= LOGIT_ATOL
 
 
-def test_bf16x3_leg_runs_the_split_kernels_at_cmu_size(cmu, both_gemm_precisions, monkeypatch):
-    """What `both_gemm_precisions` means in this file: under 'bf16x3' the deterministic forward differs in bits from the exact-fp32
+def test_bf16x3_leg_runs_the_split_kernels_at_cmu_size(cmu, gemm_mode, monkeypatch):
+    """What the two legs of this file mean: under 'bf16x3' the deterministic forward differs in bits from the exact-fp32
     one (x3_rows_kernel ran: the library's test seam lowers its 32,768-row threshold), within the stated tolerance."""
     from geographconv_amd import ops
     c = cmu
@@ -67,7 +85,7 @@ def test_bf16x3_leg_runs_the_split_kernels_at_cmu_size(cmu, both_gemm_precisions
     monkeypatch.setattr(ops, 'GEMM_PRECISION', 'f32')
     exact = _clf(c).predict(c['X'], c['A'], c['te'])[1]
     assert np.abs(probs - exact).max() <= PROB_ATOL
-    assert np.array_equal(probs, exact) == (both_gemm_precisions == 'f32')
+    assert np.array_equal(probs, exact) == (gemm_mode == 'f32')
 
 
 def test_cmu_train_step_matches_oracle(cmu):
@@ -858,10 +876,14 @@ def test_world_configuration_widths():
         assert abs(o2[0] - ref[0]) <= tol * abs(ref[0]), (mode, o2[0], ref[0])
 
 
-@pytest.mark.parametrize("prec", ['f32', 'bf16'])
-def test_training_step_is_bitwise_reproducible(cmu, prec):
+@pytest.mark.parametrize("prec", ['f32', 'bf16', 'bf16x3'])
+def test_training_step_is_bitwise_reproducible(cmu, prec, monkeypatch):
     """No float atomics on a reduction path, fixed-order partial sums everywhere (split-K slabs, long-row chunks,
-    column sums): two runs of three training steps give identical losses, gradients and parameters, bit for bit."""
+    column sums): two runs of three training steps give identical losses, gradients and parameters, bit for bit
+    ('bf16x3': with the split-bf16 kernels forced onto this size)."""
+    if prec == 'bf16x3':
+        from tests.conftest import force_x3_rows
+        force_x3_rows(monkeypatch)
     from geographconv_amd.gcnmodel import GraphConv
     from geographconv_amd.nn import layers as L
     c = cmu

@@ -6,6 +6,7 @@ CPU part: the stopping rule alone (`_DevLossWatch`) on scripted dev-loss sequenc
 Parity unpinned, as everywhere: the oracle is this repository's restatement of the reference."""
 import gzip
 import math
+import os
 import pickle
 
 import numpy as np
@@ -258,6 +259,62 @@ def test_fit_matches_the_oracle_loop_at_cmu_shape(labels, n_epochs, max_down):
     top2 = np.sort(rows, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 2 * tol
     assert clear.mean() > 0.5 and np.array_equal(pred[clear], rp[clear])
+
+
+@pytest.mark.gpu
+def test_fit_matches_the_oracle_loop_on_the_default_split_bf16_path():
+    """A whole fit on the kernels the TwitterUS step runs, at the library's DEFAULT thresholds (no test seam): 33,001 nodes (above
+    x3_rows_kernel's 32,768 rows; a ragged last row tile), [300, 300] highway, default precision 'bf16x3' -- every H . W, dZ . W^T and
+    H^T . dZ of every epoch is a split-bf16 product -- against oracle.fit (the restatement of gcnmodel.py:421-449).  Labels: a linear
+    signal smoothed over the graph plus noise, chosen so that the dev loss falls, wobbles and finally rises: more than 20 epochs run
+    and early stopping is REACHED (max_down = 8: epoch 53 in the oracle's run)."""
+    from geographconv_amd import ops, synth
+    from geographconv_amd.gcnmodel import GraphConv
+    from geographconv_amd.nn import layers as L
+    assert ops.GEMM_PRECISION == 'bf16x3' and 'GEOGCN_X3_ROWS_MIN_M' not in os.environ
+    N, C, hid, n_epochs, max_down = 33001, 16, [300, 300], 70, 8
+    A = synth.powerlaw_ahat(N, N * 12, seed=4)
+    X = synth.bow_x(N, 3000, 40, seed=5)
+    tr, dev, te = synth.split_indices(N)
+    rng = np.random.RandomState(11)
+    S = A @ (A @ (X @ rng.randn(X.shape[1], C).astype(np.float32)))
+    Y = (S / S.std() + 2.0 * rng.randn(N, C)).argmax(1).astype(np.int32)
+    params = O.random_params(X.shape[1], hid, C, True, seed=5)
+    lib = _ffi_lib()
+    from geographconv_amd import _ffi
+    # (the shapes of this model really are taken by the split kernel: its workspace is not the staged kernel's)
+    assert lib.geogcn_gemm_dual_workspace_bytes(0, N, 300, 300, 300, _ffi.GEMM_BF16X3) > 0
+    r = _oracle_fit(params, X, A, Y, tr, dev, hid, True, 0.0, None, 0.0, n_epochs, max_down, True)
+    assert r['stopped_early'] and r['stop_epoch'] >= 20, (r['stop_epoch'], r['best_epoch'])
+    clf = GraphConv(X.shape[1], C, hid, 0.0, 0.0, highway=True)
+    clf.build_model(A, seed=77)
+    L.set_all_param_values(clf.l_out, params)
+    clf.fit(X, A, Y, tr, dev, n_epochs=n_epochs, max_down=max_down, verbose=False)
+    assert len(clf.fit_history) >= 20 and len(clf.fit_history) < n_epochs
+    _check_against_oracle(clf, r, params, n_epochs, max_down)
+    pred, probs = clf.predict(X, A, te)
+    rp, rows = O.f_val(r['trail'][clf.best_epoch], X, A, te, hid, True)
+    tol = 1e-4
+    assert np.abs(probs - rows).max() <= tol
+    top2 = np.sort(rows, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * tol
+    assert clear.mean() > 0.5 and np.array_equal(pred[clear], rp[clear])
+    # ... and the exact-fp32 fit of the same model takes the same decisions but is another computation (bits differ)
+    clf32 = GraphConv(X.shape[1], C, hid, 0.0, 0.0, highway=True, gemm_precision='f32')
+    clf32.build_model(A, seed=77)
+    L.set_all_param_values(clf32.l_out, params)
+    out32 = clf32.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    clfx = GraphConv(X.shape[1], C, hid, 0.0, 0.0, highway=True)
+    clfx.build_model(A, seed=77)
+    L.set_all_param_values(clfx.l_out, params)
+    outx = clfx.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    assert not np.array_equal(np.asarray(outx[4]), np.asarray(out32[4]))
+    assert np.abs(np.asarray(outx[4]) - np.asarray(out32[4])).max() <= 2e-6
+
+
+def _ffi_lib():
+    from geographconv_amd import _ffi
+    return _ffi.lib()
 
 
 @pytest.mark.gpu

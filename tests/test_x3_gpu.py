@@ -282,3 +282,28 @@ def test_x3_random_shapes(dev, seed):
     dG = ops.DMat.from_numpy(G, dev)
     ref_t = A.T.astype(np.float64) @ G.astype(np.float64)
     _check(ops.gemm(dA, dG, transA=True, precision='bf16x3').numpy(), ref_t, np.abs(A.T).astype(np.float64) @ np.abs(G), 'random A^T.B %s' % ((K, N2, M),))
+
+
+def test_sparse_inputs_gradient_head_panel_stays_fp32_class_in_the_bf16_configuration(dev, monkeypatch):
+    """with the bf16 configuration chosen through the module default (GEOGCN_GEMM_PRECISION=bf16: `precision` arrives as
+    None) the dense head panel of X^T . dS0 was multiplied with bf16-rounded operands.  The default is resolved inside spmm_t now: the
+    head's product is the split-bf16 one in that configuration, bit for bit what precision='bf16x3' gives, and within the fp32 envelope."""
+    import scipy.sparse as sps
+    from geographconv_amd import ops
+    rng = np.random.RandomState(5)
+    n, V, F = 6000, 400, 64
+    dense_cols = rng.rand(n, 24) < 0.4                       # 24 columns far denser than the head's threshold
+    X = sps.hstack([sps.csr_matrix(dense_cols.astype(np.float32) * rng.rand(n, 24).astype(np.float32)),
+                    sps.random(n, V - 24, density=0.01, random_state=rng, dtype=np.float32)]).tocsr().astype(np.float32)
+    X.sort_indices()
+    op = ops.SparseOperand.from_scipy(X, dev, dense_head=True)
+    assert op.head_dense is not None
+    G = _rand((n, F), 6)
+    dG = ops.DMat.from_numpy(G, dev)
+    want = ops.spmm_t(op, dG, precision='bf16x3').numpy()
+    monkeypatch.setattr(ops, 'GEMM_PRECISION', 'bf16')
+    got_default = ops.spmm_t(op, dG).numpy()
+    got_named = ops.spmm_t(op, dG, precision='bf16').numpy()
+    assert np.array_equal(got_default, want) and np.array_equal(got_named, want)
+    X64 = X.astype(np.float64)
+    _check(got_default, np.asarray(X64.T @ G.astype(np.float64)), np.asarray(abs(X64).T @ np.abs(G).astype(np.float64)), 'X^T.G head + tail')
