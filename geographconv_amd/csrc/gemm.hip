@@ -877,6 +877,21 @@ SplitPlan plan_grid(int64_t M, int64_t n_nt, int64_t K) {
         // over as many CUs as that allows instead of 18 slices of 16 stages on 256 CUs
         const int64_t max_ns = std::max<int64_t>(1, K / (BK * 4));
         ns = std::min(ns, max_ns);
+        if constexpr (WM == 2 && WN == 4) {
+            // (round 6) the wide tiles run one 8-wave block per CU with all tiles of a K slab on ONE XCD (32 CUs).  More tiles than that
+            // -- 900 x [900 | 900]: 36 -- and one slab per XCD takes two rounds with the second almost empty (measured: 0.21 of the bf16
+            // peak against 0.38 at 300 wide): take s slabs per XCD, s <= 8, so that tiles x s fills whole rounds of 32
+            constexpr int64_t cus = kNumCU / kNumXCD;
+            if (tiles > cus) {
+                int64_t best_s = 1, best_num = 0, best_den = 1;
+                for (int64_t sx = 1; sx <= 8; ++sx) {
+                    if (sx * kNumXCD > max_ns) break;
+                    const int64_t num = tiles * sx, den = cus * cdiv(tiles * sx, cus);          // efficiency num / den
+                    if (num * best_den > best_num * den) { best_s = sx; best_num = num; best_den = den; }
+                }
+                ns = best_s * kNumXCD;
+            }
+        }
         sp.kchunk = cdiv(cdiv(K, ns), BK) * BK;
         sp.nsplit = (int)cdiv(K, sp.kchunk);
     }
@@ -941,7 +956,7 @@ int launch_gemm(const GemmCall& c, void* ws, size_t ws_bytes, hipStream_t st) {
         const int T = a.n_mt * n_nt;
         int ns = sp.nsplit;
         const int ns_cap = kNumXCD * std::max(1, (kNumCU / kNumXCD) / T);
-        if (ns > ns_cap) ns = ns_cap;
+        if (T <= kNumCU / kNumXCD && ns > ns_cap) ns = ns_cap;          // (more tiles than an XCD has CUs: plan_grid chose whole rounds)
         const int64_t kchunk = ns == sp.nsplit ? sp.kchunk : cdiv(cdiv(c.K[0], ns), BK) * BK;
         const int nsplit = (int)cdiv(c.K[0], kchunk);
         // (a slab's rows must lie within one 2 GB buffer descriptor for its end to be a hardware bound -- checked on the slab these kernels
@@ -1006,9 +1021,12 @@ inline int pick_tile(int64_t n) {
 // block per CU.  Both streamed operands are staged once instead of once per N tile, and the 160x160 tile of the
 // 4-wave kernel only fits one block (= one wave per SIMD) per CU: 0.83 -> 0.755 ms at 440000x300x300.  For
 // NN / NT the 4-wave tiles with two blocks per CU measured 3 % faster, so those keep them.
-inline int wide_bn(int64_t N) {
+inline int wide_bn(int64_t N, int precision = GEOGCN_GEMM_F32) {
     if (N > 256 && N <= 320) return 320;
     if (N > 160 && N <= 256) return 256;
+    // (round 6) wider weight gradients under bf16x3 -- the reference's WORLD run, README.md:177-181: -hid 900 900 900, 930 classes -- in
+    // several wide tiles, so that gemm_x3.hip's A^T . B kernel takes them (900 -> 3 x 320, 512 -> 2 x 256); exact fp32 keeps its 4-wave tiles
+    if (N > 320 && precision == GEOGCN_GEMM_BF16X3) return cdiv(N, 320) * 320 <= cdiv(N, 256) * 256 ? 320 : 256;
     return 0;
 }
 
@@ -1043,8 +1061,8 @@ int dispatch_tiles(int bm, int bn, const GemmCall& c, void* ws, size_t ws_bytes,
 }
 
 // tile shape of a call: (bm, bn)
-inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int n_nseg, int& bm, int& bn) {
-    const int wbn = transA ? wide_bn(maxN) : 0;
+inline void choose_tiles(bool transA, bool transB, int64_t M, int64_t maxN, int n_nseg, int& bm, int& bn, int precision = GEOGCN_GEMM_F32) {
+    const int wbn = transA ? wide_bn(maxN, precision) : 0;
     bn = wbn ? wbn : pick_tile(maxN);
     if (transA) {
         bm = pick_tile(M);
@@ -1176,7 +1194,7 @@ int run_call(bool transA, bool transB, const GemmCall& c, void* ws, size_t ws_by
     if (const int kp = rows_kp(c, transA, transB); kp && ws && aligned16(ws) && ws_bytes >= rows_ws_bytes(c, kp))
         return run_rows(kp, transB, c, ws, st);          // (too small a workspace -- an older caller: the staged kernel)
     int bm, bn;
-    choose_tiles(transA, transB, c.M, c.maxN(), c.n_nseg, bm, bn);
+    choose_tiles(transA, transB, c.M, c.maxN(), c.n_nseg, bm, bn, c.precision);
     if (transA) return dispatch_tiles<true, false>(bm, bn, c, ws, ws_bytes, st);
     if (transB) return dispatch_tiles<false, true>(bm, bn, c, ws, ws_bytes, st);
     return dispatch_tiles<false, false>(bm, bn, c, ws, ws_bytes, st);
@@ -1188,8 +1206,8 @@ size_t splitk_ws_bytes(int64_t M, int64_t maxN, int n_nseg, int64_t K) {
     return sp.nsplit <= 1 ? 0 : (size_t)sp.nsplit * (size_t)M * (size_t)(((maxN + 3) & ~(int64_t)3) * n_nseg) * sizeof(float);
 }
 
-size_t transA_ws_bytes(int64_t M, int64_t maxN, int n_nseg, int64_t K) {
-    const int bm = pick_tile(M), bn = pick_tile(maxN), wbn = wide_bn(maxN);
+size_t transA_ws_bytes(int64_t M, int64_t maxN, int n_nseg, int64_t K, int precision) {
+    const int bm = pick_tile(M), bn = pick_tile(maxN), wbn = wide_bn(maxN, precision);
     if (wbn == 320) return bm == 160 ? splitk_ws_bytes<160, 320, 2, 4>(M, maxN, n_nseg, K) : splitk_ws_bytes<128, 320, 2, 4>(M, maxN, n_nseg, K);
     if (wbn == 256) return bm == 160 ? splitk_ws_bytes<160, 256, 2, 4>(M, maxN, n_nseg, K) : splitk_ws_bytes<128, 256, 2, 4>(M, maxN, n_nseg, K);
     if (bm == 128 && bn == 128) return splitk_ws_bytes<128, 128>(M, maxN, n_nseg, K);
@@ -1249,7 +1267,7 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
         const size_t h = gemm_bf16_tn_workspace_bytes(M, N, K);      // 0: shape left to the fp32 kernel
         if (h) return h;
     }
-    return transA_ws_bytes(M, N, 1, K);
+    return transA_ws_bytes(M, N, 1, K, precision);
 }
 
 size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, int32_t precision) {
@@ -1261,7 +1279,7 @@ size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, i
         const int kp = rows_kp(c, false);
         return kp ? rows_ws_bytes(c, kp) : 0;
     }
-    return transA_ws_bytes(M, std::max(N0, N1), 2, K);
+    return transA_ws_bytes(M, std::max(N0, N1), 2, K, precision);
 }
 
 size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, int32_t precision) {
@@ -1313,6 +1331,17 @@ static int gemm_entry(const char* fn, int32_t transA, int32_t transB, int64_t M,
     // GEOGCN_GEMM_BF16X3 is a permission: the split-bf16 kernels of gemm_x3.hip where they take the shape (run_call below), the staged
     // split-bf16 kernel for panel outputs, exact fp32 for everything else -- so that a fused launch and its separate launches stay
     // bit-identical at every size
+    if (!transA && precision == GEOGCN_GEMM_BF16X3 && panel_w && !c_bf16) {
+        // (round 6) the whole-rows split-bf16 kernel writes the panels itself where it takes the shape (the TwitterUS-size ranks' H . W);
+        // smaller calls: the staged split-bf16 kernel below, as before
+        GemmCall c{};
+        c.M = M; c.n_nseg = 1; c.n_kseg = 1;
+        c.A[0] = A; c.lda[0] = lda; c.B[0] = B; c.ldb[0] = ldb; c.C[0] = (float*)Cv; c.ldc[0] = ldc; c.bias[0] = bias;
+        c.N[0] = N; c.K[0] = K; c.act[0] = act; c.act[1] = GEOGCN_ACT_NONE; c.accumulate = 0;
+        c.panel_w = panel_w; c.panel_R = panel_R; c.precision = precision;
+        if (const int kc = x3_rows_kc(c, false, transB != 0); kc && ws && aligned16(ws) && ws_bytes >= x3_rows_ws_bytes(c, kc))
+            return x3_run_rows(kc, transB != 0, c, ws, st);
+    }
     if (!transA && (precision == GEOGCN_GEMM_BF16 || (precision == GEOGCN_GEMM_BF16X3 && panel_w)))
         return gemm_bf16_dispatch(precision, transB, M, N, K, A, lda, B, ldb, Cv, ldc, c_bf16, bias, act, accumulate, ws,
                                   ws_bytes, st, panel_w, panel_R);

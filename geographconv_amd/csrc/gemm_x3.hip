@@ -101,6 +101,7 @@ struct X3RowsArgs {
     int accumulate;
     const float* gateG; int64_t ldg; const float* gateT; int64_t ldt;                              // as RowsArgs (gemm.hip)
     const float* postY; int64_t ldy; const uint8_t* postKeep; int64_t postF; float postScale;
+    int panel_w; int64_t panel_R;       // single products only: C[0] as feature panels [N / panel_w][panel_R][panel_w] (the all-to-all's send layout, gemm.hip)
 };
 
 template <int KC, int ACT, bool GATE = false, bool POST = false>
@@ -300,7 +301,16 @@ __global__ __launch_bounds__(TPB, 2) void x3_rows_kernel(const X3RowsArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (col0 + r >= Nseg) x[r] = 0.f;
-                    if (row_ok && col0 < Nseg) *reinterpret_cast<float4*>(crow + col0) = make_float4(x[0], x[1], x[2], x[3]);
+                    if (row_ok && col0 < Nseg) {
+                        float* dst = crow + col0;
+                        if constexpr (!GATE && !POST) {
+                            if (a.panel_w) {          // (panel_w % 4 == 0: the four columns of a lane lie in one panel)
+                                const int64_t q = col0 / a.panel_w;
+                                dst = Cout + (q * a.panel_R + row) * a.panel_w + (col0 - q * a.panel_w);
+                            }
+                        }
+                        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+                    }
                     if (extra && i + 1 < MR) eload(i + 1, j);
                     if constexpr (POST) {
                         if (j + 1 < WCT) pload(i, j + 1);
@@ -439,8 +449,9 @@ __global__ __launch_bounds__(512, 1) void x3_tn_kernel(const X3TnCall a) {
 // the exact one under the label 'bf16x3'.
 constexpr int64_t kX3RowsMinM = 32768;
 inline int64_t x3_rows_min_m() { return test_seam_i64("GEOGCN_X3_ROWS_MIN_M", kX3RowsMinM); }
-inline int rows_passes(int64_t N) { return N <= 4 * kWCT * 16 ? 1 : 2; }
-inline int rows_wct(int64_t N) { return (int)cdiv(cdiv(N, 16), 4 * rows_passes(N)); }      // 5, or 4 (N <= 256, 321..512), or fewer
+constexpr int64_t kX3RowsMaxN = 1024, kX3RowsMaxK = 1024;          // (round 6: 640 until then; the reference's WORLD run is 900 / 930 wide)
+inline int rows_passes(int64_t N) { return (int)cdiv(N, 4 * kWCT * 16); }                  // column passes of 320 (300 -> 1, 600 -> 2, 900 -> 3)
+inline int rows_wct(int64_t N) { return (int)cdiv(cdiv(N, 16), 4 * rows_passes(N)); }      // 5, or 4 (N <= 256, 321..512, 961..1024), or fewer
 inline int chunks_of(int64_t K, int kc) { return (int)cdiv(K, kc); }
 inline size_t seg_tiles(int64_t N) { return (size_t)4 * rows_passes(N) * kWCT; }
 
@@ -468,22 +479,25 @@ int launch_x3_rows(const X3RowsArgs& a, int act, hipStream_t st) {
 }  // namespace
 
 // Shapes: every call gemm.hip's whole-rows kernel takes (the fused launches, single A . B^T, single A . B of 256 / 512 columns) and,
-// here, single A . B of ANY width up to 640 (the staged bf16x3 kernel is what such a call would run on otherwise); K up to 640 in chunks
-// of 160 (K <= 256: 128).  Returns the chunk width, 0 = not taken.
+// here, single A . B of ANY width up to 1,024 (the staged bf16x3 kernel is what such a call would run on otherwise); K up to 1,024 in
+// chunks of 160 (K <= 256: 128).  Returns the chunk width, 0 = not taken.
 int x3_rows_kc(const GemmCall& c, bool transA, bool transB) {
     (void)transB;
 #ifdef GEOGCN_NO_X3_ROWS          // A/B build only (GEOGCN_BUILD_DEFINES)
     return 0;
 #endif
     const int64_t min_m = x3_rows_min_m();
-    if (transA || c.panel_w || c.M < min_m || c.precision != GEOGCN_GEMM_BF16X3) return 0;
+    if (transA || c.M < min_m || c.precision != GEOGCN_GEMM_BF16X3) return 0;
+    // (round 6) panel outputs -- the partitioned path's H . W written straight into the all-to-all's send layout -- for single products
+    if (c.panel_w && (c.n_nseg != 1 || c.n_kseg != 1 || c.accumulate || c.gateG || c.postY)) return 0;
     const bool seam = min_m != kX3RowsMinM;                  // under the test seam: every shape the kernel CAN compute, not only those it is fast on
     const int64_t kmax = c.n_kseg == 2 ? std::max(c.K[0], c.K[1]) : c.K[0];
-    if (kmax > 640) return 0;
+    if (kmax > kX3RowsMaxK) return 0;
     const int kc = cdiv(kmax, 32) * 32 <= 256 ? 128 : 160;
-    if (c.n_kseg == 2 && c.N[0] > 320) return 0;              // one accumulator: one column pass
+    // (two K segments over several column passes -- dH = dZ . Wh^T + dU . Wt^T at 600 / 900 columns -- since round 6: a pass walks the chunks
+    //  of both segments into its accumulators like a single product's; gemm.hip's exact whole-rows kernel keeps one pass)
     for (int q = 0; q < c.n_nseg; ++q) {
-        if (c.N[q] > 640) return 0;
+        if (c.N[q] > kX3RowsMaxN) return 0;
         const int64_t cols = (int64_t)rows_passes(c.N[q]) * 4 * std::max(rows_wct(c.N[q]), 4) * 16;
         if (!seam && (cols - c.N[q]) * 4 > cols) return 0;    // at most a quarter of a pass multiplies zero columns
     }
@@ -506,6 +520,7 @@ int x3_run_rows(int kc, bool transB, const GemmCall& c, void* ws, hipStream_t st
     a.accumulate = c.accumulate;
     a.gateG = c.gateG; a.ldg = c.ldg; a.gateT = c.gateT; a.ldt = c.ldt;
     a.postY = c.postY; a.ldy = c.ldy; a.postKeep = c.postKeep; a.postF = c.postF; a.postScale = c.postScale;
+    a.panel_w = c.panel_w; a.panel_R = c.panel_R;
     const int ks = kc / 32;
     for (int q = 0; q < 2; ++q) {
         a.A[q] = c.A[q]; a.lda[q] = c.lda[q]; a.K[q] = (int)c.K[q];

@@ -209,6 +209,13 @@ class Comm:
         self.part = None if N is None else RowPartition(N, 1, 0)
         self.device = device
 
+    @property
+    def capturable(self):
+        """May a whole partitioned f_train step be recorded into a hipGraph and replayed (GraphConv(hip_graph=True))?  Only when every
+        collective is a stream-ordered device operation: RCCL through torch.distributed's nccl backend or the library's geogcn_comm_*
+        entry points (RCCL 2.26 collectives are capturable).  Host-staged transports (gloo, staged-gloo) are not."""
+        return False
+
     def prepare(self, A_host):
         """Hook called with the host adjacency before anything is partitioned (row-split balancing)."""
 
@@ -451,6 +458,17 @@ class TorchDistComm(Comm):
         self.halo = None                    # HaloPlan, built by graph_operand
         self.halo_rows = None               # rows received per exchange and rank under the halo scheme (prepare)
         self._bufs = {}
+
+    @property
+    def capturable(self):
+        if isinstance(self.dist, HostStagedGloo) or torch.device(self.device).type != 'cuda':
+            return False
+        if isinstance(self.dist, NativeRccl):
+            return True
+        try:
+            return self.dist.get_backend(self.group) == 'nccl'
+        except Exception:
+            return bool(getattr(self.dist, 'capturable', False))          # (a stand-in transport says so itself: tools/sim_rank.py)
 
     # -- row split ---------------------------------------------------------------------------------------
     def prepare(self, A_host):

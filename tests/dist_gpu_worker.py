@@ -210,8 +210,40 @@ def main():
                 assert np.allclose(got[1], ref[1], rtol=2e-2, atol=2e-3), what
                 for i, (g, r) in enumerate(zip(got[2], ref[2])):
                     assert np.allclose(g, r, rtol=5e-2, atol=5e-3 * np.abs(r).max() + 1e-6), (what, i)
+    # (round 6) the partitioned step captured in a hipGraph and replayed (GraphConv(hip_graph=True); transports that are stream-ordered
+    # RCCL only -- comm.capturable): six steps with the Philox dropout stream follow the eager run of the same partitioned model
+    A_, X_, Y_ = _synth.small_graph(5003, 9.0, 700, 12, 11, seed=5, empty_rows=3)
+    hid, C_ = [52, 52], 11
+    params = O.random_params(700, hid, C_, True, seed=6, scale=0.3)
+    perm = np.random.RandomState(7).permutation(5003)
+    tr_, dv_ = np.sort(perm[:2500]).astype(np.int32), np.sort(perm[2500:3500]).astype(np.int32)
+    n_captured = 0
+    # (host-staged transports -- the multi-rank one-GPU runs -- cannot be captured: GraphConv then stays eager, nothing to compare)
+    for exchange in ('allgather', 'a2a', 'agpipe', 'halo') if TorchDistComm(5003, device).capturable else ():
+        runs = {}
+        for mode in (False, True):
+            comm = TorchDistComm(5003, device, exchange=exchange)
+            clf = GraphConv(700, C_, hid, 1e-6, 0.5, highway=True, device=device, comm=comm, hip_graph=mode)
+            clf.build_model(None, seed=77)
+            L.set_all_param_values(clf.l_out, [q.copy() for q in params])
+            clf._force_dist = True
+            hist = []
+            for step in range(6):
+                o = clf.f_train(X_, Y_[tr_], Y_[dv_], A_, tr_, dv_)
+                hist.append([float(v) for v in o[:4]])
+            runs[mode] = (hist, clf.gather_output(o[4]), L.get_all_param_values(clf.l_out), clf)
+        (he, Pe, pe, _), (hg, Pg, pg, clfg) = runs[False], runs[True]
+        captured = clfg._hg is not None and clfg._hg.get('graph') is not None
+        assert captured == bool(comm.capturable), (exchange, captured, comm.capturable)
+        n_captured += int(captured)
+        assert len(set(h[0] for h in hg)) == 6, exchange                        # six different steps, not one replayed
+        for a, b in zip(he, hg):
+            assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[2] - b[2]) <= 1e-5 * abs(a[2]), (exchange, a, b)
+        assert np.abs(Pe - Pg).max() <= 1e-5, exchange
+        for q, r in zip(pe, pg):
+            assert np.abs(q - r).max() <= 2e-3 * 0.05 + 1e-7 and np.mean(np.abs(q - r)) <= 1e-7, exchange
     if dist.get_rank() == 0:
-        print('DIST_GPU_OK world=%d backend=%s' % (dist.get_world_size(), type(comm.dist).__name__))
+        print('DIST_GPU_OK world=%d backend=%s captured_schemes=%d' % (dist.get_world_size(), type(comm.dist).__name__, n_captured))
     dist.destroy_process_group()
 
 

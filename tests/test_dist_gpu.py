@@ -24,6 +24,7 @@ def test_torchrun_nccl_world1_matches_golden():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_GPU_OK world=%d' % n in r.stdout
+    assert 'captured_schemes=4' in r.stdout          # (round 6) the partitioned step under hipGraph, every exchange scheme, over RCCL
 
 
 def test_torchrun_native_rccl_entry_points_match_golden():
@@ -38,7 +39,7 @@ def test_torchrun_native_rccl_entry_points_match_golden():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_GPU_OK world=%d' % n in r.stdout
-    assert 'backend=NativeRccl' in r.stdout
+    assert 'backend=NativeRccl' in r.stdout and 'captured_schemes=4' in r.stdout
 
 
 def test_comm_entry_points_world1():

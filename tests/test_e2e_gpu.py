@@ -848,11 +848,17 @@ def test_degenerate_shapes_train_and_predict(N, V, C, hid, highway):
     assert np.isfinite(o16[0]) and np.all(np.isfinite(np.asarray(o16[4])))
 
 
-def test_world_configuration_widths():
+@pytest.mark.parametrize("x3_forced", [False, True])
+def test_world_configuration_widths(x3_forced, monkeypatch):
     """The reference's WORLD run uses hid 900 and 930 classes (README.md:180): widest supported SpMM operand
-    (K4 = 15), 6 x 160 GEMM tiles, the 16-register softmax / CE kernels -- against the oracle on a small graph."""
+    (K4 = 15), 6 x 160 GEMM tiles, the 16-register softmax / CE kernels -- against the oracle on a small graph.
+    `x3_forced`: with the library's test seam the 900 / 930-wide products of this 700-node graph run on the split-bf16
+    whole-rows kernel (three column passes, six K chunks: what a WORLD-size graph runs since round 6), same tolerances."""
     from geographconv_amd.gcnmodel import GraphConv
     from geographconv_amd.nn import layers as L
+    if x3_forced:
+        from tests.conftest import force_x3_rows
+        force_x3_rows(monkeypatch)
     A, X, Y = synth.small_graph(700, 8.0, 500, 25, 930, seed=8, hub=True, empty_rows=1)
     hid = [900, 900]
     params = O.random_params(X.shape[1], hid, 930, True, seed=2)
@@ -874,6 +880,12 @@ def test_world_configuration_widths():
         o2 = c2.f_train(X, Y[tr], Y[dev], A, tr, dev)
         tol = 2e-2 if mode == 'bf16' else 1e-5
         assert abs(o2[0] - ref[0]) <= tol * abs(ref[0]), (mode, o2[0], ref[0])
+    c32 = GraphConv(X.shape[1], 930, hid, 0.0, 0.0, highway=True, gemm_precision='f32')
+    c32.build_model(A, seed=77)
+    L.set_all_param_values(c32.l_out, params)
+    o32 = c32.f_train(X, Y[tr], Y[dev], A, tr, dev)
+    # (forced: the split kernel ran -- other bits than the exact kernels'; not forced: 700 rows stay on the exact A . B kernels)
+    assert np.array_equal(np.asarray(out[4]), np.asarray(o32[4])) == (not x3_forced)
 
 
 @pytest.mark.parametrize("prec", ['f32', 'bf16', 'bf16x3'])

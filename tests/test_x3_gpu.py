@@ -46,7 +46,8 @@ def _takes_x3(M, N, K, transB=False):
 M0 = 33000          # >= 32,768 rows: the whole-rows kernels; not a multiple of 64 (a ragged last tile)
 
 
-@pytest.mark.parametrize("N,K", [(300, 300), (256, 300), (300, 256), (600, 300), (129, 300), (300, 129), (640, 608), (100, 300)])
+@pytest.mark.parametrize("N,K", [(300, 300), (256, 300), (300, 256), (600, 300), (129, 300), (300, 129), (640, 608), (100, 300),
+                                 (900, 900), (930, 900), (900, 256), (1024, 1024), (641, 1000)])
 def test_x3_rows_single_products(dev, N, K):
     from geographconv_amd import ops
     A = _wide_range((M0, K), 1)
@@ -133,9 +134,13 @@ def test_x3_rows_shapes_really_take_the_kernel(dev):
     for (N, K, tb) in [(300, 300, 0), (256, 300, 0), (300, 256, 1), (300, 300, 1)]:
         assert _takes_x3(440000, N, K, bool(tb)), (N, K, tb)
     assert not _takes_x3(9475, 300, 300)            # CMU size: not taken (such a call runs the exact fp32 kernels)
+    # (round 6) the reference's WORLD widths (README.md:177-181: -hid 900 900 900, 930 classes): taken in both orientations
+    for (N, K, tb) in [(900, 900, 0), (900, 900, 1), (930, 900, 0), (900, 930, 1), (1024, 1024, 0)]:
+        assert _takes_x3(440000, N, K, bool(tb)), (N, K, tb)
+    assert not _takes_x3(440000, 1025, 300) and not _takes_x3(440000, 300, 1025)
 
 
-@pytest.mark.parametrize("N0,N1,K", [(300, 300, 300), (256, 300, 300), (300, 129, 256), (600, 300, 300)])
+@pytest.mark.parametrize("N0,N1,K", [(300, 300, 300), (256, 300, 300), (300, 129, 256), (600, 300, 300), (900, 900, 900)])
 def test_x3_rows_dual(dev, N0, N1, K):
     """The highway block's forward pair in one launch: (Z, T) = (H . Wh, sigmoid(H . Wt + bt))."""
     from geographconv_amd import ops
@@ -160,7 +165,7 @@ def test_x3_rows_dual(dev, N0, N1, K):
     assert np.abs(T.numpy() - Te.numpy()).max() <= 1e-5
 
 
-@pytest.mark.parametrize("N,K0,K1", [(300, 300, 300), (300, 256, 300), (256, 300, 300), (129, 300, 129)])
+@pytest.mark.parametrize("N,K0,K1", [(300, 300, 300), (300, 256, 300), (256, 300, 300), (129, 300, 129), (600, 600, 600), (900, 900, 900)])
 def test_x3_rows_kcat_and_epilogues(dev, N, K0, K1):
     """dH = dZ . Wh^T + dU . Wt^T: plain, accumulating, with the carry gradient, with the dropout + tanh gradient on top."""
     from geographconv_amd import ops
@@ -200,7 +205,8 @@ def test_x3_rows_kcat_and_epilogues(dev, N, K0, K1):
            extra=3e-7 * (np.abs(r1) + np.abs(G)))
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 300, 70000), (300, 256, 50001), (256, 300, 40000), (129, 300, 33333), (300, 600, 36000)])
+@pytest.mark.parametrize("M,N,K", [(300, 300, 70000), (300, 256, 50001), (256, 300, 40000), (129, 300, 33333), (300, 600, 36000),
+                                   (900, 900, 40000), (900, 930, 33001), (930, 900, 20000), (512, 1024, 20000)])
 def test_x3_tn(dev, M, N, K):
     """dW = H^T . dZ over the node dimension (split-K slabs combined in slab order)."""
     from geographconv_amd import ops
@@ -211,6 +217,8 @@ def test_x3_tn(dev, M, N, K):
     got = ops.gemm(dA, dB, transA=True, precision='bf16x3')
     _check(got.numpy(), ref, mag, 'A^T.B')
     assert np.array_equal(got.numpy(), ops.gemm(dA, dB, transA=True, precision='bf16x3').numpy())
+    # (x3_tn_kernel really took the shape: the exact kernels give other bits)
+    assert not np.array_equal(got.numpy(), ops.gemm(dA, dB, transA=True, precision='f32').numpy())
     C0 = _rand((M, N), 20)
     dC = ops.DMat.from_numpy(C0, dev)
     ops.gemm(dA, dB, out=dC, transA=True, accumulate=True, precision='bf16x3')
@@ -307,3 +315,37 @@ def test_sparse_inputs_gradient_head_panel_stays_fp32_class_in_the_bf16_configur
     assert np.array_equal(got_default, want) and np.array_equal(got_named, want)
     X64 = X.astype(np.float64)
     _check(got_default, np.asarray(X64.T @ G.astype(np.float64)), np.asarray(abs(X64).T @ np.abs(G).astype(np.float64)), 'X^T.G head + tail')
+
+
+@pytest.mark.parametrize("N,K,W,transB", [(300, 300, 8, False), (300, 300, 3, True), (256, 300, 4, False), (600, 300, 8, False), (129, 300, 2, False)])
+def test_x3_rows_panel_output(dev, N, K, W, transB):
+    """(round 6) The partitioned path's H . W written as feature panels -- the all-to-all's send layout [W][R][wp] -- by the whole-rows
+    split-bf16 kernel itself (until round 5 a bf16x3 panel product ran on the round-1 staged kernel): bit for bit the row-major product
+    of the same kernel, rearranged; bias + activation included; pad columns and pad rows untouched."""
+    from geographconv_amd import ops
+    M, R = M0, M0 + 3
+    A = _wide_range((M, K), 31)
+    B = _rand((N, K) if transB else (K, N), 32, 0.1)
+    bias = _rand((N,), 33)
+    dA, dB = ops.DMat.from_numpy(A, dev), ops.DMat.from_numpy(B, dev)
+    db = torch.from_numpy(np.pad(bias, (0, ops.pad4(N) - N))).to(dev)
+    wp = ops.pad4(-(-N // W))
+    for kw in (dict(), dict(bias=db, act=ops.ACT_TANH)):
+        rows = ops.gemm(dA, dB, transB=transB, precision='bf16x3', **kw).numpy()
+        p = ops.Panels(M, N, R, W, wp, dev)
+        p.t.fill_(7.0)
+        ops.gemm(dA, dB, out=p, transB=transB, precision='bf16x3', **kw)
+        t = p.t.view(W, R, wp).cpu().numpy()
+        got = t[:, :M, :].transpose(1, 0, 2).reshape(M, W * wp)
+        assert np.array_equal(got[:, :N], rows), (N, K, W, transB, bool(kw))
+        assert np.all(t[:, M:, :] == 7.0)                                   # pad rows: untouched
+        assert np.all(got[:, ops.pad4(N):] == 7.0)                          # columns beyond roundup4(N): untouched
+        assert np.all(got[:, N:ops.pad4(N)] == 0.0)                         # the float4 that holds column N - 1 is completed with zeros
+    # the staged split-bf16 kernel (what a panel product ran on before, and still runs on below the row threshold) gives other bits
+    small = ops.Panels(1000, N, 1000, W, wp, dev)
+    ops.gemm(ops.DMat.from_numpy(A[:1000], dev), dB, out=small, transB=transB, precision='bf16x3')
+    gs = small.t.view(W, 1000, wp).cpu().numpy().transpose(1, 0, 2).reshape(1000, W * wp)[:, :N]
+    ref = A[:1000].astype(np.float64) @ (B.T if transB else B).astype(np.float64)
+    mag = np.abs(A[:1000]).astype(np.float64) @ np.abs(B.T if transB else B).astype(np.float64)
+    _check(gs, ref, mag, 'staged panels')
+    _check(rows[:1000], ref, mag, 'whole-rows panels')

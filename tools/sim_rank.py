@@ -24,6 +24,8 @@ class _Done:
 
 
 class FakeDist:
+    capturable = True          # local copies on the launch stream: a captured step replays them
+
     class ReduceOp:
         SUM = 0
 
@@ -89,14 +91,15 @@ def main():
     ap.add_argument('--hid', nargs='+', type=int, default=[300, 300, 300])
     ap.add_argument('--gemm-precision', default='f32')
     ap.add_argument('--reorder', default=None, help="GraphConv(reorder=...): 'lpa' numbers communities contiguously")
+    ap.add_argument('--hip-graph', action='store_true', help="capture the rank's step in a hipGraph and replay it (round 6)")
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     A, X, Y, (tr, dv, te), C = synth.make_graph(args.shape)
     comm = SimComm(A.shape[0], dev, args.rank, args.world, args.exchange)
     clf = GraphConv(X.shape[1], C, args.hid, 0.0, 0.5, highway=True, device=dev, comm=comm, gemm_precision=args.gemm_precision,
-                    reorder=args.reorder)
+                    reorder=args.reorder, hip_graph=args.hip_graph)
     clf.build_model(A, seed=77)
-    for _ in range(2):
+    for _ in range(4 if args.hip_graph else 2):          # (two eager steps, then the capture, then a first replay)
         clf.f_train(X, Y[tr], Y[dv], A, tr, dv)
     torch.cuda.synchronize()
     d = comm.dist
@@ -108,8 +111,9 @@ def main():
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     if comm.halo_rows is not None:
         print('halo rows per rank and exchange: %s  (an all-gather delivers %d)' % (comm.halo_rows.tolist(), comm.part.N - comm.part.n_local))
-    print('world=%d rank=%d exchange=%s %s rows %d (of %d): %.2f ms compute per step; per step: %d all-to-all (%.0f MB on the wire), '
-          '%d all-gather (%.0f MB)' % (args.world, args.rank, comm.exchange, args.gemm_precision, comm.part.n_local, comm.part.N, ms,
+    print('world=%d rank=%d exchange=%s %s%s rows %d (of %d): %.2f ms compute per step; per step: %d all-to-all (%.0f MB on the wire), '
+          '%d all-gather (%.0f MB)' % (args.world, args.rank, comm.exchange, args.gemm_precision,
+                                       ' hipGraph' if args.hip_graph and clf._hg and clf._hg.get('graph') is not None else '', comm.part.n_local, comm.part.N, ms,
                                        d.n_a2a // args.steps, d.bytes_a2a / args.steps / 1e6, d.n_ag // args.steps,
                                        d.bytes_ag / args.steps / 1e6))
 
