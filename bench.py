@@ -23,7 +23,10 @@ over RCCL -- DESIGN.md section 5).  The north_star's scheme (1-D row split of A_
 printed at once (marked "early line"); the other schemes (feature repartition with two all-to-alls, slab-pipelined all-gather) and the
 partition check follow, each behind a try/except and a wall-clock guard (--scheme-timeout): whatever happens to them, the last line of
 stdout is one JSON line whose `value` is the fastest scheme that finished (`exchange_choice`, `alt`, `alt2`; a failed scheme is reported
-as {"exchange": ..., "error": ...}); `config.dist` carries the world size seen, the RCCL version and every rank's device.
+as {"exchange": ..., "error": ...}); `config.dist` carries the world size seen, the RCCL version and every rank's device.  Round 6: the
+--graph: the fastest capturable scheme (the all-gather ones: RCCL's all-to-all is not safe under capture, tools/rccl_capture_probe.py) is
+timed once more with its step captured in a hipGraph and replayed ("<scheme>+hipgraph", `config.hip_graph`; a candidate for `value` only
+if its last training loss follows the eager run's; off by default; never under the host-staged backend).
 The JSON line also carries
   roofline       : the dominant kernel (spmm_rows_kernel, A_hat^T . dS at F=300: the two plain full-graph products of
                    a step), algorithmic bytes / average duration measured live with library-side hipEvent pairs on the
@@ -303,7 +306,7 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
         kern = {'f32': 'gemm_tn_direct_kernel' if form == 'tn' else
                        ('gemm_rows_kernel' if (form == 'nt' or N_ in range(193, 257) or N_ in range(449, 513)) and M_ >= 32768 and N_ <= 640
                         and -(-K_ // 16) * 16 in (256, 304) else 'gemm_kernel'),
-                'bf16x3': ('x3_tn_kernel' if form == 'tn' and N_ > 160 else 'x3_rows_kernel' if form != 'tn' and M_ >= 32768 and N_ <= 640 and K_ <= 640
+                'bf16x3': ('x3_tn_kernel' if form == 'tn' and N_ > 160 else 'x3_rows_kernel' if form != 'tn' and M_ >= 32768 and N_ <= 1024 and K_ <= 1024
                            else 'exact fp32 kernel'),
                 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
         mfma("%s product %d x %d x %d (%s; C %s%s)" % ({'nn': 'A . B', 'nt': 'A . B^T', 'tn': 'A^T . B'}[form], M_, N_, K_, kern,
@@ -613,7 +616,12 @@ def main():
                     help="N > 1: the exchange scheme timed FIRST (auto: the north_star's all-gather); the others are timed after it, each "
                          "behind its own try/except and wall-clock guard, and `value` is the fastest that finished")
     ap.add_argument('--no-alt', action='store_true', help='N > 1: time only the first scheme')
+    ap.add_argument('--schemes', default='allgather,a2a,agpipe',
+                    help='N > 1: the exchange schemes timed (and checked) after the first one, comma-separated (default: all of them)')
     ap.add_argument('--no-check', action='store_true', help='N > 1: skip the partition_check block')
+    ap.add_argument('--graph', action='store_true',
+                    help='N > 1: time the fastest CAPTURABLE scheme (the all-gather ones) once more with its step captured in a hipGraph; off by '
+                         'default: one simulated rank gains 1 %% (profiles/r06_sim_rank_bf16x3.txt) and RCCL capture has only ever run at world 1 here')
     ap.add_argument('--no-extras', action='store_true', help='N = 1: skip alt_exact_f32, the layer block and the gather ceiling')
     ap.add_argument('--scheme-timeout', type=float, default=None,
                     help='N > 1: wall-clock guard per scheme / check, seconds (default 300; 900 under the host-staged functional-check backend)')
@@ -704,9 +712,9 @@ def main():
         from geographconv_amd.dist import TorchDistComm
         return TorchDistComm(N, device, exchange=exchange)
 
-    def make_clf(c, dropout, prec=None):
+    def make_clf(c, dropout, prec=None, hip_graph=False):
         m = GraphConv(X.shape[1], C, args.hid, 0.0, dropout, highway=True, device=device, comm=c,
-                      gemm_precision=prec or precision, reorder=args.reorder)
+                      gemm_precision=prec or precision, reorder=args.reorder, hip_graph=hip_graph)
         m.build_model(A, seed=77)
         m._force_dist = force_dist and c is not None
         return m
@@ -734,22 +742,27 @@ def main():
     n_conv = len(args.hid)
     live_traffic = {}          # filled by the `--traffic live` passes (N = 1, headline configuration) before the line is built
 
-    def run_scheme(c, prec=None):
-        """W warm-up + K timed steps of one configuration -> everything the line needs from it."""
-        how = inject.get(c.exchange if c is not None else 'single')
+    def run_scheme(c, prec=None, hip_graph=False):
+        """W warm-up + K timed steps of one configuration -> everything the line needs from it.  `hip_graph`: the step captured in a
+        hipGraph (two eager steps, the capture, then replays: at least four untimed steps before the timed region)."""
+        how = inject.get((c.exchange if c is not None else 'single') + ('+hipgraph' if hip_graph else ''))
         if how == 'raise':
             raise RuntimeError("injected failure (GEOGCN_BENCH_INJECT) in scheme %s" % c.exchange)
         if how == 'hang':
             while True:
                 time.sleep(1.0)
-        m = make_clf(c, args.dropout, prec)
+        m = make_clf(c, args.dropout, prec, hip_graph)
         # the dense operand of the timed SpMM: F = hid at one GPU; one feature panel per rank under the a2a scheme
         F = args.hid[-1]
         if c is not None and c.exchange == 'a2a':
             F = c.panel_width(args.hid[-1], bf16_operand)
         g = m._device_graph(X, A)
-        t, step_ms, kern_ms, last = timed_region(m, lambda: m.f_train(X, y_tr, y_dev, A, tr, dev), args.steps, args.warmup, barrier, F, g)
-        return {"comm": c, "clf": m, "g": g, "F": F, "t": reduce_max(t), "step_ms": step_ms, "kern_ms": kern_ms, "last": last}
+        t, step_ms, kern_ms, last = timed_region(m, lambda: m.f_train(X, y_tr, y_dev, A, tr, dev), args.steps,
+                                                 max(args.warmup, 4) if hip_graph else args.warmup, barrier, F, g)
+        if hip_graph and not (m._hg is not None and m._hg.get('graph') is not None):
+            raise RuntimeError("the step was not captured (transport not capturable, or the capture was dropped)")
+        return {"comm": c, "clf": m, "g": g, "F": F, "t": reduce_max(t), "step_ms": step_ms, "kern_ms": kern_ms, "last": last,
+                "hip_graph": bool(hip_graph)}
 
     notes = {'allgather': "the north_star's 1-D row split of A_hat + all-gather of H",
              'agpipe': "the north_star's 1-D row split of A_hat + all-gather of H in feature slabs, slab q + 1 on the wire while slab q is multiplied",
@@ -807,7 +820,7 @@ def main():
         nnz_bwd_out = int(g['A_tr'][1].nnz) if g.get('A_tr') is not None else nnz
         di = None
         if dist_info is not None:
-            di = dict(dist_info, exchange=comm.exchange,
+            di = dict(dist_info, exchange=comm.exchange + ('+hipgraph' if r.get("hip_graph") else ''),
                       data_path=type(comm.dist).__name__ if hasattr(comm, 'dist') and not isinstance(comm.dist, type(torch.distributed)) else "torch.distributed")
         out = {
             "metric": "GCN-layer fwd+bwd edges/sec", "value": n_conv * nnz * args.steps / t, "unit": "edges/s", "n_gpus": world,
@@ -825,6 +838,7 @@ def main():
                        "edges_per_step": n_conv * nnz,
                        "edges_traversed_per_step": 2 * (n_conv - 1) * nnz + nnz + nnz_bwd_out,
                        "parallelism": "rows%d" % world if world > 1 else "single",
+                       "hip_graph": bool(r.get("hip_graph")),
                        "world_size": world, "collectives": None if comm is None else ("%s, exchange = %s" % ("STAGED through the host + gloo (functional check, NOT a measurement)" if staged else "RCCL (torch.distributed nccl)", comm.exchange)),
                        "dist": di,
                        "reorder": args.reorder,
@@ -895,7 +909,7 @@ def main():
         return build_line(head, ex)
 
     if world > 1 and not args.no_alt:
-        for name in [n for n in ('allgather', 'a2a', 'agpipe') if n != first_name]:
+        for name in [n for n in args.schemes.split(',') if n and n != first_name]:
             watchdog.arm(args.scheme_timeout, 'exchange scheme %s' % name,
                          lambda msg, name=name: emit(dict(final_line({"exchange": name, "error": msg}), watchdog_fired=True)))
             try:
@@ -905,11 +919,33 @@ def main():
                 log('[bench] rank %d: exchange scheme %s failed: %r' % (rank, name, e))
             finally:
                 watchdog.disarm()
+    # (round 6, --graph) ... and the fastest capturable scheme once more with its step captured in a hipGraph and replayed (~60 launches per
+    # 4-5 ms rank-step at 8 ranks): a candidate for `value` like any other scheme when it follows the eager run's losses (same Philox
+    # stream, same number of steps: the last training loss must agree to 1e-3); behind the same guards
+    if world > 1 and args.graph and not staged:
+        done_now = {k: v for k, v in results.items() if k is not None and make_comm(k).capturable}
+        base = min(done_now, key=lambda e: done_now[e]["t"]) if done_now else None
+        if base is not None:
+            name = base + '+hipgraph'
+            watchdog.arm(min(args.scheme_timeout, 180.0), 'exchange scheme %s' % name,
+                         lambda msg, name=name: emit(dict(final_line({"exchange": name, "error": msg}), watchdog_fired=True)))
+            try:
+                r = run_scheme(make_comm(base), hip_graph=True)
+                r["kern_ms"] = r["kern_ms"] or done_now[base]["kern_ms"]          # (replays record no per-kernel events: the eager run's)
+                l0, l1 = float(done_now[base]["last"][0]), float(r["last"][0])
+                if not (abs(l1 - l0) <= 1e-3 * abs(l0)):
+                    raise RuntimeError("captured run's last training loss %r differs from the eager run's %r" % (l1, l0))
+                results[name] = r
+            except Exception as e:
+                failed.append({"exchange": name, "error": repr(e)})
+                log('[bench] rank %d: exchange scheme %s failed: %r' % (rank, name, e))
+            finally:
+                watchdog.disarm()
     if world > 1 and not args.no_check:
         watchdog.arm(args.scheme_timeout, 'partition_check',
                      lambda msg: emit(dict(final_line(), partition_check={"error": msg}, watchdog_fired=True)))
         try:
-            comms = {k: v["comm"] for k, v in results.items() if k is not None}
+            comms = {k: v["comm"] for k, v in results.items() if k is not None and '+' not in k}
             extras["partition_check"] = partition_check(make_clf, comms, X, A, Y, tr, dev, rank)
         except Exception as e:
             extras["partition_check"] = {"error": repr(e)}

@@ -461,6 +461,12 @@ class TorchDistComm(Comm):
 
     @property
     def capturable(self):
+        # Measured on the GPU box (tools/rccl_capture_probe.py, RCCL 2.26.6, world 1): all_reduce and all_gather_into_tensor -- blocking
+        # or async -- are captured and replayed; all_to_all_single (a group of point-to-point transfers) is NOT safe under capture
+        # (async: segmentation fault in capture_end; blocking: replays, then the communicator hangs at teardown).  So the all-gather
+        # schemes only; a2a / halo steps stay eager.
+        if self.exchange not in ('allgather', 'agpipe'):
+            return False
         if isinstance(self.dist, HostStagedGloo) or torch.device(self.device).type != 'cuda':
             return False
         if isinstance(self.dist, NativeRccl):

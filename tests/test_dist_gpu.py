@@ -24,7 +24,7 @@ def test_torchrun_nccl_world1_matches_golden():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_GPU_OK world=%d' % n in r.stdout
-    assert 'captured_schemes=4' in r.stdout          # (round 6) the partitioned step under hipGraph, every exchange scheme, over RCCL
+    assert 'captured_schemes=2' in r.stdout          # (round 6) the partitioned step under hipGraph over RCCL: the two all-gather schemes (all-to-all steps stay eager)
 
 
 def test_torchrun_native_rccl_entry_points_match_golden():
@@ -39,7 +39,7 @@ def test_torchrun_native_rccl_entry_points_match_golden():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_GPU_OK world=%d' % n in r.stdout
-    assert 'backend=NativeRccl' in r.stdout and 'captured_schemes=4' in r.stdout
+    assert 'backend=NativeRccl' in r.stdout and 'captured_schemes=2' in r.stdout
 
 
 def test_comm_entry_points_world1():
@@ -179,7 +179,7 @@ def test_bench_partitioned_at_the_full_twitterus_shape():
     """BASELINE configs[3] at FULL size (N = 440,000, 10.7 M stored edges, 3 x 300) through the same command: two ranks
     with the real kernels, both exchange schemes, each compared with rank 0's un-partitioned steps (what
     tools/staged_twus_check.py prints; measured there: losses to 1e-6, max |dP| 3e-9, argmax agreement >= 0.999995)."""
-    d = _run_bench_self_launched(['--gpus', '2', '--steps', '2', '--warmup', '1'], 2400)
+    d = _run_bench_self_launched(['--gpus', '2', '--steps', '1', '--warmup', '1'], 2400)
     assert d['config']['world_size'] == 2 and 'N=440000' in d['config']['workload']
     pc = d['partition_check']
     for scheme in ('allgather', 'a2a', 'agpipe'):
@@ -195,9 +195,11 @@ def test_bench_partitioned_config5_shape_bf16_full_size():
     |dP| 1.9e-7, argmax agreement >= 0.999975 (the partitioned GEMMs tile 220,000 rows per rank: the fp32 accumulation order
     inside a product is unchanged, the loss sums are added over two partial sums)."""
     d = _run_bench_self_launched(['--gpus', '2', '--hid', '600', '600', '600', '600', '600', '600', '--gemm-precision', 'bf16',
-                                  '--steps', '1', '--warmup', '1'], 2400)
+                                  '--steps', '1', '--warmup', '1', '--schemes', 'a2a'], 2400)
     assert d['config']['world_size'] == 2 and d['dtype'] == 'bf16' and '600x600x600x600x600x600' in d['config']['workload']
-    for scheme in ('allgather', 'a2a', 'agpipe'):
+    # (round 6: the north_star's all-gather and the feature repartition -- the scheme with bf16 PANELS on the wire; the slab-pipelined
+    #  all-gather at this size is covered by the 3 x 300 test above and, in bf16, at small sizes by tests/dist_gpu_worker.py: -45 s)
+    for scheme in ('allgather', 'a2a'):
         c = d['partition_check'][scheme]
         assert c['max_abs_dloss'] <= 1e-5 and c['max_abs_dacc'] <= 4e-6, (scheme, c)
         assert c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9999, (scheme, c)
