@@ -149,6 +149,10 @@ int splitk_reduce_launch(int64_t M, int64_t N, int nsplit, const float* W, int64
 
 // gemm_bf16.hip
 size_t gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+size_t gemm_bf16_tn_dual_workspace_bytes(int64_t M, int64_t N0, int64_t N1, int64_t K);
+int gemm_bf16_tn_dual_dispatch(int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda, const float* B0, int64_t ldb0,
+                               const float* B1, int64_t ldb1, float* C0, int64_t ldc0, float* C1, int64_t ldc1, void* ws, size_t ws_bytes,
+                               hipStream_t st);
 int gemm_bf16_tn_dispatch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                           float* C, int64_t ldc, const float* bias, int act, int accumulate, void* ws, size_t ws_bytes,
                           hipStream_t st);
@@ -160,6 +164,12 @@ int gemm_bf16_dual_dispatch(int64_t M, int64_t N0, int64_t N1, int64_t K, const 
                             int64_t ldb0, const float* B1, int64_t ldb1, void* C0, int64_t ldc0, int c0_bf16, float* C1,
                             int64_t ldc1, const float* bias1, int act1, void* ws, size_t ws_bytes, hipStream_t st);
 struct GateOps { const float* G; int64_t ldg; const float* T; int64_t ldt; };
+// (round 6) C = A0 . op(B0) + A1 . op(B1) [+ C | + G (1 - T)] in one launch of the bf16 whole-rows kernel; 1 = shape not taken
+size_t gemm_bf16_kcat_workspace_bytes(int64_t N, int64_t K0, int64_t K1);
+bool gemm_bf16_kcat_native(int64_t N, int64_t K0, int64_t K1);
+int gemm_bf16_kcat_dispatch(int transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0, const float* B0,
+                            int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C, int64_t ldc,
+                            int accumulate, void* ws, size_t ws_bytes, hipStream_t st, const GateOps* gate);
 int gemm_bf16_dispatch(int precision, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, void* C, int64_t ldc, int c_bf16, const float* bias, int act,
                        int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int panel_w = 0, int64_t panel_R = 0,

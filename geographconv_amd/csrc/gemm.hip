@@ -1272,6 +1272,9 @@ size_t geogcn_gemm_workspace_bytes(int32_t transA, int32_t transB, int64_t M, in
 
 size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, int32_t precision) {
     if (M <= 0 || N0 <= 0 || N1 <= 0 || K <= 0) return 0;
+    if (transA && precision == GEOGCN_GEMM_BF16)          // (round 6) the bf16 configuration's two weight gradients in one launch, or its two launches
+        return std::max(gemm_bf16_tn_dual_workspace_bytes(M, N0, N1, K),
+                        std::max(geogcn_gemm_workspace_bytes(1, 0, M, N0, K, precision), geogcn_gemm_workspace_bytes(1, 0, M, N1, K, precision)));
     if (!transA) {          // the whole-rows kernels' fragment-ordered weights (0: the call runs on the staged kernel)
         GemmCall c{};
         c.M = M; c.n_nseg = 2; c.n_kseg = 1; c.N[0] = N0; c.N[1] = N1; c.K[0] = K; c.precision = precision;
@@ -1284,6 +1287,7 @@ size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, i
 
 size_t geogcn_gemm_kcat_workspace_bytes(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, int32_t precision) {
     if (M <= 0 || N <= 0 || K0 <= 0 || K1 <= 0) return 0;
+    if (precision == GEOGCN_GEMM_BF16) return gemm_bf16_kcat_workspace_bytes(N, K0, K1);      // (also covers the two separate launches of other shapes)
     GemmCall c{};
     c.M = M; c.n_nseg = 1; c.n_kseg = 2; c.N[0] = N; c.K[0] = K0; c.K[1] = K1; c.precision = precision;
     if (const int kc = x3_rows_kc(c, false, transB != 0)) return x3_rows_ws_bytes(c, kc);
@@ -1393,7 +1397,8 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
                          float* C1, int64_t ldc1, const float* bias0, int32_t act0, const float* bias1, int32_t act1,
                          int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "gemm_dual_f32";
-    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3, GEOGCN_E_ARG, "%s: precision must be F32 or BF16X3 (%d)", fn, precision);
+    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3 || (precision == GEOGCN_GEMM_BF16 && transA), GEOGCN_E_ARG,
+                   "%s: precision must be F32 or BF16X3 (or BF16 with transA = 1; the bf16 forward pair is geogcn_gemm_dual_bf16) (%d)", fn, precision);
     GEOGCN_REQUIRE(M >= 0 && N0 >= 0 && N1 >= 0 && K >= 0, GEOGCN_E_SIZE, "%s: negative size", fn);
     if (M == 0 || (N0 == 0 && N1 == 0)) return 0;
     GEOGCN_REQUIRE(N0 > 0 && N1 > 0, GEOGCN_E_SIZE, "%s: both products need columns (N0=%lld N1=%lld)", fn, (long long)N0,
@@ -1415,6 +1420,13 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
         const int rc = zero_rows_async(C0, M, (N0 + 3) & ~(int64_t)3, ldc0, st);
         return rc ? rc : zero_rows_async(C1, M, (N1 + 3) & ~(int64_t)3, ldc1, st);
     }
+    if (precision == GEOGCN_GEMM_BF16) {          // transA: (dW0, dW1) = A^T . [B0 | B1], bf16 products
+        GEOGCN_REQUIRE(!bias0 && !bias1 && act0 == GEOGCN_ACT_NONE && act1 == GEOGCN_ACT_NONE, GEOGCN_E_ARG, "%s: the bf16 A^T . [B0 | B1] has no epilogue", fn);
+        const int rc = gemm_bf16_tn_dual_dispatch(M, N0, N1, K, A, lda, B0, ldb0, B1, ldb1, C0, ldc0, C1, ldc1, ws, ws_bytes, st);
+        if (rc != 1) return rc;
+        if (const int r = geogcn_gemm_f32(1, 0, M, N0, K, A, lda, B0, ldb0, C0, ldc0, nullptr, GEOGCN_ACT_NONE, 0, precision, ws, ws_bytes, stream)) return r;
+        return geogcn_gemm_f32(1, 0, M, N1, K, A, lda, B1, ldb1, C1, ldc1, nullptr, GEOGCN_ACT_NONE, 0, precision, ws, ws_bytes, stream);
+    }
     GemmCall c{};
     c.M = M; c.n_nseg = 2; c.n_kseg = 1;
     c.A[0] = A; c.lda[0] = lda;
@@ -1425,12 +1437,26 @@ int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int6
     return run_call(transA != 0, false, c, ws, ws_bytes, st);
 }
 
+// (round 6) the bf16 configuration's k-concatenated product: one launch of the bf16 whole-rows kernel where it takes the shape, else the
+// two launches the reverse sweep made until now (the first writes -- with the carry --, the second accumulates)
+static int kcat_bf16(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0, const float* B0, int64_t ldb0,
+                     const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C, int64_t ldc, int accumulate, const GateOps* gate,
+                     void* ws, size_t ws_bytes, hipStream_t st) {
+    const int rc = gemm_bf16_kcat_dispatch(transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, accumulate, ws, ws_bytes, st, gate);
+    if (rc != 1) return rc;
+    if (const int r = gemm_bf16_dispatch(GEOGCN_GEMM_BF16, transB, M, N, K0, A0, lda0, B0, ldb0, C, ldc, 0, nullptr, GEOGCN_ACT_NONE, accumulate,
+                                         ws, ws_bytes, st, 0, 0, gate))
+        return r;
+    return gemm_bf16_dispatch(GEOGCN_GEMM_BF16, transB, M, N, K1, A1, lda1, B1, ldb1, C, ldc, 0, nullptr, GEOGCN_ACT_NONE, 1, ws, ws_bytes, st, 0, 0,
+                              nullptr);
+}
+
 // C = A0.op(B0) + A1.op(B1) [+ C]: one accumulator over both reductions, exact fp32
 int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0,
                          const float* B0, int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1,
                          float* C, int64_t ldc, int32_t accumulate, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "gemm_kcat_f32";
-    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3, GEOGCN_E_ARG, "%s: precision must be F32 or BF16X3 (%d)", fn, precision);
+    GEOGCN_REQUIRE(precision >= GEOGCN_GEMM_F32 && precision <= GEOGCN_GEMM_BF16, GEOGCN_E_ARG, "%s: unknown precision %d", fn, precision);
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C, GEOGCN_E_NULL, "%s: null pointer", fn);
@@ -1439,6 +1465,8 @@ int geogcn_gemm_kcat_f32(int32_t transB, int64_t M, int64_t N, int64_t K0, int64
                    "%s: leading dimension too small", fn);
     GEOGCN_REQUIRE(ld_ok(A0, lda0) && ld_ok(A1, lda1) && ld_ok(B0, ldb0) && ld_ok(B1, ldb1) && ld_ok(C, ldc), GEOGCN_E_ALIGN,
                    "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
+    if (precision == GEOGCN_GEMM_BF16)
+        return kcat_bf16(transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, accumulate, nullptr, ws, ws_bytes, (hipStream_t)stream);
     GemmCall c{};
     c.M = M; c.n_nseg = 1; c.n_kseg = 2;
     c.A[0] = A0; c.lda[0] = lda0; c.A[1] = A1; c.lda[1] = lda1;
@@ -1549,7 +1577,7 @@ static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N,
                            float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt, const float* Y, int64_t ldy,
                            const uint8_t* keep, int64_t keepF, float scale, int32_t precision, void* ws, size_t ws_bytes, void* stream) {
     GEOGCN_REQUIRE(M >= 0 && N >= 0 && K0 > 0 && K1 > 0, GEOGCN_E_SIZE, "%s: bad sizes", fn);
-    GEOGCN_REQUIRE(precision == GEOGCN_GEMM_F32 || precision == GEOGCN_GEMM_BF16X3, GEOGCN_E_ARG, "%s: precision must be F32 or BF16X3 (%d)", fn, precision);
+    GEOGCN_REQUIRE(precision >= GEOGCN_GEMM_F32 && precision <= GEOGCN_GEMM_BF16, GEOGCN_E_ARG, "%s: unknown precision %d", fn, precision);
     if (M == 0 || N == 0) return 0;
     GEOGCN_REQUIRE(A0 && A1 && B0 && B1 && C && G && T, GEOGCN_E_NULL, "%s: null pointer", fn);
     const int64_t b0_cols = transB ? K0 : N, b1_cols = transB ? K1 : N, n4 = (N + 3) & ~(int64_t)3;
@@ -1559,6 +1587,18 @@ static int kcat_gated_impl(const char* fn, int32_t transB, int64_t M, int64_t N,
                        ld_ok(T, ldt),
                    GEOGCN_E_ALIGN, "%s: operands need 16-byte aligned bases and ld %% 4 == 0", fn);
     GEOGCN_REQUIRE(C != G && C != T, GEOGCN_E_ARG, "%s: C must not alias G or T", fn);
+    if (precision == GEOGCN_GEMM_BF16) {
+        const GateOps gate{G, ldg, T, ldt};
+        if (const int rc = kcat_bf16(transB, M, N, K0, K1, A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, C, ldc, 0, &gate, ws, ws_bytes, (hipStream_t)stream))
+            return rc;
+        if (Y) {
+            const int F4 = (int)((N + 3) / 4);
+            const int64_t blocks = std::min<int64_t>(cdiv(M * F4, TPB), (int64_t)kNumCU * 16);
+            hipLaunchKernelGGL(tanh_bwd_post_kernel, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, M, (int)N, F4, C, ldc, Y, ldy, keep, keepF, scale);
+            GEOGCN_LAUNCH_CHECK("tanh_bwd_post_kernel");
+        }
+        return 0;
+    }
     GemmCall c{};
     c.M = M; c.n_nseg = 1; c.n_kseg = 2;
     c.A[0] = A0; c.lda[0] = lda0; c.A[1] = A1; c.lda[1] = lda1;

@@ -91,6 +91,9 @@ struct Bf16Args {
     int passes0 = 0, passes1 = 0;
     const unsigned short* Bp1 = nullptr; void* C1 = nullptr; int64_t ldc1 = 0; const float* bias1 = nullptr; int64_t N1 = 0;
     int c_bf16_1 = 0; int64_t n_store1 = 0;
+    // whole-rows kernel, KCAT instances only (round 6): a SECOND reduction segment -- C = A . op(B) + A1 . op(B1), one accumulator
+    // (dH = dZ . Wh^T + dU . Wt^T of the highway block): A1's tile sits behind A's in the LDS rows, B1's fragments behind B's in k
+    const float* A1 = nullptr; int64_t lda1 = 0; int64_t K1 = 0;
 };
 
 template <int BM, int BN, int NS, int NT>
@@ -405,7 +408,8 @@ int launch_bf16(const Bf16Args& a, int act, hipStream_t st) {
 // arithmetic as gemm_bf16_kernel: the results are bit-identical.
 template <int NS_>
 __global__ __launch_bounds__(TPB) void prep_b_frag_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int NKs, int n_tiles,
-                                                          int b_is_nk, unsigned short* __restrict__ out) {
+                                                          int b_is_nk, unsigned short* __restrict__ out, int kstep_base = 0, int nk_total = 0) {
+    if (nk_total == 0) nk_total = NKs;          // (a k-concatenated launch: this weight's k-steps start at kstep_base of nk_total per column tile)
     const int64_t total = (int64_t)n_tiles * NKs * 512;
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
         const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
@@ -414,26 +418,27 @@ __global__ __launch_bounds__(TPB) void prep_b_frag_kernel(const float* __restric
         const int n = nt * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8 + el;
         float x = 0.f;
         if (k < K && n < N) x = b_is_nk ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n];
-        out[e] = (unsigned short)bf16_rne(x);
+        out[(((int64_t)nt * nk_total + kstep_base + kt) << 9) + (e & 511)] = (unsigned short)bf16_rne(x);
     }
 }
 
 constexpr int kRowsBM = 64, kRowsWCT = 5, kRowsDepth = 2;
 
-template <int KP, int ACT, bool GATE = false>
-__global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a, const int passes) {
+// KCAT: KP counts BOTH reduction segments (2 x 608 / 320 / 256): the LDS rows hold [A row | A1 row] as bf16 (157 KB at 2 x 608: one
+// block per CU), the k loop walks the weights' fragments of both segments into the same accumulators.
+template <int KP, int ACT, bool GATE = false, bool KCAT = false>
+__global__ __launch_bounds__(TPB, (KP * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) void gemm_bf16_rows_kernel(const Bf16Args a, const int passes) {
     constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
     constexpr int PITCH = KP * 2 + 16;          // bytes per LDS row: an odd multiple of 16 -> conflict-free ds_read_b128
-    constexpr int F4R = KP / 4;                 // float4 per row
+    constexpr int NSEG = KCAT ? 2 : 1, KPS = KP / NSEG;      // reduction segments; padded depth of one
+    constexpr int F4R = KPS / 4;                // float4 per row and segment
     constexpr int ITERS = BM * F4R / TPB;
     constexpr int CH = 2, IPC = ITERS / CH;     // two batches of loads: half the staging registers
     constexpr int MR = BM / 16, NK = KP / 32;
-    static_assert(BM * F4R % (TPB * CH) == 0, "a tile must divide over the block in two batches");
+    static_assert(BM * F4R % (TPB * CH) == 0 && (PITCH / 16) % 2 == 1, "a tile must divide over the block in two batches");
     extern __shared__ __attribute__((aligned(16))) unsigned char As[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int K4 = (int)((a.K + 3) & ~(int64_t)3);            // pad columns of A up to roundup4(K) are zero (geogcn.h); beyond: not read
-    const uint32_t ld4 = (uint32_t)a.lda * 4u;
     const int P = a.n_nseg == 2 ? a.passes0 + a.passes1 : passes;
     for (int mt = blockIdx.x; mt < a.n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
@@ -444,26 +449,34 @@ __global__ __launch_bounds__(TPB, 2) void gemm_bf16_rows_kernel(const Bf16Args a
             asm volatile("" : "+v"(tt));
             // one descriptor per tile: rows past M read as zeros in hardware
             const int64_t rows = std::min<int64_t>(BM, a.M - m0);
-            const __amdgpu_buffer_rsrc_t rs = tn_rsrc(a.A + m0 * a.lda, rows * a.lda * 4);
 #pragma unroll
-            for (int ch = 0; ch < CH; ++ch) {
-                float4 v[IPC];
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const float* Ap = (KCAT && sg) ? a.A1 : a.A;
+                const int64_t lda = (KCAT && sg) ? a.lda1 : a.lda;
+                // pad columns of A up to roundup4(K) are zero (geogcn.h); beyond: not read
+                const int K4 = (int)((((KCAT && sg) ? a.K1 : a.K) + 3) & ~(int64_t)3);
+                const uint32_t ld4 = (uint32_t)lda * 4u;
+                const __amdgpu_buffer_rsrc_t rs = tn_rsrc(Ap + m0 * lda, rows * lda * 4);
 #pragma unroll
-                for (int i = 0; i < IPC; ++i) {
-                    const int idx = tt + TPB * (ch * IPC + i);
-                    const int r = idx / F4R, c = idx - r * F4R;
-                    v[i] = tn_load4(rs, c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : kOob);
+                for (int ch = 0; ch < CH; ++ch) {
+                    float4 v[IPC];
+#pragma unroll
+                    for (int i = 0; i < IPC; ++i) {
+                        const int idx = tt + TPB * (ch * IPC + i);
+                        const int r = idx / F4R, c = idx - r * F4R;
+                        v[i] = tn_load4(rs, c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : kOob);
+                    }
+#pragma unroll
+                    for (int i = 0; i < IPC; ++i) {
+                        const int idx = tt + TPB * (ch * IPC + i);
+                        const int r = idx / F4R, c = idx - r * F4R;
+                        uint2 w;
+                        w.x = bf16_pack(v[i].x, v[i].y);
+                        w.y = bf16_pack(v[i].z, v[i].w);
+                        *reinterpret_cast<uint2*>(As + r * PITCH + sg * (KPS * 2) + c * 8) = w;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int i = 0; i < IPC; ++i) {
-                    const int idx = tt + TPB * (ch * IPC + i);
-                    const int r = idx / F4R, c = idx - r * F4R;
-                    uint2 w;
-                    w.x = bf16_pack(v[i].x, v[i].y);
-                    w.y = bf16_pack(v[i].z, v[i].w);
-                    *reinterpret_cast<uint2*>(As + r * PITCH + c * 8) = w;
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -597,6 +610,27 @@ inline int rows_kp(int64_t N, int64_t K, int panel_w, int ns) {
 }
 inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
 
+// k-concatenated launch (no activation; plain / accumulating / with the gate carry)
+template <int KP>
+int launch_rows_kcat(const Bf16Args& a, hipStream_t st) {
+    constexpr int lds = kRowsBM * (KP * 2 + 16);
+    const int passes = rows_passes(a.N);
+    const int G = (int)std::min<int64_t>((int64_t)kNumCU * 2, a.n_mt);
+    if (a.gateG) {
+        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, true, true>;
+        static LdsAttrOnce lds_once;
+        if (const int rc_ = lds_once.ensure((const void*)kern, lds)) return rc_;
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);
+    } else {
+        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, false, true>;
+        static LdsAttrOnce lds_once;
+        if (const int rc_ = lds_once.ensure((const void*)kern, lds)) return rc_;
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);
+    }
+    GEOGCN_LAUNCH_CHECK("gemm_bf16_rows_kernel (k-concatenated)");
+    return 0;
+}
+
 template <int KP>
 int launch_rows(const Bf16Args& a, int act, hipStream_t st) {
     constexpr int lds = kRowsBM * (KP * 2 + 16);
@@ -637,6 +671,9 @@ struct TnArgs {
     float* W; int64_t ldw;              // slabs [nsplit][M][ldw]
     int64_t kchunk;
     int n_mt, n_nt, nsplit;
+    // (round 6) a SECOND column segment of the same launch -- (dWh, dWt) = H^T . [dZ | dU]: H is read once for both.  Column tiles
+    // [0, nt_per_seg) belong to B / N, the rest to B1 / N1; segment q's columns start at q * seg_w of a slab row
+    int nt_per_seg = 0; const float* B1 = nullptr; int64_t ldb1 = 0; int64_t N1 = 0; int64_t seg_w = 0;
 };
 
 // PF = stages of global loads in flight per thread (register ring).  One block per CU and 20 MFMAs of 16 cycles per wave and
@@ -662,10 +699,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
     const int xcd = b % kNumXCD, s = b / kNumXCD;
     const int tiles = a.n_nt * a.n_mt;
     const int tile = s % tiles;
-    const int nt = __builtin_amdgcn_readfirstlane(tile % a.n_nt);
+    const int ntile = __builtin_amdgcn_readfirstlane(tile % a.n_nt);
     const int mt = __builtin_amdgcn_readfirstlane(tile / a.n_nt);
     const int z = __builtin_amdgcn_readfirstlane(xcd + kNumXCD * (s / tiles));
     if (z >= a.nsplit) return;
+    const int seg = (a.nt_per_seg && ntile >= a.nt_per_seg) ? 1 : 0;          // block-uniform
+    const int nt = seg ? ntile - a.nt_per_seg : ntile;
+    const int64_t Nseg = seg ? a.N1 : a.N;
     const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
     const int64_t kbeg = (int64_t)z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const int nk = (int)((kend - kbeg + BKH - 1) / BKH);
@@ -676,10 +716,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
     const int cols4 = isA ? BM / 4 : BN / 4;
     const bool active = it < 4 * cols4;
     const int k8 = it / cols4, c4 = it % cols4;
-    const float* P = isA ? a.A : a.B;
-    const int64_t ld = isA ? a.lda : a.ldb;
+    const float* P = isA ? a.A : (seg ? a.B1 : a.B);
+    const int64_t ld = isA ? a.lda : (seg ? a.ldb1 : a.ldb);
     const int64_t c0 = isA ? m0 : n0;
-    const int64_t ctot = isA ? a.M : a.N;
+    const int64_t ctot = isA ? a.M : Nseg;
     const bool col_ok = active && (c4 * 4 < ((ctot + 3) & ~(int64_t)3) - c0);
     // (the two operands use different descriptors: built per lane group, uniform within a wave except wave 2/3
     //  boundary at thread 192 = wave 3 start, so every wave is uniform)
@@ -753,8 +793,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
       }
     }
     // slab z: lane (li, lg) holds C[row = li][col = 4*lg + r] of each 16x16 sub-tile
-    float* Wz = a.W + (int64_t)z * a.M * a.ldw;
-    const int64_t n_store = (a.N + 3) & ~(int64_t)3;
+    float* Wz = a.W + (int64_t)z * a.M * a.ldw + (seg ? a.seg_w : 0);
+    const int64_t n_store = (Nseg + 3) & ~(int64_t)3;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         const int64_t row = m0 + wm * (BM / 2) + i * 16 + li;
@@ -763,7 +803,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_kernel(const TnArgs a) {
             const int64_t col0 = n0 + wn * (BN / 4) + j * 16 + lg * 4;
             float x[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = (col0 + q < a.N) ? acc[i][j][q] : 0.f;
+            for (int q = 0; q < 4; ++q) x[q] = (col0 + q < Nseg) ? acc[i][j][q] : 0.f;
             if (row < a.M && col0 < n_store)
                 *reinterpret_cast<float4*>(Wz + row * a.ldw + col0) = make_float4(x[0], x[1], x[2], x[3]);
         }
@@ -774,13 +814,13 @@ struct TnPlan {
     int bm, bn, n_mt, n_nt, nsplit;
     int64_t kchunk;
 };
-inline bool tn_plan(int64_t M, int64_t N, int64_t K, TnPlan& p) {
+inline bool tn_plan(int64_t M, int64_t N, int64_t K, TnPlan& p, int n_nseg = 1) {          // (N: the wider segment)
     if (N <= 160) return false;                                   // narrow outputs stay on the fp32 kernel
     p.bm = (cdiv(M, 160) * 160 < cdiv(M, 128) * 128) ? 160 : 128;
     const int64_t w320 = cdiv(N, 320) * 320, w256 = cdiv(N, 256) * 256;
     p.bn = (w256 <= w320) ? 256 : 320;
     p.n_mt = (int)cdiv(M, p.bm);
-    p.n_nt = (int)cdiv(N, p.bn);
+    p.n_nt = (int)cdiv(N, p.bn) * n_nseg;
     const int64_t tiles = (int64_t)p.n_mt * p.n_nt;
     int64_t ns = std::max<int64_t>(1, kNumCU / tiles);
     if (ns >= kNumXCD) ns = ns / kNumXCD * kNumXCD;              // whole XCD rounds (the kernel groups a slab's tiles per XCD)
@@ -842,6 +882,41 @@ int gemm_bf16_dual_dispatch(int64_t M, int64_t N0, int64_t N1, int64_t K, const 
     if (kp == 608) return launch_rows<608>(a, act1, st);
     if (kp == 320) return launch_rows<320>(a, act1, st);
     return launch_rows<256>(a, act1, st);
+}
+
+// ---- (round 6) dH = dZ . Wh^T + dU . Wt^T of the highway block in ONE launch in the bf16 configuration: both products into one
+// accumulator, one pass over dH (until now: the first product written -- with the carry -- and the second accumulated onto it: dH written,
+// read and written again, 2.1 GB per 600-wide block at the TwitterUS size).  Shapes: both K pad to the same 608 / 320 / 256, N <= 640.
+static int kcat_kp(int64_t N, int64_t K0, int64_t K1) {
+    const int k0 = rows_kp(N, K0, 0, 1), k1 = rows_kp(N, K1, 0, 1);
+    return (k0 && k0 == k1) ? k0 : 0;
+}
+size_t gemm_bf16_kcat_workspace_bytes(int64_t N, int64_t K0, int64_t K1) {
+    const size_t separate = std::max(gemm_bf16_workspace_bytes(GEOGCN_GEMM_BF16, N, K0), gemm_bf16_workspace_bytes(GEOGCN_GEMM_BF16, N, K1));
+    const int kp = kcat_kp(N, K0, K1);
+    return kp ? std::max(separate, 2 * dual_slot_bytes(N, kp)) : separate;
+}
+bool gemm_bf16_kcat_native(int64_t N, int64_t K0, int64_t K1) { return kcat_kp(N, K0, K1) != 0; }
+// returns 1 when the shape is not one the k-concatenated kernel takes (the caller then runs two launches)
+int gemm_bf16_kcat_dispatch(int transB, int64_t M, int64_t N, int64_t K0, int64_t K1, const float* A0, int64_t lda0, const float* B0,
+                            int64_t ldb0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C, int64_t ldc,
+                            int accumulate, void* ws, size_t ws_bytes, hipStream_t st, const GateOps* gate) {
+    const int kp = kcat_kp(N, K0, K1);
+    if (!kp || lda0 % 4 != 0 || lda1 % 4 != 0) return 1;
+    const size_t need = 2 * dual_slot_bytes(N, kp);
+    GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "gemm_kcat(bf16): workspace too small (%zu < %zu)", ws_bytes, need);
+    const int nks = kp / BKH, n_tiles = 4 * rows_passes(N) * kRowsWCT;
+    unsigned short* planes = (unsigned short*)ws;
+    const unsigned fgrid = (unsigned)std::min<int64_t>(cdiv((int64_t)n_tiles * nks * 512, TPB), 1024);
+    hipLaunchKernelGGL((prep_b_frag_kernel<1>), dim3(fgrid), dim3(TPB), 0, st, B0, ldb0, (int)K0, (int)N, nks, n_tiles, transB, planes, 0, 2 * nks);
+    hipLaunchKernelGGL((prep_b_frag_kernel<1>), dim3(fgrid), dim3(TPB), 0, st, B1, ldb1, (int)K1, (int)N, nks, n_tiles, transB, planes, nks, 2 * nks);
+    GEOGCN_LAUNCH_CHECK("prep_b_frag_kernel");
+    Bf16Args a{M, N, K0, A0, lda0, planes, 2 * kp, C, ldc, nullptr, accumulate, (int)cdiv(M, kRowsBM), 1, 0, (N + 3) & ~(int64_t)3, 0, 0};
+    a.A1 = A1; a.lda1 = lda1; a.K1 = K1;
+    if (gate) { a.gateG = gate->G; a.ldg = gate->ldg; a.gateT = gate->T; a.ldt = gate->ldt; }
+    if (kp == 608) return launch_rows_kcat<1216>(a, st);
+    if (kp == 320) return launch_rows_kcat<640>(a, st);
+    return launch_rows_kcat<512>(a, st);
 }
 
 // called by geogcn_gemm_f32 for transA == 0 and precision != F32
@@ -918,6 +993,43 @@ size_t gemm_bf16_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     TnPlan p;
     if (!tn_plan(M, N, K, p)) return 0;
     return (size_t)p.nsplit * (size_t)M * (size_t)((N + 3) & ~(int64_t)3) * sizeof(float);
+}
+
+// (round 6) (dW0, dW1) = A^T . [B0 | B1] in one launch (the highway block's two weight gradients: H read once); returns 1 if not handled
+size_t gemm_bf16_tn_dual_workspace_bytes(int64_t M, int64_t N0, int64_t N1, int64_t K) {
+    TnPlan p;
+    const size_t separate = std::max(gemm_bf16_tn_workspace_bytes(M, N0, K), gemm_bf16_tn_workspace_bytes(M, N1, K));
+    if (!tn_plan(M, std::max(N0, N1), K, p, 2) || std::min(N0, N1) <= 160) return separate;
+    const int64_t seg_w = (std::max(N0, N1) + 3) & ~(int64_t)3;
+    return std::max(separate, (size_t)p.nsplit * (size_t)M * (size_t)(2 * seg_w) * sizeof(float));
+}
+int gemm_bf16_tn_dual_dispatch(int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda, const float* B0, int64_t ldb0,
+                               const float* B1, int64_t ldb1, float* C0, int64_t ldc0, float* C1, int64_t ldc1, void* ws, size_t ws_bytes,
+                               hipStream_t st) {
+    TnPlan p;
+    if (!tn_plan(M, std::max(N0, N1), K, p, 2) || std::min(N0, N1) <= 160) return 1;
+    const int64_t seg_w = (std::max(N0, N1) + 3) & ~(int64_t)3, ldw = 2 * seg_w;
+    const size_t need = (size_t)p.nsplit * (size_t)M * (size_t)ldw * sizeof(float);
+    GEOGCN_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GEOGCN_E_ARG, "gemm_dual(bf16, transA): workspace too small (%zu < %zu)", ws_bytes, need);
+    TnArgs a{M, N0, K, A, lda, B0, ldb0, (float*)ws, ldw, p.kchunk, p.n_mt, p.n_nt, p.nsplit};
+    a.nt_per_seg = p.n_nt / 2; a.B1 = B1; a.ldb1 = ldb1; a.N1 = N1; a.seg_w = seg_w;
+    const dim3 grid((unsigned)((int64_t)p.n_mt * p.n_nt * cdiv(p.nsplit, kNumXCD) * kNumXCD));
+#define GEOGCN_TN(BM_, BN_)                                                                                     \
+    do {                                                                                                        \
+        auto kern = gemm_bf16_tn_kernel<BM_, BN_>;                                                              \
+        constexpr int lds = 2 * (BM_ + BN_) * ROWB;                                                             \
+        static LdsAttrOnce lds_once;                                                                            \
+        if (const int rc_ = lds_once.ensure((const void*)kern, (int)(lds))) return rc_;                         \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                  \
+        GEOGCN_LAUNCH_CHECK("gemm_bf16_tn_kernel");                                                             \
+    } while (0)
+    if (p.bm == 160 && p.bn == 320) GEOGCN_TN(160, 320);
+    else if (p.bm == 160) GEOGCN_TN(160, 256);
+    else if (p.bn == 320) GEOGCN_TN(128, 320);
+    else GEOGCN_TN(128, 256);
+#undef GEOGCN_TN
+    if (const int rc = splitk_reduce_launch(M, N0, p.nsplit, (const float*)ws, ldw, C0, ldc0, nullptr, GEOGCN_ACT_NONE, 0, st)) return rc;
+    return splitk_reduce_launch(M, N1, p.nsplit, (const float*)ws + seg_w, ldw, C1, ldc1, nullptr, GEOGCN_ACT_NONE, 0, st);
 }
 
 // dW = A^T . B (A: K x M, B: K x N, fp32 in memory) with bf16 products; returns 1 if this shape is not handled

@@ -297,7 +297,11 @@ class DenseLayer(Layer):
                 # the same pair in the bf16 configuration: Z leaves the accumulators as bf16 (the SpMM's operand), T as fp32
                 conv = self._fusable_sibling(input, tape, kwargs, bf16=True)
                 zf, y = K.gemm_dual_bf16(input, conv.W.data, self.W.data, bias1=bias, act1=act)
-                tape[('fused_z', conv)] = (input, zf)            # (no 'fused_with': the reverse sweep keeps its bf16 launches)
+                tape[('fused_z', conv)] = (input, zf)
+                # (round 6) the reverse sweep forms dH = dZ . Wh^T + dU . Wt^T in one launch where the bf16 whole-rows kernel takes both
+                # reductions (tuning.FUSE_BF16_KCAT); the two weight gradients stay separate launches
+                if K.kcat_gated_native(input.n, self.W.shape[0], 'bf16'):
+                    saved['fused_with'] = conv
             elif isinstance(input, K.DMat):
                 y = K.gemm(input, self.W.data, bias=bias, act=act, precision=prec)   # bias + act fused
             else:
@@ -388,8 +392,8 @@ class DenseLayer(Layer):
         gradient can then leave the product's epilogue as that layer's pre-activation gradient."""
         K = backend.active()
         d = self.input_layer
-        if not tuning.FUSE_ACT_BWD or not isinstance(d, DropoutLayer) or tape is None:
-            return None
+        if not tuning.FUSE_ACT_BWD or not isinstance(d, DropoutLayer) or tape is None or K.bf16_gather(kwargs.get('gemm_precision')):
+            return None          # (the bf16 whole-rows kernel has the carry epilogue only: that configuration keeps its act_bwd pass)
         below = d.input_layer
         keep = tape.get(d, {}).get('mask')
         if (keep is None or not isinstance(below, DenseLayer) or below.nonlinearity is not _nl.tanh or below.b is None
@@ -538,7 +542,11 @@ class DenseLayer(Layer):
             fused = tape.pop(('fused_dz', self), None) if tape is not None else None
             if fused is not None:
                 conv = tape[self]['fused_with']
-                K.gemm_dual(x, fused, dZ, out0=conv.W.grad, out1=self.W.grad, transA=True, precision=prec)     # dWh, dWt = H^T.[dZ | dU]
+                if K.bf16_gather(prec) and not tuning.FUSE_BF16_DUAL_TN:          # (bf16 configuration: two launches are faster, tuning.py)
+                    K.gemm(x, fused, out=conv.W.grad, transA=True, precision=prec)
+                    K.gemm(x, dZ, out=self.W.grad, transA=True, precision=prec)
+                else:
+                    K.gemm_dual(x, fused, dZ, out0=conv.W.grad, out1=self.W.grad, transA=True, precision=prec)     # dWh, dWt = H^T.[dZ | dU]
                 tape[self]['bwd_done'] = True
                 if not need_input_grad:
                     return [None]

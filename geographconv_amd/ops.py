@@ -458,11 +458,12 @@ def gemm(A: DMat, B: DMat, out: DMat = None, transA=False, transB=False, bias=No
     return out
 
 
-def _fused_precision(precision):
-    """The fused highway launches exist in two precisions: 'f32' and 'bf16x3' (the bf16 configuration keeps its own launches)."""
+def _fused_precision(precision, allow_bf16=False):
+    """The fused highway launches exist in two precisions: 'f32' and 'bf16x3'; the k-concatenated product (gemm_kcat) also in 'bf16'
+    (round 6: one launch of the bf16 whole-rows kernel; the bf16 configuration keeps its own launches for the other pairs)."""
     p = precision or GEMM_PRECISION
-    if p not in ('f32', 'bf16x3'):
-        raise ValueError("fused highway GEMM launches take precision 'f32' or 'bf16x3', not %r" % (p,))
+    if p not in ('f32', 'bf16x3') and not (allow_bf16 and p == 'bf16'):
+        raise ValueError("fused highway GEMM launches take precision 'f32' or 'bf16x3'%s, not %r" % (" or 'bf16'" if allow_bf16 else '', p))
     return GEMM_PRECISIONS[p]
 
 
@@ -483,7 +484,7 @@ def gemm_dual(A: DMat, B0: DMat, B1: DMat, out0: DMat = None, out1: DMat = None,
     ws = _gemm_ws.get(dev)
     if ws is None:
         ws = _gemm_ws[dev] = Workspace(dev)
-    prec = _fused_precision(precision)
+    prec = _fused_precision(precision, allow_bf16=bool(transA))          # (bf16: the two weight gradients; its forward pair is gemm_dual_bf16)
     w = ws.get(lib.geogcn_gemm_dual_workspace_bytes(int(transA), M, B0.F, B1.F, K, prec))
     check(lib.geogcn_gemm_dual_f32(int(transA), M, B0.F, B1.F, K, _p(A.t), A.ld, _p(B0.t), B0.ld, _p(B1.t), B1.ld,
                                    _p(out0.t), out0.ld, _p(out1.t), out1.ld, _p(bias0), int(act0), _p(bias1), int(act1),
@@ -520,7 +521,12 @@ def gemm_gated_native(n, F, precision=None):
 
 def kcat_gated_native(n, F, precision=None):
     """Does dH = dZ . Wh^T + dU . Wt^T + G * (1 - T) run with the carry in the epilogue at this size (a whole-rows kernel)?"""
-    return _ffi.lib().geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F), _fused_precision(precision)) > 0
+    lib = _ffi.lib()
+    if (precision or GEMM_PRECISION) == 'bf16':
+        # the k-concatenated bf16 launch holds the fragments of BOTH weights: a larger workspace than a single product's says it is taken
+        return (tuning.FUSE_BF16_KCAT and lib.geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F), _ffi.GEMM_BF16)
+                > lib.geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_BF16))
+    return lib.geogcn_gemm_kcat_workspace_bytes(1, int(n), int(F), int(F), int(F), _fused_precision(precision)) > 0
 
 
 @_timed('gemm_dual_bf16')
@@ -545,7 +551,7 @@ def gemm_dual_bf16(A: DMat, B0: DMat, B1: DMat, out0=None, out1: DMat = None, bi
 @_timed('gemm_kcat')
 def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=False, accumulate=False, gate_carry: GateCarry = None,
               tanh_bwd=None, precision=None):
-    """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (`precision` 'f32' or 'bf16x3') --
+    """out = A0 . op(B0) + A1 . op(B1) [+ out]: two products, one accumulator, one pass over out (`precision` 'f32', 'bf16x3' or 'bf16') --
     dH = dZ . Wh^T + dU . Wt^T of the highway block.  `gate_carry`: ... + G * (1 - T) formed in the epilogue (then no accumulate).
     `tanh_bwd` = (Y, keep_mask, scale), with a gate carry only: the result times keep * scale * (1 - Y^2) -- the dropout + tanh gradient
     of the layer below the first block in the same epilogue (geogcn_gemm_kcat_gated_tanhbwd_f32)."""
@@ -564,7 +570,7 @@ def gemm_kcat(A0: DMat, B0: DMat, A1: DMat, B1: DMat, out: DMat = None, transB=F
     ws = _gemm_ws.get(A0.device)
     if ws is None:
         ws = _gemm_ws[A0.device] = Workspace(A0.device)
-    prec = _fused_precision(precision)
+    prec = _fused_precision(precision, allow_bf16=True)
     w = ws.get(lib.geogcn_gemm_kcat_workspace_bytes(int(transB), A0.n, N, A0.F, A1.F, prec))
     if gate_carry is not None:
         g, t = gate_carry.G, gate_carry.T

@@ -64,6 +64,17 @@ FUSE_SOFTMAX = True
 # the bf16 whole-rows kernel -- H read and rounded once (geogcn_gemm_dual_bf16); same bits as the two launches
 FUSE_BF16_DUAL = True
 
+# bf16 configuration, one GPU (round 6): the highway block's dH = dZ . Wh^T + dU . Wt^T (+ the carry) in ONE launch of the bf16 whole-rows
+# kernel (both reduction segments in LDS, one accumulator) instead of a writing and an accumulating launch: dH written once instead of
+# written, read and written (-2.1 GB per 600-wide block at the TwitterUS size).  The sum is associated differently from the two launches
+# (one fp32 accumulator over both reductions): equal to rounding, not bit for bit
+FUSE_BF16_KCAT = True
+# ... and its two weight gradients (dWh, dWt) = H^T . [dZ | dU] in one launch of the bf16 A^T . B kernel (H read once; geogcn_gemm_dual_f32
+# with transA = 1 and GEOGCN_GEMM_BF16).  Built, tested -- and OFF: same box, two alternations, configs[4] on one GPU 68.07 / 67.90 ms with
+# it against 67.31 / 66.34 without the reverse sweep's fusions, where the one-launch dH alone measured 65.61 against 66.74: the 16 tiles
+# of a slab (4 x 2 x 2 of 160 x 320) on one XCD run slower than two launches of 8
+FUSE_BF16_DUAL_TN = False
+
 # bf16 configuration, one GPU: highway_bwd stores the branch gradient dS as bf16 (what A^T . dS gathers) instead of fp32 + a cast
 # pass (-0.37 ms per 600-wide block; same bits)
 FUSE_BF16_DS = True

@@ -204,9 +204,9 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  *                      per product: fp32-class accuracy (dropped terms O(2^-24 |a||b|); measured against fp64
  *                      1.0-1.4e-7 sum|a.b| at K = 300, the exact kernel 1.4-1.5e-7), 2.7x fewer MFMA cycles.  It is a
  *                      PERMISSION, not a promise: shapes no split-bf16 kernel takes run exact fp32 (csrc/gemm_x3.hip: whole
- *                      rows of A for M >= 32,768, K <= 640, N <= 640; transA = 1 for 128 / 160 x 256 / 320 tiles; the
- *                      staged split-bf16 kernel of csrc/gemm_bf16.hip only where the output is feature panels,
- *                      geogcn_gemm_panels_f32).  Non-finite operands: an Inf or NaN in A or B gives NaN in every output
+ *                      rows of A for M >= 32,768, K <= 1,024, N <= 1,024; transA = 1 in 128 / 160 x 256 / 320 tiles, several per
+ *                      row of C beyond 320 columns; feature-panel outputs, geogcn_gemm_panels_f32, on the same whole-rows kernel
+ *                      from 32,768 rows and on the staged split-bf16 kernel of csrc/gemm_bf16.hip below).  Non-finite operands: an Inf or NaN in A or B gives NaN in every output
  *                      it reaches (the split's residual Inf - Inf), where the exact kernels would give Inf for an Inf times a
  *                      non-zero; so does a finite |x| >= 0x1.ffp+127 (3.396e38: it rounds to the bf16 infinity).  Every other fp32
  *                      value, subnormals included, splits exactly;

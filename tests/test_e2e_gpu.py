@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 # default WITH the split-bf16 kernels forced onto these sizes, 'f32' = exact) -- except those that name their precision themselves
 # (they would run the same bits twice):
 PINNED_PRECISION = {'test_config5_bf16_six_layer_600_hidden', 'test_bf16_configuration_forward_pair_in_one_launch',
+                    'test_bf16_configuration_input_gradient_in_one_launch',
                     'test_bf16_configuration_branch_gradient_stored_as_bf16', 'test_training_step_is_bitwise_reproducible',
                     'test_world_configuration_widths'}
 
@@ -575,6 +576,8 @@ def test_carry_gradient_in_the_epilogue_of_the_first_of_two_products(cmu, monkey
     from geographconv_amd.nn import layers as L
     c = cmu
     kw = {'gemm_precision': 'bf16'} if config == 'bf16' else {}
+    if config == 'bf16':
+        monkeypatch.setattr(tuning, 'FUSE_BF16_KCAT', False)          # (this test is about the TWO launches; the one launch: next test)
     if config != 'bf16':
         monkeypatch.setattr(tuning, 'FUSE_GEMMS', False)
         monkeypatch.setattr(ops, 'gemm_gated_native', lambda n, F, precision=None: True)      # (9,475 rows: carry + accumulate inside the call)
@@ -593,6 +596,47 @@ def test_carry_gradient_in_the_epilogue_of_the_first_of_two_products(cmu, monkey
         assert (len(made) > 0, len(formed)) == ((True, 0) if fused else (False, 0)), (fused, len(made), len(formed))
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
     assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
+def test_bf16_configuration_input_gradient_in_one_launch(cmu, monkeypatch):
+    """tuning.FUSE_BF16_KCAT (round 6): in the bf16 configuration the highway block's dH = dZ . Wh^T + dU . Wt^T + G (1 - T) is ONE launch of
+    the bf16 whole-rows kernel (both reductions into one fp32 accumulator) instead of a writing and an accumulating launch; with
+    tuning.FUSE_BF16_DUAL_TN (off by default: measured slower) its two weight gradients H^T . [dZ | dU] are one launch as well (other split-K
+    slabs than the two launches).  Same bf16 products, another association of the fp32 sums: three training steps agree with the separate
+    launches to fp32 rounding (not bit for bit) under both settings,
+    with the carry formed in the epilogue and with the stored carry alike (those two ARE bitwise equal: same accumulator, same addend)."""
+    from geographconv_amd import ops, tuning
+    from geographconv_amd.nn import layers as L
+    c = cmu
+    calls = []
+    orig = ops.gemm_kcat
+    monkeypatch.setattr(ops, 'gemm_kcat', lambda *a, **k: (calls.append(k.get('precision')), orig(*a, **k))[1])
+    runs = {}
+    for kcat, carry, dual_tn in ((True, True, False), (True, False, False), (False, True, False), (True, True, True)):
+        monkeypatch.setattr(tuning, 'FUSE_BF16_KCAT', kcat)
+        monkeypatch.setattr(tuning, 'FUSE_GATE_CARRY', carry)
+        monkeypatch.setattr(tuning, 'FUSE_BF16_DUAL_TN', dual_tn)
+        del calls[:]
+        clf = _clf(c, gemm_precision='bf16')
+        clf.inject_dropout_mask(c['mask'])
+        hist = []
+        for step in range(3):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+        runs[(kcat, carry) if not dual_tn else 'dual_tn'] = (hist, np.asarray(out[4]).copy(), clf.get_grads(), L.get_all_param_values(clf.l_out))
+        assert (len(calls) == 6 and set(calls) == {'bf16'}) if kcat else not calls, (kcat, calls)      # two blocks x three steps
+    a, b, two = runs[(True, True)], runs[(True, False)], runs[(False, True)]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    for h1, h2 in zip(a[0], two[0]):
+        assert abs(h1[0] - h2[0]) <= 2e-6 * abs(h2[0]) and abs(h1[2] - h2[2]) <= 2e-6 * abs(h2[2]) and h1[1] == h2[1] and h1[3] == h2[3]
+    assert np.abs(a[1] - two[1]).max() <= 2e-6
+    for i, (x, y) in enumerate(zip(a[2], two[2])):
+        assert np.abs(x - y).max() <= 1e-4 * np.abs(y).max() + 1e-9, i
+    assert any(not np.array_equal(x, y) for x, y in zip(a[2], two[2]))          # (another computation: the one launch really ran)
+    dt = runs['dual_tn']
+    assert np.abs(dt[1] - a[1]).max() <= 2e-6          # (at this size the one launch cuts the node dimension into the same 160-row slabs: same bits)
+    for i, (x, y) in enumerate(zip(dt[2], a[2])):
+        assert np.abs(x - y).max() <= 1e-4 * np.abs(y).max() + 1e-9, i
 
 
 def test_output_layers_softmax_in_the_epilogue_of_its_graph_product(cmu, monkeypatch):
@@ -645,6 +689,7 @@ def test_bf16_configuration_forward_pair_in_one_launch(cmu, monkeypatch):
     from geographconv_amd import ops, tuning
     from geographconv_amd.nn import layers as L
     c = cmu
+    monkeypatch.setattr(tuning, 'FUSE_BF16_KCAT', False)          # (the reverse sweep's fused launches hang on the forward pair: kept out of this A/B)
     calls = []
     orig = ops.gemm_dual_bf16
     monkeypatch.setattr(ops, 'gemm_dual_bf16', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])

@@ -383,6 +383,79 @@ def test_gemm_bf16_whole_rows_kernel(dev, M, N, K):
     assert np.all(np.abs(got.numpy() - ref) <= env)
 
 
+@pytest.mark.parametrize("M,N,K0,K1", [(1000, 600, 600, 600), (4099, 300, 300, 300), (130, 256, 256, 250), (65, 129, 300, 289), (64, 640, 590, 600),
+                                       (1, 600, 600, 600), (700, 600, 600, 300), (333, 700, 600, 600)])
+def test_gemm_bf16_kcat_one_launch(dev, M, N, K0, K1):
+    """(round 6) dH = dZ . Wh^T + dU . Wt^T of the bf16 configuration in ONE launch of the bf16 whole-rows kernel (both reductions
+    in LDS, one accumulator): against the same arithmetic in float64 -- operands rounded to bf16, exact products -- within the
+    fp32 accumulation envelope; plain, accumulating, with the carry gradient G (1 - T) in the epilogue; equal to the two separate
+    launches to rounding; run-to-run equal.  The last two shapes are NOT taken by the k-concatenated kernel (K paddings differ /
+    N > 640): the entry point then runs the two launches itself."""
+    from geographconv_amd import _ffi, ops
+
+    def bf16(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).double().numpy()
+
+    A0, A1 = _rand((M, K0), 21), _rand((M, K1), 22)
+    W0, W1 = _rand((N, K0), 23) * 0.3, _rand((N, K1), 24) * 0.3                 # weights as stored: transB
+    d = {k: ops.DMat.from_numpy(v, dev) for k, v in dict(A0=A0, A1=A1, W0=W0, W1=W1).items()}
+    ref = bf16(A0) @ bf16(W0).T + bf16(A1) @ bf16(W1).T
+    env = 4e-7 * (K0 + K1) ** 0.5 * (np.abs(bf16(A0)) @ np.abs(bf16(W0)).T + np.abs(bf16(A1)) @ np.abs(bf16(W1)).T) + 1e-6
+    lib = _ffi.lib()
+    native = (lib.geogcn_gemm_kcat_workspace_bytes(1, M, N, K0, K1, _ffi.GEMM_BF16) > max(lib.geogcn_gemm_workspace_bytes(0, 1, M, N, K0, _ffi.GEMM_BF16),
+                                                                                          lib.geogcn_gemm_workspace_bytes(0, 1, M, N, K1, _ffi.GEMM_BF16)))
+    assert native == ((K0 + 31) // 32 == (K1 + 31) // 32 and N <= 640 and (K0 + 31) // 32 * 32 in (256, 320, 608))
+    got = ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], transB=True, precision='bf16')
+    assert np.all(np.abs(got.numpy() - ref) <= env), np.abs(got.numpy() - ref).max()
+    assert torch.all(got.t[:, N:] == 0)                                         # pad columns stay zero
+    assert torch.equal(got.t, ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], transB=True, precision='bf16').t)
+    two = ops.gemm(d['A0'], d['W0'], transB=True, precision='bf16')
+    ops.gemm(d['A1'], d['W1'], out=two, transB=True, accumulate=True, precision='bf16')
+    assert np.all(np.abs(got.numpy() - two.numpy()) <= 2 * env)
+    if not native:
+        assert torch.equal(got.t, two.t)                                        # the entry point's own two launches
+    C0 = _rand((M, N), 25)
+    dC = ops.DMat.from_numpy(C0, dev)
+    ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], out=dC, transB=True, accumulate=True, precision='bf16')
+    assert np.all(np.abs(dC.numpy() - (ref + C0)) <= env + 1e-6)
+    G, T = _rand((M, N), 26), np.random.RandomState(27).rand(M, N).astype(np.float32)
+    carry = ops.GateCarry(ops.DMat.from_numpy(G, dev), ops.DMat.from_numpy(T, dev))
+    fused = ops.gemm_kcat(d['A0'], d['W0'], d['A1'], d['W1'], transB=True, gate_carry=carry, precision='bf16')
+    want = ref + G.astype(np.float64) * (1 - T)
+    assert np.all(np.abs(fused.numpy() - want) <= env + 3e-7 * (np.abs(ref) + np.abs(G)) + 1e-6)
+    # the same operands without the transposed weight layout
+    d0, d1 = ops.DMat.from_numpy(np.ascontiguousarray(W0.T), dev), ops.DMat.from_numpy(np.ascontiguousarray(W1.T), dev)
+    assert torch.equal(ops.gemm_kcat(d['A0'], d0, d['A1'], d1, precision='bf16').t, got.t)
+
+
+@pytest.mark.parametrize("K,M,N0,N1", [(70000, 600, 600, 600), (50001, 300, 300, 256), (33333, 256, 300, 300), (20000, 600, 600, 129)])
+def test_gemm_bf16_dual_tn_one_launch(dev, K, M, N0, N1):
+    """(round 6) (dWh, dWt) = H^T . [dZ | dU] of the bf16 configuration in ONE launch of the bf16 A^T . B kernel (H read once): against the
+    same arithmetic in float64 (operands rounded to bf16, exact products) within the fp32 accumulation envelope, equal to the two launches
+    to rounding, run-to-run equal; a pair with a narrow segment (N <= 160) is not taken: the entry point runs the two launches itself."""
+    from geographconv_amd import ops
+
+    def bf16(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).double().numpy()
+
+    A, B0, B1 = _rand((K, M), 31), _rand((K, N0), 32), _rand((K, N1), 33)
+    dA, d0, d1 = (ops.DMat.from_numpy(x, dev) for x in (A, B0, B1))
+    g0, g1 = ops.gemm_dual(dA, d0, d1, transA=True, precision='bf16')
+    s0 = ops.gemm(dA, d0, transA=True, precision='bf16')
+    s1 = ops.gemm(dA, d1, transA=True, precision='bf16')
+    for got, single, B in ((g0, s0, B0), (g1, s1, B1)):
+        if min(N0, N1) > 160:          # (a narrow product stays on the exact fp32 kernel in the bf16 configuration: compared with its single launch below)
+            ref = bf16(A).T @ bf16(B)
+            env = 4e-7 * K ** 0.5 * (np.abs(bf16(A)).T @ np.abs(bf16(B))) + 1e-6
+            assert np.all(np.abs(got.numpy() - ref) <= env), np.abs(got.numpy() - ref).max()
+            assert np.all(np.abs(got.numpy() - single.numpy()) <= 2 * env)
+        assert torch.all(got.t[:, B.shape[1]:] == 0)
+    again = ops.gemm_dual(dA, d0, d1, transA=True, precision='bf16')
+    assert torch.equal(again[0].t, g0.t) and torch.equal(again[1].t, g1.t)
+    if min(N0, N1) <= 160:
+        assert torch.equal(g0.t, s0.t) and torch.equal(g1.t, s1.t)
+
+
 @pytest.mark.parametrize("R,M,N", [(5000, 300, 300), (4097, 300, 129), (333, 300, 600), (20000, 64, 8)])
 def test_gemm_tn_splitk_matches_oracle_and_is_deterministic(dev, R, M, N):
     from geographconv_amd import ops
