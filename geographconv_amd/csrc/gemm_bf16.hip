@@ -424,17 +424,20 @@ __global__ __launch_bounds__(TPB) void prep_b_frag_kernel(const float* __restric
 
 constexpr int kRowsBM = 64, kRowsWCT = 5, kRowsDepth = 2;
 
-// KCAT: KP counts BOTH reduction segments (2 x 608 / 320 / 256): the LDS rows hold [A row | A1 row] as bf16 (157 KB at 2 x 608: one
-// block per CU), the k loop walks the weights' fragments of both segments into the same accumulators.
-template <int KP, int ACT, bool GATE = false, bool KCAT = false>
-__global__ __launch_bounds__(TPB, (KP * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) void gemm_bf16_rows_kernel(const Bf16Args a, const int passes) {
+// KCAT (k-concatenated launch, round 6): KP counts BOTH reduction segments (2 x 608 / 320 / 256) and the k loop walks the weights'
+// fragments of both into the same accumulators.  KCAT = 1: the LDS rows hold [A row | A1 row] (157 KB at 2 x 608: one block per CU,
+// each tile loaded once); KCAT = 2: the LDS rows hold ONE segment (79 KB: two blocks per CU), every column pass loads segment 0's tile,
+// multiplies, then segment 1's -- the accumulators live across the reload, as in x3_rows_kernel's K chunks.
+template <int KP, int ACT, bool GATE = false, int KCAT = 0>
+__global__ __launch_bounds__(TPB, ((KCAT == 2 ? KP / 2 : KP) * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) void gemm_bf16_rows_kernel(const Bf16Args a, const int passes) {
     constexpr int BM = kRowsBM, WCT = kRowsWCT, DEPTH = kRowsDepth, D1 = DEPTH + 1;
-    constexpr int PITCH = KP * 2 + 16;          // bytes per LDS row: an odd multiple of 16 -> conflict-free ds_read_b128
     constexpr int NSEG = KCAT ? 2 : 1, KPS = KP / NSEG;      // reduction segments; padded depth of one
+    constexpr int KL = KCAT == 2 ? KPS : KP;    // k columns an LDS row holds
+    constexpr int PITCH = KL * 2 + 16;          // bytes per LDS row: an odd multiple of 16 -> conflict-free ds_read_b128
     constexpr int F4R = KPS / 4;                // float4 per row and segment
     constexpr int ITERS = BM * F4R / TPB;
     constexpr int CH = 2, IPC = ITERS / CH;     // two batches of loads: half the staging registers
-    constexpr int MR = BM / 16, NK = KP / 32;
+    constexpr int MR = BM / 16, NK = KP / 32, NKS = KPS / 32;
     static_assert(BM * F4R % (TPB * CH) == 0 && (PITCH / 16) % 2 == 1, "a tile must divide over the block in two batches");
     extern __shared__ __attribute__((aligned(16))) unsigned char As[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -442,44 +445,46 @@ __global__ __launch_bounds__(TPB, (KP * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) v
     const int P = a.n_nseg == 2 ? a.passes0 + a.passes1 : passes;
     for (int mt = blockIdx.x; mt < a.n_mt; mt += gridDim.x) {
         const int64_t m0 = (int64_t)mt * BM;
-        {
+        const int64_t rows = std::min<int64_t>(BM, a.M - m0);
+        // segment sg's 64 x KPS tile: fp32 from HBM (one descriptor per tile: rows past M read as zeros in hardware), rounded to bf16 into
+        // the LDS rows at byte `at`
+        auto load_seg = [&](const int sg, const int at) {
             // (the offsets of the loads and LDS stores are the same for every tile: left alone, hipcc computes them once and keeps
             //  ~76 registers alive across the MFMA loop -- an opaque copy of the thread index makes them per-tile work)
             int tt = tid;
             asm volatile("" : "+v"(tt));
-            // one descriptor per tile: rows past M read as zeros in hardware
-            const int64_t rows = std::min<int64_t>(BM, a.M - m0);
+            const float* Ap = (KCAT && sg) ? a.A1 : a.A;
+            const int64_t lda = (KCAT && sg) ? a.lda1 : a.lda;
+            // pad columns of A up to roundup4(K) are zero (geogcn.h); beyond: not read
+            const int K4 = (int)((((KCAT && sg) ? a.K1 : a.K) + 3) & ~(int64_t)3);
+            const uint32_t ld4 = (uint32_t)lda * 4u;
+            const __amdgpu_buffer_rsrc_t rs = tn_rsrc(Ap + m0 * lda, rows * lda * 4);
 #pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) {
-                const float* Ap = (KCAT && sg) ? a.A1 : a.A;
-                const int64_t lda = (KCAT && sg) ? a.lda1 : a.lda;
-                // pad columns of A up to roundup4(K) are zero (geogcn.h); beyond: not read
-                const int K4 = (int)((((KCAT && sg) ? a.K1 : a.K) + 3) & ~(int64_t)3);
-                const uint32_t ld4 = (uint32_t)lda * 4u;
-                const __amdgpu_buffer_rsrc_t rs = tn_rsrc(Ap + m0 * lda, rows * lda * 4);
+            for (int ch = 0; ch < CH; ++ch) {
+                float4 v[IPC];
 #pragma unroll
-                for (int ch = 0; ch < CH; ++ch) {
-                    float4 v[IPC];
-#pragma unroll
-                    for (int i = 0; i < IPC; ++i) {
-                        const int idx = tt + TPB * (ch * IPC + i);
-                        const int r = idx / F4R, c = idx - r * F4R;
-                        v[i] = tn_load4(rs, c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : kOob);
-                    }
-#pragma unroll
-                    for (int i = 0; i < IPC; ++i) {
-                        const int idx = tt + TPB * (ch * IPC + i);
-                        const int r = idx / F4R, c = idx - r * F4R;
-                        uint2 w;
-                        w.x = bf16_pack(v[i].x, v[i].y);
-                        w.y = bf16_pack(v[i].z, v[i].w);
-                        *reinterpret_cast<uint2*>(As + r * PITCH + sg * (KPS * 2) + c * 8) = w;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < IPC; ++i) {
+                    const int idx = tt + TPB * (ch * IPC + i);
+                    const int r = idx / F4R, c = idx - r * F4R;
+                    v[i] = tn_load4(rs, c * 4 < K4 ? (uint32_t)r * ld4 + (uint32_t)c * 16u : kOob);
                 }
+#pragma unroll
+                for (int i = 0; i < IPC; ++i) {
+                    const int idx = tt + TPB * (ch * IPC + i);
+                    const int r = idx / F4R, c = idx - r * F4R;
+                    uint2 w;
+                    w.x = bf16_pack(v[i].x, v[i].y);
+                    w.y = bf16_pack(v[i].z, v[i].w);
+                    *reinterpret_cast<uint2*>(As + r * PITCH + at + c * 8) = w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (KCAT != 2) {
+            load_seg(0, 0);
+            if constexpr (KCAT == 1) load_seg(1, KPS * 2);
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll 1
         for (int ps = 0; ps < P; ++ps) {
             // (segment, pass inside it: wave-uniform)
@@ -502,16 +507,16 @@ __global__ __launch_bounds__(TPB, (KP * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) v
             // B fragments DEPTH k-steps ahead in a ring of DEPTH + 1 register sets.  The k loop stays ROLLED (DEPTH + 1 steps per
             // trip; ring slots are compile-time constants inside a trip) and the scheduler is fenced per step, so the requests stay
             // one set per step; requests past the last step re-read the last one (no branch around a load)
-            auto bload = [&](bf16x8 (&b)[WCT], int kt) {
-                const int kk = kt < NK ? kt : NK - 1;
+            auto bload = [&](bf16x8 (&b)[WCT], int kt, int lim) {
+                const int kk = kt < lim ? kt : lim - 1;
 #pragma unroll
                 for (int j = 0; j < WCT; ++j)
                     b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, lane * 16, ((tile0 + j) * NK + kk) * 1024, 0));
             };
-            auto kstep = [&](const bf16x8 (&b)[WCT], int kt) {
+            auto kstep = [&](const bf16x8 (&b)[WCT], int kt, int kl) {          // kl: the k-step inside the tile LDS holds
                 bf16x8 af[MR];
 #pragma unroll
-                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (i * 16 + li) * PITCH + kt * 64 + lg * 16);
+                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (i * 16 + li) * PITCH + kl * 64 + lg * 16);
 #pragma unroll
                 for (int j = 0; j < WCT; ++j)
 #pragma unroll
@@ -520,16 +525,40 @@ __global__ __launch_bounds__(TPB, (KP * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) v
                         // columns of one row of C
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], af[i], acc[i][j], 0, 0, 0);
             };
-            bf16x8 ring[D1][WCT];
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) bload(ring[d], d);
+            if constexpr (KCAT == 2) {
+                // one reduction segment at a time: its tile into LDS (the ring of B fragments is not alive across the reload: the staging
+                // registers of the tile load take its place), then its k-steps into the same accumulators
 #pragma unroll 1
-            for (int k0 = 0; k0 < NK; k0 += D1) {
+                for (int sg = 0; sg < 2; ++sg) {
+                    __syncthreads();          // everybody done with the tile before (the previous segment's, pass's or row tile's)
+                    load_seg(sg, 0);
+                    __syncthreads();
+                    const int kb = sg * NKS;
+                    bf16x8 ring[D1][WCT];
 #pragma unroll
-                for (int u = 0; u < D1; ++u) {
-                    bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH);
-                    if (k0 + u < NK) kstep(ring[u], k0 + u);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int d = 0; d < DEPTH; ++d) bload(ring[d], kb + d, kb + NKS);
+#pragma unroll 1
+                    for (int k0 = 0; k0 < NKS; k0 += D1) {
+#pragma unroll
+                        for (int u = 0; u < D1; ++u) {
+                            bload(ring[(u + DEPTH) % D1], kb + k0 + u + DEPTH, kb + NKS);
+                            if (k0 + u < NKS) kstep(ring[u], kb + k0 + u, k0 + u);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            } else {
+                bf16x8 ring[D1][WCT];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) bload(ring[d], d, NK);
+#pragma unroll 1
+                for (int k0 = 0; k0 < NK; k0 += D1) {
+#pragma unroll
+                    for (int u = 0; u < D1; ++u) {
+                        bload(ring[(u + DEPTH) % D1], k0 + u + DEPTH, NK);
+                        if (k0 + u < NK) kstep(ring[u], k0 + u, k0 + u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             // epilogue: the arithmetic of gemm_bf16_kernel, in its order
@@ -595,7 +624,7 @@ __global__ __launch_bounds__(TPB, (KP * 2 + 16) * kRowsBM > 80 * 1024 ? 1 : 2) v
                 }
             }
         }
-        __syncthreads();          // everybody done reading this tile's rows
+        if constexpr (KCAT != 2) __syncthreads();          // everybody done reading this tile's rows (KCAT = 2 synchronises before every load)
     }
 }
 
@@ -611,18 +640,22 @@ inline int rows_kp(int64_t N, int64_t K, int panel_w, int ns) {
 inline int rows_passes(int64_t N) { return N <= 4 * kRowsWCT * 16 ? 1 : 2; }
 
 // k-concatenated launch (no activation; plain / accumulating / with the gate carry)
+#ifndef GEOGCN_BF16_KCAT_MODE
+#define GEOGCN_BF16_KCAT_MODE 1          // (measured, profiles/r06_bf16_kcat_mode_ab.txt: dH 1.75 ms in mode 1, 1.83 in mode 2, 1.95 as two launches) 1: both segments' tiles in LDS (one block per CU at 2 x 608), 2: one segment at a time (two blocks per CU)
+#endif
 template <int KP>
 int launch_rows_kcat(const Bf16Args& a, hipStream_t st) {
-    constexpr int lds = kRowsBM * (KP * 2 + 16);
+    constexpr int KM = GEOGCN_BF16_KCAT_MODE;
+    constexpr int lds = kRowsBM * ((KM == 2 ? KP / 2 : KP) * 2 + 16);
     const int passes = rows_passes(a.N);
     const int G = (int)std::min<int64_t>((int64_t)kNumCU * 2, a.n_mt);
     if (a.gateG) {
-        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, true, true>;
+        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, true, KM>;
         static LdsAttrOnce lds_once;
         if (const int rc_ = lds_once.ensure((const void*)kern, lds)) return rc_;
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);
     } else {
-        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, false, true>;
+        auto kern = gemm_bf16_rows_kernel<KP, GEOGCN_ACT_NONE, false, KM>;
         static LdsAttrOnce lds_once;
         if (const int rc_ = lds_once.ensure((const void*)kern, lds)) return rc_;
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(TPB), lds, st, a, passes);
