@@ -281,8 +281,10 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
     wb = 4 * F * F                                 # one weight matrix
     act = 4 * N * F                                # one N x F fp32 activation
     from geographconv_amd import tuning as _tuning
-    fp = 'bf16x3' if precision == 'bf16x3' else 'f32'        # precision of the fused highway launches
-    rows = "x3_rows_kernel: 64 rows of A per block in K chunks, three bf16 planes in LDS" if fp == 'bf16x3' else "gemm_rows_kernel: 64 whole rows of A per block"
+    fp = precision if precision in ('bf16x3', 'bf16') else 'f32'        # precision of the fused highway launches (bf16: only the k-concatenated dH is one)
+    rows = {'bf16x3': "x3_rows_kernel: 64 rows of A per block in K chunks, three bf16 planes in LDS",
+            'bf16': "gemm_bf16_rows_kernel: 64 whole rows of both A operands per block as bf16 in LDS",
+            'f32': "gemm_rows_kernel: 64 whole rows of A per block"}[fp]
     mfma("H . [Wh | Wt], sigmoid on the gate half  (%s, dual)" % rows, 'gemm_dual_nn', 2 * fl, 3 * act + 2 * wb, fp)
     mfma("H^T . [dZ | dU]  (%s; split-K + ordered combine)" % (
         "x3_tn_kernel: operands transposed + split into three bf16 planes on their way into LDS" if fp == 'bf16x3'
