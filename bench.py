@@ -882,7 +882,8 @@ def main():
     first = run_scheme(comm)
     results[first_name] = first
     extras = {}
-    if world > 1 and rank == 0:
+    multi = world > 1 or force_dist          # (GEOGCN_BENCH_FORCE_DIST=1: the whole N > 1 flow at world 1 -- real RCCL on a one-GPU box; tests/test_dist_gpu.py)
+    if multi and rank == 0:
         early = build_line(first, {})
         early["note"] = ("early line: the first scheme only, printed before the other schemes and the partition check run -- a later line of "
                          "this invocation supersedes it")
@@ -896,7 +897,7 @@ def main():
         best = min(done, key=lambda e: done[e]["t"]) if done else None
         head = done[best] if best is not None else first
         ex = dict(extras)
-        if world > 1:
+        if multi:
             others = [summary(k, v) for k, v in done.items() if k != best] + failed + ([pending_error] if pending_error else [])
             ex["exchange_choice"] = {"how": "the north_star's all-gather timed first; every other scheme over the same %d steps after %d warm-up steps, each "
                                             "behind a try/except and a %.0f s wall-clock guard; value = the fastest that finished" % (args.steps, args.warmup, args.scheme_timeout),
@@ -910,7 +911,7 @@ def main():
                 ex["alt_more"] = others[2:]
         return build_line(head, ex)
 
-    if world > 1 and not args.no_alt:
+    if multi and not args.no_alt:
         for name in [n for n in args.schemes.split(',') if n and n != first_name]:
             watchdog.arm(args.scheme_timeout, 'exchange scheme %s' % name,
                          lambda msg, name=name: emit(dict(final_line({"exchange": name, "error": msg}), watchdog_fired=True)))
@@ -924,7 +925,7 @@ def main():
     # (round 6, --graph) ... and the fastest capturable scheme once more with its step captured in a hipGraph and replayed (~60 launches per
     # 4-5 ms rank-step at 8 ranks): a candidate for `value` like any other scheme when it follows the eager run's losses (same Philox
     # stream, same number of steps: the last training loss must agree to 1e-3); behind the same guards
-    if world > 1 and args.graph and not staged:
+    if multi and args.graph and not staged:
         done_now = {k: v for k, v in results.items() if k is not None and make_comm(k).capturable}
         base = min(done_now, key=lambda e: done_now[e]["t"]) if done_now else None
         if base is not None:
@@ -934,7 +935,11 @@ def main():
             try:
                 r = run_scheme(make_comm(base), hip_graph=True)
                 r["kern_ms"] = r["kern_ms"] or done_now[base]["kern_ms"]          # (replays record no per-kernel events: the eager run's)
-                l0, l1 = float(done_now[base]["last"][0]), float(r["last"][0])
+                # (the captured run warms up for at least four steps: bring the eager model of the same scheme to the same step count first)
+                last_e = done_now[base]["last"]
+                for _ in range(max(args.warmup, 4) - args.warmup):
+                    last_e = done_now[base]["clf"].f_train(X, y_tr, y_dev, A, tr, dev)
+                l0, l1 = float(last_e[0]), float(r["last"][0])
                 if not (abs(l1 - l0) <= 1e-3 * abs(l0)):
                     raise RuntimeError("captured run's last training loss %r differs from the eager run's %r" % (l1, l0))
                 results[name] = r
@@ -943,7 +948,7 @@ def main():
                 log('[bench] rank %d: exchange scheme %s failed: %r' % (rank, name, e))
             finally:
                 watchdog.disarm()
-    if world > 1 and not args.no_check:
+    if multi and not args.no_check:
         watchdog.arm(args.scheme_timeout, 'partition_check',
                      lambda msg: emit(dict(final_line(), partition_check={"error": msg}, watchdog_fired=True)))
         try:

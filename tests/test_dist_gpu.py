@@ -154,6 +154,36 @@ def test_bench_launches_its_own_ranks_and_checks_itself():
         assert c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9995, (scheme, c)
 
 
+def test_bench_whole_multi_gpu_flow_over_rccl_at_world_1():
+    """(round 6) The N > 1 flow of bench.py -- early line, every exchange scheme behind its guard, the hipGraph variant of the fastest
+    capturable scheme (--graph), the partition check -- over REAL RCCL (torch.distributed nccl, no host staging) on the one GPU the
+    box has: GEOGCN_BENCH_FORCE_DIST=1 runs the partitioned code path at world 1.  One rank's collectives are trivial, but the process
+    group, the in-place all-gathers on device buffers, the all-to-alls, the gradient all-reduce and the capture all run on the library
+    the driver's 8-GPU run will use."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GEOGCN_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT='29561')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'GEOGCN_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--shape', 'cmu', '--steps', '3', '--warmup', '2', '--no-extras', '--traffic', 'none',
+           '--cpu-sample', 'none', '--graph']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 2 and json.loads(lines[0])['note'].startswith('early line')
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 1 and d['config']['dist']['torch_backend'] == 'nccl' and d['config']['dist']['staged'] is False
+    ch = d['exchange_choice']
+    assert ch['timed_first'] == 'allgather' and {'allgather', 'a2a', 'agpipe'} <= set(ch['ms_per_step'])
+    graphed = [k for k in ch['ms_per_step'] if k.endswith('+hipgraph')]
+    assert len(graphed) == 1 and graphed[0].split('+')[0] in ('allgather', 'agpipe'), ch          # (all-to-all steps are not captured)
+    assert not any('error' in x for x in (d.get('alt'), d.get('alt2')) + tuple(d.get('alt_more', ())) if x), d
+    assert d['config']['hip_graph'] == (ch['picked'] in graphed)
+    for scheme in ('allgather', 'a2a', 'agpipe'):
+        c = d['partition_check'][scheme]
+        assert c['max_abs_dloss'] <= 2e-5 and c['max_abs_dP'] <= 2e-6 and c['argmax_agreement'] >= 0.9995, (scheme, c)
+
+
 def test_bench_survives_schemes_that_fail():
     """One exception in a scheme timed after the first must not cost the headline (the first contact with real links
     may be the only one): with a failure injected into a2a AND agpipe on every rank, the last line of stdout is still one parsable
