@@ -308,7 +308,7 @@ def other_kernels(clf, step, g, hid, N, C, precision, n_steps=5):
         kern = {'f32': 'gemm_tn_direct_kernel' if form == 'tn' else
                        ('gemm_rows_kernel' if (form == 'nt' or N_ in range(193, 257) or N_ in range(449, 513)) and M_ >= 32768 and N_ <= 640
                         and -(-K_ // 16) * 16 in (256, 304) else 'gemm_kernel'),
-                'bf16x3': ('x3_tn_kernel' if form == 'tn' and N_ > 160 else 'x3_rows_kernel' if form != 'tn' and M_ >= 32768 and N_ <= 1024 and K_ <= 1024
+                'bf16x3': ('x3_tn_kernel' if form == 'tn' and N_ > 160 else 'x3_rows_kernel' if form != 'tn' and M_ >= 4096 and N_ <= 1024 and K_ <= 1024
                            else 'exact fp32 kernel'),
                 'bf16': 'gemm_bf16_rows_kernel / gemm_bf16_kernel / gemm_bf16_tn_kernel'}[prec]
         mfma("%s product %d x %d x %d (%s; C %s%s)" % ({'nn': 'A . B', 'nt': 'A . B^T', 'tn': 'A^T . B'}[form], M_, N_, K_, kern,

@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
 
 // The library's two TEST SEAMS (geographconv_amd/tuning.py lists them; nothing else in csrc/ reads the environment): an integer from the
 // environment, read at EVERY call so that a test's monkeypatch.setenv / delenv takes effect on the next launch (core.hip).
-//   GEOGCN_X3_ROWS_MIN_M     rows from which the split-bf16 whole-rows kernel takes an A . B (gemm_x3.hip; default 32,768)
+//   GEOGCN_X3_ROWS_MIN_M     rows from which the split-bf16 whole-rows kernel takes an A . B (gemm_x3.hip; default 4,096)
 //   GEOGCN_TN_SLAB_LIMIT     bytes one buffer descriptor is taken to bound in the A^T . B slab kernels (gemm.hip; default 2^31 - 1)
 int64_t test_seam_i64(const char* name, int64_t dflt);
 

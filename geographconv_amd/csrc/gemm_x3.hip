@@ -443,11 +443,11 @@ __global__ __launch_bounds__(512, 1) void x3_tn_kernel(const X3TnCall a) {
 }
 
 // ---- whole-rows kernel: which calls take it, its workspace, its launch -----------------------------------------------------------------
-// Below this many rows an A . B stays on the exact fp32 kernels (the weights' split + fragment-order pass is a launch of its own and a
-// 64-row block per CU no longer fills the chip).  The test seam GEOGCN_X3_ROWS_MIN_M (common.h) lowers it -- and lifts the rule about
+// Below this many rows an A . B stays on the exact fp32 kernels (the weights' split + fragment-order pass is a launch of its own and
+// 64-row blocks no longer fill the chip).  The test seam GEOGCN_X3_ROWS_MIN_M (common.h) lowers it -- and lifts the rule about
 // padded columns below -- so that the model-level oracle tests at CMU / fixture sizes (12-wide layers included) run THIS kernel and not
 // the exact one under the label 'bf16x3'.
-constexpr int64_t kX3RowsMinM = 32768;
+constexpr int64_t kX3RowsMinM = 4096;          // (32,768 until round 6; the CMU-shape step, 9,475 rows: 1.118 -> 1.010 ms with its products on this kernel, profiles/r06_cmu_x3_threshold.txt)
 inline int64_t x3_rows_min_m() { return test_seam_i64("GEOGCN_X3_ROWS_MIN_M", kX3RowsMinM); }
 constexpr int64_t kX3RowsMaxN = 1024, kX3RowsMaxK = 1024;          // (round 6: 640 until then; the reference's WORLD run is 900 / 930 wide)
 inline int rows_passes(int64_t N) { return (int)cdiv(N, 4 * kWCT * 16); }                  // column passes of 320 (300 -> 1, 600 -> 2, 900 -> 3)

@@ -515,8 +515,11 @@ def gemm_gated_native(n, F, precision=None):
     p = precision or GEMM_PRECISION
     if p == 'bf16':
         return True
-    # (bf16x3: the split-bf16 whole-rows kernel takes every shape the exact one does)
-    return p in ('f32', 'bf16x3') and _ffi.lib().geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_F32) > 0
+    lib = _ffi.lib()
+    if p == 'bf16x3' and (lib.geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_BF16X3)
+                          > 3 * ((int(F) + 31) // 32 * 32) * int(F) * 2):
+        return True          # the split-bf16 whole-rows kernel takes it (its fragment-ordered weights are larger than the staged kernel's planes)
+    return p in ('f32', 'bf16x3') and lib.geogcn_gemm_workspace_bytes(0, 1, int(n), int(F), int(F), _ffi.GEMM_F32) > 0
 
 
 def kcat_gated_native(n, F, precision=None):

@@ -11,8 +11,8 @@ Environment variables read by product code -- four, all about WHICH configuratio
 call (csrc/common.h `test_seam_i64`) so that a test's monkeypatch.setenv reaches kernels only large operands reach by default; they
 replace the exported debug hook of round 5 and are not configuration:
 
-  GEOGCN_X3_ROWS_MIN_M   rows from which x3_rows_kernel takes an A . B (default 32,768); tests set 64 so that the model-level oracle
-                         tests at CMU / fixture sizes run the split-bf16 kernel the TwitterUS step runs (tests/conftest.py)
+  GEOGCN_X3_ROWS_MIN_M   rows from which x3_rows_kernel takes an A . B (default 4,096; 32,768 until round 6); tests set 1 so that the model-level oracle
+                         tests at fixture sizes (12-wide layers on 96 nodes included) run the split-bf16 kernel the TwitterUS step runs (tests/conftest.py)
   GEOGCN_TN_SLAB_LIMIT   bytes one buffer descriptor is taken to bound in the A^T . B slab kernels (default 2^31 - 1): the fallback's test
 
 Everything else is a module attribute below: a

@@ -204,9 +204,9 @@ int  geogcn_timer_read_ms(geogcn_timer* t, float* out_ms, int32_t max_out, int32
  *                      per product: fp32-class accuracy (dropped terms O(2^-24 |a||b|); measured against fp64
  *                      1.0-1.4e-7 sum|a.b| at K = 300, the exact kernel 1.4-1.5e-7), 2.7x fewer MFMA cycles.  It is a
  *                      PERMISSION, not a promise: shapes no split-bf16 kernel takes run exact fp32 (csrc/gemm_x3.hip: whole
- *                      rows of A for M >= 32,768, K <= 1,024, N <= 1,024; transA = 1 in 128 / 160 x 256 / 320 tiles, several per
+ *                      rows of A for M >= 4,096 (32,768 until round 6), K <= 1,024, N <= 1,024; transA = 1 in 128 / 160 x 256 / 320 tiles, several per
  *                      row of C beyond 320 columns; feature-panel outputs, geogcn_gemm_panels_f32, on the same whole-rows kernel
- *                      from 32,768 rows and on the staged split-bf16 kernel of csrc/gemm_bf16.hip below).  Non-finite operands: an Inf or NaN in A or B gives NaN in every output
+ *                      from 4,096 rows and on the staged split-bf16 kernel of csrc/gemm_bf16.hip below).  Non-finite operands: an Inf or NaN in A or B gives NaN in every output
  *                      it reaches (the split's residual Inf - Inf), where the exact kernels would give Inf for an Inf times a
  *                      non-zero; so does a finite |x| >= 0x1.ffp+127 (3.396e38: it rounds to the bf16 infinity).  Every other fp32
  *                      value, subnormals included, splits exactly;
@@ -253,7 +253,10 @@ int geogcn_gemm_panels_f32(int32_t transB, int64_t M, int64_t N, int64_t K, cons
  * 304, N0 and N1 filling 320-column passes) run on the whole-rows kernel -- 64 rows of A per block read once, the weights
  * re-laid in fragment order into `ws` -- with bit-identical results; without it (ws too small / NULL) on the staged kernel.  */
 /* `precision`: GEOGCN_GEMM_F32 (the exact kernels above) or GEOGCN_GEMM_BF16X3 (the same launches with fp32-class split-bf16
- * products where csrc/gemm_x3.hip takes the shape -- see geogcn_gemm_f32 -- exact fp32 otherwise); the workspace is sized for it.  */
+ * products where csrc/gemm_x3.hip takes the shape -- see geogcn_gemm_f32 -- exact fp32 otherwise); the workspace is sized for it.
+ * GEOGCN_GEMM_BF16 is accepted with transA = 1 only (round 6; no bias / activation): both weight gradients of the bf16 configuration
+ * in one launch of its A^T . B kernel where both segments are wider than 160 columns, its two launches otherwise (the forward pair of
+ * that configuration is geogcn_gemm_dual_bf16 below).                                                                              */
 size_t geogcn_gemm_dual_workspace_bytes(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, int32_t precision);
 int geogcn_gemm_dual_f32(int32_t transA, int64_t M, int64_t N0, int64_t N1, int64_t K, const float* A, int64_t lda,
                          const float* B0, int64_t ldb0, const float* B1, int64_t ldb1, float* C0, int64_t ldc0,
@@ -294,8 +297,12 @@ int geogcn_gemm_kcat_gated_tanhbwd_f32(int32_t transB, int64_t M, int64_t N, int
                                        float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
                                        const float* Y, int64_t ldy, const uint8_t* keep, int64_t keepF, float scale, int32_t precision,
                                        void* ws, size_t ws_bytes, void* stream);
-/* ... and for ONE product: C[M x N] = A . op(B) + G * (1 - T) in any `precision` (the bf16 configuration forms dH_in with two
- * calls: this one, then an accumulating geogcn_gemm_f32).  ws as for geogcn_gemm_f32 (geogcn_gemm_workspace_bytes).             */
+/* (round 6) geogcn_gemm_kcat_f32 and geogcn_gemm_kcat_gated_f32 also take GEOGCN_GEMM_BF16: one launch of the bf16 whole-rows kernel
+ * with both reductions' row tiles in LDS where K0 and K1 pad to the same 256 / 320 / 608 and N <= 640 (one fp32 accumulator over both
+ * reductions: equal to the two launches to rounding, not bit for bit), the two launches otherwise; geogcn_gemm_kcat_workspace_bytes
+ * covers both.  geogcn_gemm_kcat_gated_tanhbwd_f32 with GEOGCN_GEMM_BF16 applies the tanh gradient in a pass of its own.          */
+/* ... and for ONE product: C[M x N] = A . op(B) + G * (1 - T) in any `precision` (the bf16 configuration formed dH_in with two
+ * calls until round 6: this one, then an accumulating geogcn_gemm_f32).  ws as for geogcn_gemm_f32 (geogcn_gemm_workspace_bytes). */
 int geogcn_gemm_gated_f32(int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                           int64_t ldb, float* C, int64_t ldc, const float* G, int64_t ldg, const float* T, int64_t ldt,
                           int32_t precision, void* ws, size_t ws_bytes, void* stream);

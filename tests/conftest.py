@@ -34,7 +34,7 @@ X3_EVERYWHERE_MIN_M = 1           # every row count (a block of x3_rows_kernel t
 
 def force_x3_rows(monkeypatch, min_m=X3_EVERYWHERE_MIN_M):
     """Lower the library's test seam GEOGCN_X3_ROWS_MIN_M (csrc/common.h; read at every call) so that the split-bf16 whole-rows kernel
-    takes every A . B of at least `min_m` rows -- by default only the TwitterUS-size products reach it (32,768 rows)."""
+    takes every A . B of at least `min_m` rows -- by default only products of at least 4,096 rows reach it (and only column counts that fill its passes)."""
     monkeypatch.setenv('GEOGCN_X3_ROWS_MIN_M', str(min_m))
 
 

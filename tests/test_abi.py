@@ -61,16 +61,16 @@ def test_the_librarys_test_seams_are_read_per_call(built, monkeypatch):
 
     def takes(M, N, K):          # (the whole-rows kernel's fragment-ordered weights are larger than the staged kernel's three planes)
         return lib.geogcn_gemm_workspace_bytes(0, 0, M, N, K, _ffi.GEMM_BF16X3) > 3 * ((K + 31) // 32 * 32) * N * 2
-    assert takes(32768, 300, 300) and not takes(32767, 300, 300) and not takes(9475, 300, 300)
+    assert takes(4096, 300, 300) and not takes(4095, 300, 300) and takes(9475, 300, 300)          # (CMU size: taken since round 6)
     assert takes(440000, 900, 900) and takes(440000, 1024, 1024) and not takes(440000, 1025, 300)
     assert not takes(440000, 129, 300)                                # half a column pass of padding: not taken by default
     monkeypatch.setenv('GEOGCN_X3_ROWS_MIN_M', '1')
-    assert takes(9475, 300, 300) and takes(96, 12, 12) and takes(440000, 129, 300) and not takes(96, 1025, 12)
+    assert takes(700, 300, 300) and takes(96, 12, 12) and takes(440000, 129, 300) and not takes(96, 1025, 12)
     for bad in ('0', '-5', 'abc', '12x', ''):
         monkeypatch.setenv('GEOGCN_X3_ROWS_MIN_M', bad)
-        assert not takes(9475, 300, 300) and takes(32768, 300, 300), bad
+        assert not takes(700, 300, 300) and takes(4096, 300, 300), bad
     monkeypatch.delenv('GEOGCN_X3_ROWS_MIN_M')
-    assert not takes(9475, 300, 300)
+    assert not takes(700, 300, 300)
     assert not any('debug' in name for name in _ffi.SIGNATURES) and not hasattr(lib, 'geogcn_debug_set_tn_slab_limit')
 
 

@@ -79,7 +79,7 @@ def test_cmu_forward_logits_and_labels(cmu):
 
 def test_bf16x3_leg_runs_the_split_kernels_at_cmu_size(cmu, gemm_mode, monkeypatch):
     """What the two legs of this file mean: under 'bf16x3' the deterministic forward differs in bits from the exact-fp32
-    one (x3_rows_kernel ran: the library's test seam lowers its 32,768-row threshold), within the stated tolerance."""
+    one (x3_rows_kernel ran -- at this size it does by default since round 6, threshold 4,096 rows; the seam also covers the small shapes of this file), within the stated tolerance."""
     from geographconv_amd import ops
     c = cmu
     probs = _clf(c).predict(c['X'], c['A'], c['te'])[1]

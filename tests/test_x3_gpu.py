@@ -133,7 +133,7 @@ def test_x3_rows_shapes_really_take_the_kernel(dev):
     """(the tests above would pass on the staged kernel too: make sure the TwitterUS shapes are routed to the whole-rows kernel)"""
     for (N, K, tb) in [(300, 300, 0), (256, 300, 0), (300, 256, 1), (300, 300, 1)]:
         assert _takes_x3(440000, N, K, bool(tb)), (N, K, tb)
-    assert not _takes_x3(9475, 300, 300)            # CMU size: not taken (such a call runs the exact fp32 kernels)
+    assert _takes_x3(9475, 300, 300) and not _takes_x3(4095, 300, 300)            # CMU size: taken since round 6 (threshold 4,096 rows)
     # (round 6) the reference's WORLD widths (README.md:177-181: -hid 900 900 900, 930 classes): taken in both orientations
     for (N, K, tb) in [(900, 900, 0), (900, 900, 1), (930, 900, 0), (900, 930, 1), (1024, 1024, 0)]:
         assert _takes_x3(440000, N, K, bool(tb)), (N, K, tb)
