@@ -219,7 +219,7 @@ class InputLayer(Layer):
 
 
 def _fuse_highway(fp32_operand):
-    """tuning.FUSE_HIGHWAY = 'all' (default) | 'f32' | 'none': which SpMM operand formats get the gating mix fused."""
+    """tuning.FUSE_HIGHWAY = 'all' | 'f32' (default) | 'none': which SpMM operand formats get the gating mix fused."""
     mode = tuning.FUSE_HIGHWAY
     return mode == 'all' or (mode == 'f32' and fp32_operand)
 

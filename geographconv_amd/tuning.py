@@ -43,10 +43,12 @@ def dist_backend():
 # ---- fusion A/B (both on; tests flip them to prove the fused launches equal the separate ones) ----------------------
 # highway block: (Z, T) = (H.Wh, sigmoid(H.Wt + bt)), (dWh, dWt), dH in one GEMM launch each (-0.46 ms per TWUS step)
 FUSE_GEMMS = True
-# gating mix T*Hc + (1-T)*H in the SpMM's epilogue: 'all' (default), 'f32' = for the fp32 gathered operand only, 'none'.
+# gating mix T*Hc + (1-T)*H in the SpMM's epilogue: 'all', 'f32' (default since round 6) = for the fp32 gathered operand only, 'none'.
 # (On the bf16 operand the fused epilogue was slower in round 2 -- 1.82 ms against 1.10 + 0.41 at 300 wide; re-measured at the end
 #  of round 3, same box, two alternations: 6x600 bf16 step 69.95 -> 69.56 ms, 3x300 bf16 18.06 -> 17.98: now ahead, so 'all'.)
-FUSE_HIGHWAY = 'all'
+#  Round 6, same box, two alternations: 6x600 bf16 67.99 / 67.98 ms with 'all', 67.65 / 67.67 with 'f32'; 3x300 bf16 17.40 / 17.17: the separate
+#  highway_fwd pass is ahead again on the bf16 operand -> 'f32' (the fp32 configurations are unaffected: their operand is fp32).)
+FUSE_HIGHWAY = 'f32'
 
 # the highway block's carry gradient G * (1 - T) formed in the epilogue of dH = dZ.Wh^T + dU.Wt^T (geogcn_gemm_kcat_gated_f32) instead
 # of written by highway_bwd and read back: 0.53 GB less written per 300-wide block at the TwitterUS size; same bits

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 # default WITH the split-bf16 kernels forced onto these sizes, 'f32' = exact) -- except those that name their precision themselves
 # (they would run the same bits twice):
 PINNED_PRECISION = {'test_config5_bf16_six_layer_600_hidden', 'test_bf16_configuration_forward_pair_in_one_launch',
-                    'test_bf16_configuration_input_gradient_in_one_launch',
+                    'test_bf16_configuration_input_gradient_in_one_launch', 'test_bf16_configuration_gating_mix_fused_or_separate',
                     'test_bf16_configuration_branch_gradient_stored_as_bf16', 'test_training_step_is_bitwise_reproducible',
                     'test_world_configuration_widths'}
 
@@ -709,6 +709,28 @@ def test_bf16_configuration_forward_pair_in_one_launch(cmu, monkeypatch):
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
     assert all(np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
     assert np.array_equal(runs[0][3], runs[1][3]) and np.array_equal(runs[0][4], runs[1][4])
+
+
+def test_bf16_configuration_gating_mix_fused_or_separate(cmu, monkeypatch):
+    """tuning.FUSE_HIGHWAY: 'f32' (default since round 6: on the bf16 gathered operand the separate highway_fwd pass measured faster)
+    against 'all' (the gating mix in the graph product's epilogue for the bf16 operand too): losses and probabilities of two training
+    steps bitwise equal -- the epilogue is the separate pass element for element --, gradients to fp32 rounding."""
+    from geographconv_amd import tuning
+    c = cmu
+    assert tuning.FUSE_HIGHWAY == 'f32'
+    runs = []
+    for mode in ('f32', 'all'):
+        monkeypatch.setattr(tuning, 'FUSE_HIGHWAY', mode)
+        clf = _clf(c, gemm_precision='bf16')
+        clf.inject_dropout_mask(c['mask'])
+        hist = []
+        for step in range(2):
+            out = clf.f_train(c['X'], c['Y'][c['tr']], c['Y'][c['dev']], c['A'], c['tr'], c['dev'])
+            hist.append([float(v) for v in out[:4]])
+        runs.append((hist, np.asarray(out[4]).copy(), clf.get_grads()))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])          # forward: bit for bit
+    for i, (a, b) in enumerate(zip(runs[0][2], runs[1][2])):          # (the reverse sweep then takes other launches: to fp32 rounding)
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 1e-10, i
 
 
 def test_bf16_configuration_branch_gradient_stored_as_bf16(cmu, monkeypatch):
