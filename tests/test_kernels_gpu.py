@@ -1028,6 +1028,38 @@ def test_sigmoid_epilogue_accuracy(dev):
     assert np.all(np.isnan(nan))
 
 
+def test_tanh_accuracy(dev):
+    """The library's tanh (csrc/common.h apply_act<GEOGCN_ACT_TANH>: libm's tanhf -- a 22-instruction replacement, polynomial below
+    |x| = 0.6 and 1 - 2 / (exp(2|x|) + 1) above, passed this test and the whole parity suite in round 6 and changed no kernel's time:
+    profiles/r06_fast_tanh_ab.txt; not kept; every epilogue and elementwise kernel calls it) against float64 over every binade from 2^-126 to 2^4, both signs, the branch boundary, the saturation
+    point and the special values: at most 3 units in the last place of the float32 result; odd; monotone on a fine grid; -0, +-inf, NaN."""
+    from geographconv_amd import ops
+    rng = np.random.RandomState(0)
+    parts = [np.ldexp(1.0 + rng.rand(4096), e) for e in range(-126, 5)]                       # every binade
+    parts += [np.linspace(0.55, 0.65, 200001), np.linspace(0.0, 12.0, 1200001), np.array([0.6, np.nextafter(np.float32(0.6), 0), 9.99, 10.0, 10.01, 88.0, 1e30])]
+    x = np.concatenate(parts).astype(np.float32)
+    x = np.concatenate([x, -x])
+    F = 1024
+    n = -(-x.size // F)
+    X = np.zeros((n, F), np.float32)
+    X.reshape(-1)[:x.size] = x
+    zero = torch.zeros(F, device=dev)
+    got = ops.bias_act(ops.DMat.from_numpy(X, dev), zero, ops.ACT_TANH).numpy().reshape(-1)[:x.size]
+    ref = np.tanh(x.astype(np.float64))
+    ulp = np.abs(got.astype(np.float64) - ref) / np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 3.0, (float(ulp.max()), float(x[ulp.argmax()]))
+    assert np.array_equal(got[:x.size // 2], -got[x.size // 2:])                             # odd
+    grid = np.linspace(-12, 12, 2000001).astype(np.float32)
+    G = np.zeros((-(-grid.size // F), F), np.float32)
+    G.reshape(-1)[:grid.size] = grid
+    g = ops.bias_act(ops.DMat.from_numpy(G, dev), zero, ops.ACT_TANH).numpy().reshape(-1)[:grid.size]
+    assert np.all(np.diff(g) >= -2.4e-7) and np.all(np.abs(g) <= 1.0)                        # monotone to 2 ulp of 1, never beyond 1
+    sp = np.zeros((1, F), np.float32)
+    sp[0, :5] = [-0.0, np.inf, -np.inf, np.nan, 0.0]
+    s = ops.bias_act(ops.DMat.from_numpy(sp, dev), zero, ops.ACT_TANH).numpy()[0]
+    assert s[0] == 0 and s[1] == 1 and s[2] == -1 and np.isnan(s[3]) and s[4] == 0          # (-0 + the zero bias is +0 before the activation sees it)
+
+
 @pytest.mark.parametrize("n,F", [(1000, 300), (257, 129), (3, 5)])
 def test_highway_and_tanh_kernels(dev, n, F):
     from geographconv_amd import ops
