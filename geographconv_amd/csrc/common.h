@@ -111,6 +111,17 @@ __device__ __forceinline__ float apply_act(float x) {
     }
 }
 
+// Four consecutive bias values bias[col0 .. col0 + 3] for an epilogue that owns a float4 of a row: ONE 16-byte load where the quad lies
+// inside [0, F) and the vector is 16-byte aligned (every bias of ParamStore's arena is), scalar loads otherwise; beyond F: zeros.
+// (Round 6: the epilogues read their bias one float at a time -- 40 scalar loads per lane and row at 600 columns: the 600-wide graph
+// product took 2.50 ms with a bias and 2.10 without, tools/spmm_act_probe.py.)  `vec_ok` = aligned16(bias), wave-uniform.
+__device__ __forceinline__ float4 load_bias4(const float* __restrict__ bias, int col0, int F, bool vec_ok) {
+    if (!bias) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec_ok && col0 + 3 < F) return *reinterpret_cast<const float4*>(bias + col0);
+    return make_float4(col0 < F ? bias[col0] : 0.f, col0 + 1 < F ? bias[col0 + 1] : 0.f, col0 + 2 < F ? bias[col0 + 2] : 0.f,
+                       col0 + 3 < F ? bias[col0 + 3] : 0.f);
+}
+
 // ---- Philox4x32-10 (Salmon et al. 2011): the dropout streams (elementwise.hip; fused epilogue of spmm_hot.hip) ----------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;

@@ -174,14 +174,16 @@ __device__ __forceinline__ void group_accumulate(int s, int e, int lane16, int n
 }
 
 template <int ACT>
-__device__ __forceinline__ float4 epilogue4(float4 r, int col0, int F, const float* __restrict__ bias) {
+__device__ __forceinline__ float4 epilogue4(float4 r, int col0, int F, const float* __restrict__ bias, bool bias_vec) {
     float o[4] = {r.x, r.y, r.z, r.w};
+    const float4 b4 = load_bias4(bias, col0, F, bias_vec);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = col0 + i;
         if (col < F) {
             float x = o[i];
-            if (bias) x += bias[col];
+            if (bias) x += bb[i];
             o[i] = apply_act<ACT>(x);
         } else {
             o[i] = 0.f;             // keep pad columns zero (geogcn.h convention)
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     constexpr int kGpb = kRowBlock / G;       // groups (= rows, = chunks) per block
     const int lane16 = threadIdx.x % G;
     const int nF4 = (F + 3) >> 2;
+    const bool bias_vec = (reinterpret_cast<uintptr_t>(bias) & 15u) == 0;
     float4 acc[K4];
 #pragma unroll
     for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -291,13 +294,15 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
         for (int k = 0; k < K4; ++k) {
             const int q = f4_index<G, BF>(lane16, k);
             const float a4[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+            const float4 b4 = q < nF4 ? load_bias4(bias, q * 4, F, bias_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int col = q * 4 + i;
                 float x = -INFINITY;
                 if (q < nF4 && col < F) {
                     x = a4[i];
-                    if (bias) x += bias[col];
+                    if (bias) x += bb[i];
                 }
                 v[k][i] = x;
                 if (x > m) { m = x; mi = col; }          // ascending columns within a lane: strict > keeps the first index
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(kRowBlock) void spmm_rows_kernel(
     for (int k = 0; k < K4; ++k) {
         const int q = f4_index<G, BF>(lane16, k);
         if (q < nF4) {
-            const float4 hc = epilogue4<ACT>(acc[k], q * 4, F, bias);
+            const float4 hc = epilogue4<ACT>(acc[k], q * 4, F, bias, bias_vec);
             out[q] = hc;
             if constexpr (HW == 1) {
 #ifdef GEOGCN_SPMM_HW_NT          // A/B build only: streaming cache policy for the epilogue's operands (1: T / H loads, 2: Hout store)

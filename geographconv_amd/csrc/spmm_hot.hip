@@ -233,12 +233,14 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_hot_kernel(const HotArgs a) 
             const int q = lane + kGroup * k;
             if (q < nF4) {
                 float o[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+                const float4 b4 = load_bias4(a.bias, q * 4, a.F, (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int col = q * 4 + i;
                     if (col < a.F) {
                         float x = o[i];
-                        if (a.bias) x += a.bias[col];
+                        if (a.bias) x += bb[i];
                         o[i] = apply_act<ACT>(x);
                     } else {
                         o[i] = 0.f;
