@@ -141,6 +141,36 @@ def test_spmm_highway_epilogue(dev, F, bf):
     assert torch.all(Hout.t[:, F:] == 0) and torch.all(Hc.t[:, F:] == 0)
 
 
+@pytest.mark.parametrize("F", [300, 129, 7])
+def test_spmm_bias_read_as_quads_or_scalars_gives_the_same_bits(dev, F):
+    """(round 6) The epilogues read their bias as one 16-byte load per float4 of the row where the quad lies inside the bias and the
+    vector is 16-byte aligned (csrc/common.h load_bias4), as scalars otherwise: a bias vector at an unaligned address (a view one
+    float into a buffer, exactly F floats long) gives the bits of the aligned, padded one -- plain product, highway epilogue,
+    softmax epilogue, the bf16 operand."""
+    from geographconv_amd import ops
+    A = _skewed_csr(3000, 2000, 5, hub_nnz=900)
+    dA = ops.CSR(A, dev)
+    B = ops.DMat.from_numpy(_rand((2000, F), 6), dev)
+    bias = _rand((F,), 7)
+    aligned = torch.zeros(ops.pad4(F) + 4, device=dev)
+    aligned[:F] = torch.from_numpy(bias).to(dev)
+    shifted = torch.full((F + 9,), float('nan'), device=dev)
+    shifted[1:1 + F] = torch.from_numpy(bias).to(dev)
+    un = shifted[1:1 + F]                                  # 4 bytes past a 16-byte boundary; NaN right behind its last element
+    assert un.data_ptr() % 16 == 4 and aligned.data_ptr() % 16 == 0
+    for Bop in (B, ops.cast_bf16(B)):
+        a = ops.spmm(dA, Bop, bias=aligned, act=ops.ACT_TANH)
+        b = ops.spmm(dA, Bop, bias=un, act=ops.ACT_TANH)
+        assert torch.equal(a.t, b.t) and torch.isfinite(b.t).all()
+    T = ops.DMat.from_numpy(O.sigmoid(_rand((3000, F), 8)).astype(np.float32), dev)
+    H = ops.DMat.from_numpy(_rand((3000, F), 9), dev)
+    h1 = ops.spmm_highway(dA, B, aligned, T, H)
+    h2 = ops.spmm_highway(dA, B, un, T, H)
+    assert torch.equal(h1[0].t, h2[0].t) and torch.equal(h1[1].t, h2[1].t)
+    if ops.spmm_softmax_ok(B, F):
+        assert torch.equal(ops.spmm_softmax(dA, B, aligned).t, ops.spmm_softmax(dA, B, un).t)
+
+
 def test_spmm_short_rows_bitwise_reproducible_and_sequential(dev):
     """Rows below the split threshold accumulate in stored order with fmaf: two runs are bitwise
     equal and equal to a sequential fp32 fma chain (checked via float64 emulation bound)."""
