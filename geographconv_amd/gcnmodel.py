@@ -772,8 +772,21 @@ class GraphConv():
                 l._calls_dev.fill_(l._calls)
         self._adam_state_dev[0:1].fill_(self.adam_t)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, 'captured')
+        # No garbage collection while the stream is capturing: a cyclic collection that happens to run inside the capture may finalise
+        # device objects of an EARLIER model (a captured graph, events, cached buffers) -- destroying those is not a capturable operation
+        # and the HIP runtime aborts the process (seen once in round 6: `Fatal Python error: Aborted`, "Garbage-collecting", in the GPU
+        # suite's fourth capture of a test that builds models in a loop).  torch.cuda.graph() collects once on entry; the capture
+        # itself then runs with the collector off.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph):
+                P, n_tr, n_dv = self._train_step(g, y_train, y_dev, A, train_indices, dev_indices, 'captured')
+        finally:
+            if gc_was_on:
+                gc.enable()
         # (the capture refers to the device index vectors: hold them, the content-keyed cache may drop its entries)
         keep = (self._device_indices(g['comm'], train_indices, y_train, g.get('ro')),
                 self._device_indices(g['comm'], dev_indices, y_dev, g.get('ro')))
